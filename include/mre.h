@@ -1,0 +1,126 @@
+/* mre.h -- C ABI of the MI355X batched RearrangementEnv physics step.
+ *
+ * The reference exposes no FFI for this path; its hot loop sits behind two
+ * Python object protocols:
+ *   - dm_control ``mjcf.Physics``: .step() / .forward() / .reset() /
+ *     .set_control(u) / .data.{qpos,qvel,time,site_xpos,contact}
+ *     (reference: mujoco_robot_environments/models/robot_arm.py:78-79,
+ *      environment/prop_initializer.py:190,221,250, tasks/rearrangement.py:302)
+ *   - mujoco_controllers ``OSC`` / ``MinMax``: set_target / compute_control_output /
+ *     is_converged / .status (models/robot_arm.py:71,73,83;
+ *     tasks/rearrangement.py:365-370,380,422)
+ * Each entry point below names the member it replaces, batched over
+ * ``num_envs`` independent environments (one 64-lane wavefront per env).
+ *
+ * Conventions
+ *   - return 0 on success, negative mre_status on error; message via
+ *     mre_last_error().  No exceptions cross the boundary.
+ *   - array arguments are BORROWED for the duration of the call; they may be
+ *     device pointers (e.g. torch.Tensor.data_ptr()) or host pointers
+ *     (copied with hipMemcpyDefault on the handle's stream).
+ *   - batched arrays are env-major rows: x[env][k] (one wavefront reads one
+ *     row with a single coalesced access).  fp32 on device.
+ *   - one handle <-> one host thread / HIP stream; calls are asynchronous on
+ *     that stream, mre_sync() / mre_get_* synchronise.
+ */
+#ifndef MRE_H
+#define MRE_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MRE_NQ 43      /* 7 arm + 8 gripper + 4 x 7 free-joint coordinates */
+#define MRE_NV 39
+#define MRE_NU 8       /* 7 arm motors + fingers_actuator */
+#define MRE_NQ_PAD 44  /* row stride of qpos arrays */
+#define MRE_NV_PAD 40  /* row stride of qvel / qacc arrays */
+#define MRE_MAX_PROPS 4
+
+typedef enum {
+  MRE_OK = 0,
+  MRE_ERR_ARG = -1,
+  MRE_ERR_MODEL = -2,   /* blob malformed or topology differs from the compiled kernels */
+  MRE_ERR_HIP = -3,
+  MRE_ERR_NOGPU = -4
+} mre_status;
+
+/* per-env status bits (mre_get_status); the reference raises exceptions instead
+ * (tasks/rearrangement.py:371-440, dm_control PhysicsError) */
+#define MRE_ST_NOT_CONVERGED 1u   /* arm outside OSC thresholds after run_controller */
+#define MRE_ST_NAN 2u             /* non-finite state detected */
+#define MRE_ST_CONTACT_OVERFLOW 4u /* contact / constraint-row capacity exceeded */
+
+typedef struct mre_env mre_env;
+
+/* mjcf.Physics.from_mjcf_model (tasks/rearrangement.py:181): model_blob is the
+ * output of mujoco_robot_environments_amd.model.compile.to_blob(). */
+int mre_create(const void* model_blob, size_t nbytes, int num_envs, int device_id, mre_env** out);
+int mre_destroy(mre_env*);
+const char* mre_last_error(void);
+int mre_num_envs(const mre_env*);
+/* raw HIP stream of the handle (hipStream_t as void*) for event timing */
+void* mre_stream(mre_env*);
+int mre_sync(mre_env*);
+
+/* per-env scene parameters: number of cubes (2..4, environment/props.py:604-607)
+ * and half sizes [N][4][3] (colour_splitter.yaml:3-4) */
+int mre_set_props(mre_env*, const int32_t* nprops, const float* prop_half_size);
+
+/* Physics.reset() + arm.set_joint_angles(home) (tasks/rearrangement.py:302-306):
+ * qpos = qpos0 with arm at home, qvel = 0, warm start = 0, time = 0.
+ * mask [N] (host or device, may be NULL = all). Props are parked; use
+ * mre_place_props() for PropPlacer. */
+int mre_reset(mre_env*, const uint8_t* mask);
+/* PropPlacer.__call__ (environment/prop_initializer.py:164-283): rejection
+ * sampling of cube poses in the workspace + settle with the robot frozen. */
+int mre_place_props(mre_env*, const uint8_t* mask, uint64_t seed, const float* ws_min,
+                    const float* ws_max, int max_attempts, int settle_steps);
+
+/* physics.bind(joints).qpos / .qvel access: rows [N][MRE_NQ_PAD] / [N][MRE_NV_PAD] */
+int mre_set_state(mre_env*, const float* qpos, const float* qvel);
+int mre_get_state(mre_env*, float* qpos, float* qvel);
+int mre_set_warmstart(mre_env*, const float* qacc_warmstart);
+int mre_get_warmstart(mre_env*, float* qacc_warmstart);
+/* Physics.set_control(u) (models/robot_arm.py:78): rows [N][MRE_NU] */
+int mre_set_ctrl(mre_env*, const float* ctrl);
+/* Physics.step() x nsubsteps with ctrl held (models/robot_arm.py:77-81);
+ * dm_control legacy order step2->step1 is preserved (results identical to
+ * nsubsteps reference steps).  flags: bit0 = disable constraints (test only),
+ * bit1 = freeze robot joints (JointStaticIsolator, prop_initializer.py:246). */
+int mre_step(mre_env*, int nsubsteps, unsigned flags);
+/* fused rollout: T control ticks, ctrl_seq[T][N][MRE_NU] resampled per tick,
+ * control_steps physics steps per tick (BASELINE config 2: random actions). */
+int mre_rollout(mre_env*, const float* ctrl_seq, int nticks, int control_steps, unsigned flags);
+/* optional trajectory capture for parity tests: qpos of the first `nenv` envs
+ * after every physics step -> out[step][nenv][MRE_NQ_PAD] (device or host).
+ * Pass NULL to disable. Applies to subsequent mre_step / mre_rollout / mre_run_controller. */
+int mre_set_trace(mre_env*, float* out, int nenv, int max_steps);
+
+/* OSC.set_target(position=, velocity=, quat=, angular_velocity=) -- any NULL keeps
+ * the previous value (tasks/rearrangement.py:365-375); rows [N][3|4]; mask [N] or NULL */
+int mre_osc_set_target(mre_env*, const float* pos, const float* quat, const float* vel,
+                       const float* angvel, const uint8_t* mask);
+/* OSC gains/thresholds (config/robots/arm/controller_config/osc.yaml:5-22):
+ * gains[6] = kp_pos,kd_pos,kp_ori,kd_ori,kp_null,kd_null; null_q[7]; thresholds[2] */
+int mre_osc_configure(mre_env*, const float* gains, const float* null_q, const float* thresholds,
+                      int pinv_always);
+/* MinMax.status = "max"/"min" (tasks/rearrangement.py:380,422): closed[N] 1 -> 255, 0 -> 0 */
+int mre_gripper_set(mre_env*, const uint8_t* closed);
+/* RobotArm.run_controller(duration) (models/robot_arm.py:61-94): nticks control
+ * ticks of (OSC + MinMax command, control_steps physics steps); converged_out[N]
+ * (uint8, device or host, may be NULL) = arm_converged flag. */
+int mre_run_controller(mre_env*, int nticks, int control_steps, uint8_t* converged_out);
+
+/* physics.data.site_xpos[pinch] (models/robot_arm.py:55-58), controller site pose,
+ * prop poses (props_info, tasks/rearrangement.py:245-246): rows [N][3], [N][7], [N][4][7] */
+int mre_get_sites(mre_env*, float* tcp_pos, float* eef_pose, float* prop_pose);
+int mre_get_status(mre_env*, uint32_t* status);
+/* telemetry: per-env [ncon, nefc, solver_iters, reserved] of the last step */
+int mre_get_solver_stats(mre_env*, int32_t* stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

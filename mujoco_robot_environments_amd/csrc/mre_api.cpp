@@ -1,0 +1,516 @@
+// mre_api.cpp -- host side of the C ABI declared in include/mre.h.
+// Owns the device buffers and the HIP stream of a batch of environments,
+// converts the model blob into the fp32 DevModel the kernels read, and
+// enqueues kernels.  No torch types; plain pointers and sizes only.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mre.h"
+#include "mre_dev.h"
+
+using namespace mre;
+
+extern "C" void mre_launch_step(const StepArgs* args, hipStream_t stream);
+extern "C" void mre_launch_reset(const DevModel* M, int N, float* qpos, float* qvel, float* qacc_ws,
+                                 float* ctrl, uint32_t* status, const uint8_t* mask,
+                                 hipStream_t stream);
+extern "C" void mre_launch_place(const StepArgs* args, const uint8_t* mask, uint64_t seed,
+                                 const float* ws, int max_attempts, hipStream_t stream);
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+#define HIPCHK(x)                                                                       \
+  do {                                                                                  \
+    hipError_t e_ = (x);                                                                \
+    if (e_ != hipSuccess)                                                               \
+      return fail(MRE_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_));         \
+  } while (0)
+
+struct mre_env {
+  int N = 0, device = 0;
+  hipStream_t stream = nullptr;
+  DevModel* dM = nullptr;
+  DevModel hM;
+  float *qpos = nullptr, *qvel = nullptr, *qacc_ws = nullptr, *ctrl = nullptr;
+  int* nprops = nullptr;
+  float* prop_size = nullptr;
+  float* osc_target = nullptr;
+  uint8_t* grip_closed = nullptr;
+  uint8_t* converged = nullptr;
+  uint8_t* mask = nullptr;
+  float* sites = nullptr;
+  uint32_t* status = nullptr;
+  int* stats = nullptr;
+  OscConfig osc;
+  float* trace = nullptr;
+  int trace_nenv = 0, trace_max = 0, trace_pos = 0;
+};
+
+// ------------------------------------------------------------------ blob parsing
+namespace {
+struct Blob {
+  const unsigned char* p;
+  size_t n;
+  bool find(const char* name, uint32_t* code, uint32_t* count, uint64_t* off) const {
+    uint32_t ne;
+    memcpy(&ne, p + 8, 4);
+    const unsigned char* t = p + 16;
+    for (uint32_t k = 0; k < ne; k++, t += 48)
+      if (strncmp((const char*)t, name, 32) == 0) {
+        memcpy(code, t + 32, 4); memcpy(count, t + 36, 4); memcpy(off, t + 40, 8);
+        return *off + (size_t)(*count) * (*code ? 8 : 4) <= n;
+      }
+    return false;
+  }
+  bool ints(const char* name, int* dst, int expect) const {
+    uint32_t c, cnt; uint64_t off;
+    if (!find(name, &c, &cnt, &off) || c != 0 || (int)cnt != expect) return false;
+    memcpy(dst, p + off, 4 * (size_t)cnt);
+    return true;
+  }
+  bool flts(const char* name, float* dst, int expect) const {
+    uint32_t c, cnt; uint64_t off;
+    if (!find(name, &c, &cnt, &off) || c != 1 || (int)cnt != expect) return false;
+    for (uint32_t k = 0; k < cnt; k++) {
+      double v;
+      memcpy(&v, p + off + 8 * (size_t)k, 8);
+      dst[k] = (float)v;
+    }
+    return true;
+  }
+};
+}  // namespace
+
+#define RI(name, dst, n) if (!b.ints(name, (int*)(dst), n)) return fail(MRE_ERR_MODEL, std::string("model entry ") + name)
+#define RF(name, dst, n) if (!b.flts(name, (float*)(dst), n)) return fail(MRE_ERR_MODEL, std::string("model entry ") + name)
+
+static int build_model(const void* blob, size_t nbytes, DevModel& m) {
+  if (nbytes < 16) return fail(MRE_ERR_MODEL, "blob too small");
+  Blob b{(const unsigned char*)blob, nbytes};
+  uint32_t magic;
+  memcpy(&magic, b.p, 4);
+  if (magic != 0x4D524542u) return fail(MRE_ERR_MODEL, "bad blob magic");
+  memset(&m, 0, sizeof(m));
+  int nbody, nv, nq, nM, ngeom, nsite, npair, neq, nprop, nu;
+  RI("nbody", &nbody, 1); RI("nv", &nv, 1); RI("nq", &nq, 1); RI("nM", &nM, 1); RI("ngeom", &ngeom, 1);
+  RI("nsite", &nsite, 1); RI("npair", &npair, 1); RI("neq", &neq, 1); RI("nprop", &nprop, 1);
+  RI("nu", &nu, 1);
+  if (nbody != NB || nv != NV || nq != NQ || ngeom != NG || nsite != NSITE || npair > NPAIR ||
+      neq != NEQ || nprop != NPROP || nu != NU)
+    return fail(MRE_ERR_MODEL, "scene dimensions differ from the compiled kernels");
+  RI("body_parentid", m.body_parent, NB); RI("body_jnttype", m.body_jnttype, NB);
+  RI("body_dofadr", m.body_dofadr, NB); RI("body_qposadr", m.body_qposadr, NB);
+  RI("body_propid", m.body_propid, NB);
+  RF("body_pos", m.body_pos, NB * 3); RF("body_quat", m.body_quat, NB * 4);
+  RF("body_ipos", m.body_ipos, NB * 3); RF("body_iquat", m.body_iquat, NB * 4);
+  RF("body_mass", m.body_mass, NB); RF("body_inertia", m.body_inertia, NB * 3);
+  RF("body_invweight0", m.body_invweight0, NB * 2);
+  RF("jnt_pos", m.jnt_pos, NB * 3); RF("jnt_axis", m.jnt_axis, NB * 3); RF("jnt_range", m.jnt_range, NB * 2);
+  RF("jnt_stiffness", m.jnt_stiffness, NB); RF("jnt_springref", m.jnt_springref, NB);
+  RF("jnt_solref", m.jnt_solref, NB * 2); RF("jnt_solimp", m.jnt_solimp, NB * 5);
+  RI("jnt_limited", m.jnt_limited, NB);
+  RI("dof_bodyid", m.dof_body, NV); RI("dof_parentid", m.dof_parent, NV); RI("dof_Madr", m.dof_Madr, NV);
+  m.dof_Madr[NV] = nM;
+  RF("dof_armature", m.dof_armature, NV); RF("dof_damping", m.dof_damping, NV);
+  RF("dof_invweight0", m.dof_invweight0, NV); RF("qpos0", m.qpos0, NQ);
+  RI("geom_type", m.geom_type, NG); RI("geom_bodyid", m.geom_body, NG); RI("geom_propid", m.geom_propid, NG);
+  RF("geom_size", m.geom_size, NG * 3); RF("geom_pos", m.geom_pos, NG * 3);
+  RF("geom_quat", m.geom_quat, NG * 4); RF("geom_rbound", m.geom_rbound, NG);
+  {
+    std::vector<int> pg(2 * npair);
+    RI("pair_geom", pg.data(), 2 * npair);
+    for (int k = 0; k < NPAIR; k++) { m.pair_g1[k] = -1; m.pair_g2[k] = -1; }
+    for (int k = 0; k < npair; k++) { m.pair_g1[k] = pg[2 * k]; m.pair_g2[k] = pg[2 * k + 1]; }
+  }
+  RF("pair_friction", m.pair_friction, npair * 3); RF("pair_solref", m.pair_solref, npair * 2);
+  RF("pair_solimp", m.pair_solimp, npair * 5); RF("pair_margin", m.pair_margin, npair);
+  RF("pair_gap", m.pair_gap, npair);
+  RI("site_bodyid", m.site_body, NSITE); RF("site_pos", m.site_pos, NSITE * 3);
+  RF("site_quat", m.site_quat, NSITE * 4);
+  RI("eef_site", &m.eef_site, 1); RI("tcp_site", &m.tcp_site, 1);
+  RI("eq_type", m.eq_type, NEQ); RI("eq_obj", m.eq_obj, NEQ * 2); RF("eq_data", m.eq_data, NEQ * 8);
+  RF("eq_solref", m.eq_solref, NEQ * 2); RF("eq_solimp", m.eq_solimp, NEQ * 5);
+  RI("ten_dof", m.ten_dof, 2); RF("ten_coef", m.ten_coef, 2);
+  RI("act_dof", m.act_dof, NU); RF("act_ctrlrange", m.act_ctrlrange, NU * 2);
+  RF("grip_gainprm", &m.grip_gainprm, 1); RF("grip_biasprm", m.grip_biasprm, 3);
+  RF("grip_forcerange", m.grip_forcerange, 2);
+  RF("opt_timestep", &m.timestep, 1); RF("opt_gravity", m.gravity, 3); RF("opt_impratio", &m.impratio, 1);
+  RF("opt_tolerance", &m.tolerance, 1); RI("opt_iterations", &m.iterations, 1);
+  RF("home_qpos", m.home_qpos, 7);
+  float M0d[NV];
+  RF("M0_diag", M0d, NV);
+
+  // ---- verify the topology the kernels assume: robot = bodies 1..15 with one hinge
+  // each (dof = body-1), cubes = bodies 16..19 with free joints (dofs 15+6p)
+  for (int bb = 1; bb < NB; bb++) {
+    bool ok = bb < NRB ? (m.body_jnttype[bb] == 1 && m.body_dofadr[bb] == bb - 1 && m.body_qposadr[bb] == bb - 1 &&
+                          m.body_propid[bb] < 0 && m.body_parent[bb] < bb)
+                       : (m.body_jnttype[bb] == 2 && m.body_dofadr[bb] == NRV + 6 * (bb - NRB) &&
+                          m.body_qposadr[bb] == NRV + 7 * (bb - NRB) && m.body_propid[bb] == bb - NRB &&
+                          m.body_parent[bb] == 0);
+    if (!ok) return fail(MRE_ERR_MODEL, "body layout differs from the compiled kernels");
+  }
+  if (m.dof_Madr[NRV] != NMR) return fail(MRE_ERR_MODEL, "robot mass-matrix size differs");
+  for (int a = 0; a < 7; a++)
+    if (m.act_dof[a] != a) return fail(MRE_ERR_MODEL, "arm actuators must drive dofs 0..6");
+
+  // ---- derived tables
+  m.body_level[0] = 0;
+  for (int bb = 1; bb < NB; bb++) m.body_level[bb] = m.body_level[m.body_parent[bb]] + 1;
+  for (int bb = 0; bb < NB; bb++) {
+    if (m.body_level[bb] > MAXCHAIN) return fail(MRE_ERR_MODEL, "tree deeper than MAXCHAIN");
+    m.body_desc_mask[bb] = 0;
+  }
+  for (int c = 1; c < NB; c++)
+    for (int a = c; a > 0; a = m.body_parent[a]) m.body_desc_mask[a] |= (1u << c);
+  m.robot_mass = 0;
+  for (int bb = 1; bb < NRB; bb++) {
+    m.robot_mass += m.body_mass[bb];
+    int chain[MAXCHAIN], n = 0;
+    for (int d = m.body_dofadr[bb]; d >= 0; d = m.dof_parent[d]) {
+      if (n >= MAXCHAIN) return fail(MRE_ERR_MODEL, "dof chain too long");
+      chain[n++] = d;
+    }
+    m.chain_len[bb] = n;
+    for (int k = 0; k < n; k++) m.chain_dof[bb][k] = chain[n - 1 - k];
+  }
+  for (int i = 0; i < NRV; i++) {
+    int adr = m.dof_Madr[i];
+    for (int j = i; j >= 0; j = m.dof_parent[j], adr++) { m.M_i[adr] = i; m.M_j[adr] = j; }
+    if (adr != m.dof_Madr[i + 1]) return fail(MRE_ERR_MODEL, "dof_Madr inconsistent");
+  }
+  for (int k = 0; k < NRV; k++) {
+    int anc[MAXCHAIN + 1], n = 0;
+    for (int j = m.dof_parent[k]; j >= 0; j = m.dof_parent[j]) anc[++n] = j;  // 1-based positions
+    int cnt = 0;
+    for (int p = 1; p <= n; p++)
+      for (int q = p; q <= n; q++) {
+        if (cnt >= MAXFAC) return fail(MRE_ERR_MODEL, "factor table overflow");
+        m.fac_dst[k][cnt] = (uint8_t)(m.dof_Madr[anc[p]] + (q - p));
+        m.fac_a[k][cnt] = (uint8_t)p;
+        m.fac_b[k][cnt] = (uint8_t)q;
+        cnt++;
+      }
+    m.fac_n[k] = cnt;
+  }
+  m.M0_diag_robot_sum = 0;
+  for (int i = 0; i < NRV; i++) m.M0_diag_robot_sum += M0d[i];
+  for (int p = 0; p < NPROP; p++) {  // same parking grid as the oracle's reset
+    m.park_pos[p][0] = 2.0f + 0.5f * p; m.park_pos[p][1] = 2.0f; m.park_pos[p][2] = -5.0f;
+  }
+  return MRE_OK;
+}
+
+// ------------------------------------------------------------------- lifecycle
+extern "C" const char* mre_last_error(void) { return g_err.c_str(); }
+
+extern "C" int mre_create(const void* blob, size_t nbytes, int num_envs, int device_id, mre_env** out) {
+  if (!blob || !out || num_envs <= 0) return fail(MRE_ERR_ARG, "mre_create: bad argument");
+  *out = nullptr;
+  mre_env* e = new mre_env();
+  int rc = build_model(blob, nbytes, e->hM);
+  if (rc != MRE_OK) { delete e; return rc; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    delete e;
+    return fail(MRE_ERR_NOGPU, "mre_create: no HIP device visible (the HIP path has no CPU fallback)");
+  }
+  e->N = num_envs;
+  e->device = device_id;
+  HIPCHK(hipSetDevice(device_id));
+  HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+  const size_t N = (size_t)num_envs;
+  HIPCHK(hipMalloc(&e->dM, sizeof(DevModel)));
+  HIPCHK(hipMemcpy(e->dM, &e->hM, sizeof(DevModel), hipMemcpyHostToDevice));
+  HIPCHK(hipMalloc(&e->qpos, N * NQP * 4)); HIPCHK(hipMalloc(&e->qvel, N * NVP * 4));
+  HIPCHK(hipMalloc(&e->qacc_ws, N * NVP * 4)); HIPCHK(hipMalloc(&e->ctrl, N * NU * 4));
+  HIPCHK(hipMalloc(&e->nprops, N * 4)); HIPCHK(hipMalloc(&e->prop_size, N * NPROP * 3 * 4));
+  HIPCHK(hipMalloc(&e->osc_target, N * 16 * 4)); HIPCHK(hipMalloc(&e->grip_closed, N));
+  HIPCHK(hipMalloc(&e->converged, N)); HIPCHK(hipMalloc(&e->mask, N));
+  HIPCHK(hipMalloc(&e->sites, N * 16 * 4));
+  HIPCHK(hipMalloc(&e->status, N * 4)); HIPCHK(hipMalloc(&e->stats, N * 4 * 4));
+  HIPCHK(hipMemset(e->status, 0, N * 4)); HIPCHK(hipMemset(e->stats, 0, N * 16));
+  HIPCHK(hipMemset(e->grip_closed, 0, N)); HIPCHK(hipMemset(e->osc_target, 0, N * 64));
+  HIPCHK(hipMemset(e->sites, 0, N * 64));
+  // defaults: 4 cubes of half size 0.0155
+  std::vector<int> np(N, NPROP);
+  std::vector<float> ps(N * NPROP * 3, 0.0155f);
+  HIPCHK(hipMemcpy(e->nprops, np.data(), N * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(e->prop_size, ps.data(), ps.size() * 4, hipMemcpyHostToDevice));
+  // OSC defaults (osc.yaml:5-22)
+  e->osc = OscConfig{350.f, 20.f, 500.f, 100.f, 200.f, 30.f, {0.f, -0.785f, 0.f, -2.356f, 0.f, 1.571f, 0.785f},
+                     5e-3f, 68e-3f, 0};
+  *out = e;
+  rc = mre_reset(e, nullptr);
+  if (rc != MRE_OK) return rc;
+  return mre_sync(e);
+}
+
+extern "C" int mre_destroy(mre_env* e) {
+  if (!e) return MRE_OK;
+  (void)hipSetDevice(e->device);
+  if (e->stream) (void)hipStreamSynchronize(e->stream);
+  void* ptrs[] = {e->dM, e->qpos, e->qvel, e->qacc_ws, e->ctrl, e->nprops, e->prop_size, e->osc_target,
+                  e->grip_closed, e->converged, e->mask, e->sites, e->status, e->stats};
+  for (void* p : ptrs) if (p) (void)hipFree(p);
+  if (e->stream) (void)hipStreamDestroy(e->stream);
+  delete e;
+  return MRE_OK;
+}
+
+extern "C" int mre_num_envs(const mre_env* e) { return e ? e->N : 0; }
+extern "C" void* mre_stream(mre_env* e) { return e ? (void*)e->stream : nullptr; }
+extern "C" int mre_sync(mre_env* e) {
+  if (!e) return fail(MRE_ERR_ARG, "null handle");
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return MRE_OK;
+}
+
+static int copy_in(mre_env* e, void* dst, const void* src, size_t n) {
+  HIPCHK(hipMemcpyAsync(dst, src, n, hipMemcpyDefault, e->stream));
+  return MRE_OK;
+}
+static int copy_out(mre_env* e, void* dst, const void* src, size_t n) {
+  HIPCHK(hipMemcpyAsync(dst, src, n, hipMemcpyDefault, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return MRE_OK;
+}
+// returns device mask pointer or nullptr
+static int stage_mask(mre_env* e, const uint8_t* mask, const uint8_t** dmask) {
+  *dmask = nullptr;
+  if (!mask) return MRE_OK;
+  int rc = copy_in(e, e->mask, mask, (size_t)e->N);
+  *dmask = e->mask;
+  return rc;
+}
+
+extern "C" int mre_set_props(mre_env* e, const int32_t* nprops, const float* prop_half_size) {
+  if (!e || !nprops || !prop_half_size) return fail(MRE_ERR_ARG, "mre_set_props: null");
+  int rc = copy_in(e, e->nprops, nprops, (size_t)e->N * 4);
+  if (rc) return rc;
+  return copy_in(e, e->prop_size, prop_half_size, (size_t)e->N * NPROP * 3 * 4);
+}
+
+extern "C" int mre_reset(mre_env* e, const uint8_t* mask) {
+  if (!e) return fail(MRE_ERR_ARG, "null handle");
+  const uint8_t* dmask;
+  int rc = stage_mask(e, mask, &dmask);
+  if (rc) return rc;
+  mre_launch_reset(e->dM, e->N, e->qpos, e->qvel, e->qacc_ws, e->ctrl, e->status, dmask, e->stream);
+  HIPCHK(hipGetLastError());
+  return MRE_OK;
+}
+
+extern "C" int mre_set_state(mre_env* e, const float* qpos, const float* qvel) {
+  if (!e) return fail(MRE_ERR_ARG, "null handle");
+  int rc = MRE_OK;
+  if (qpos) rc = copy_in(e, e->qpos, qpos, (size_t)e->N * NQP * 4);
+  if (!rc && qvel) rc = copy_in(e, e->qvel, qvel, (size_t)e->N * NVP * 4);
+  return rc;
+}
+extern "C" int mre_get_state(mre_env* e, float* qpos, float* qvel) {
+  if (!e) return fail(MRE_ERR_ARG, "null handle");
+  int rc = MRE_OK;
+  if (qpos) rc = copy_out(e, qpos, e->qpos, (size_t)e->N * NQP * 4);
+  if (!rc && qvel) rc = copy_out(e, qvel, e->qvel, (size_t)e->N * NVP * 4);
+  return rc;
+}
+extern "C" int mre_set_warmstart(mre_env* e, const float* w) {
+  if (!e || !w) return fail(MRE_ERR_ARG, "null");
+  return copy_in(e, e->qacc_ws, w, (size_t)e->N * NVP * 4);
+}
+extern "C" int mre_get_warmstart(mre_env* e, float* w) {
+  if (!e || !w) return fail(MRE_ERR_ARG, "null");
+  return copy_out(e, w, e->qacc_ws, (size_t)e->N * NVP * 4);
+}
+extern "C" int mre_set_ctrl(mre_env* e, const float* ctrl) {
+  if (!e || !ctrl) return fail(MRE_ERR_ARG, "null");
+  return copy_in(e, e->ctrl, ctrl, (size_t)e->N * NU * 4);
+}
+
+static void fill_args(mre_env* e, StepArgs& a) {
+  memset(&a, 0, sizeof(a));
+  a.M = e->dM; a.N = e->N;
+  a.qpos = e->qpos; a.qvel = e->qvel; a.qacc_ws = e->qacc_ws; a.ctrl = e->ctrl;
+  a.nprops = e->nprops; a.prop_size = e->prop_size;
+  a.control_steps = 1; a.mode = CTRL_HELD;
+  a.osc = e->osc; a.osc_target = e->osc_target; a.grip_closed = e->grip_closed;
+  a.sites = e->sites; a.status = e->status; a.stats = e->stats;
+  a.trace = e->trace; a.trace_nenv = e->trace_nenv; a.trace_max = e->trace_max; a.trace_base = e->trace_pos;
+}
+
+extern "C" int mre_step(mre_env* e, int nsubsteps, unsigned flags) {
+  if (!e || nsubsteps < 0) return fail(MRE_ERR_ARG, "mre_step: bad argument");
+  StepArgs a;
+  fill_args(e, a);
+  a.nsteps = nsubsteps; a.flags = flags;
+  mre_launch_step(&a, e->stream);
+  HIPCHK(hipGetLastError());
+  if (e->trace) e->trace_pos += nsubsteps;
+  return MRE_OK;
+}
+
+extern "C" int mre_rollout(mre_env* e, const float* ctrl_seq, int nticks, int control_steps, unsigned flags) {
+  if (!e || !ctrl_seq || nticks < 0 || control_steps < 1) return fail(MRE_ERR_ARG, "mre_rollout: bad argument");
+  hipPointerAttribute_t at;
+  if (hipPointerGetAttributes(&at, ctrl_seq) != hipSuccess || at.type != hipMemoryTypeDevice) {
+    (void)hipGetLastError();
+    return fail(MRE_ERR_ARG, "mre_rollout: ctrl_seq must be a device pointer");
+  }
+  StepArgs a;
+  fill_args(e, a);
+  a.nsteps = nticks * control_steps; a.control_steps = control_steps; a.mode = CTRL_SEQ;
+  a.ctrl_seq = ctrl_seq; a.flags = flags;
+  mre_launch_step(&a, e->stream);
+  HIPCHK(hipGetLastError());
+  if (e->trace) e->trace_pos += a.nsteps;
+  return MRE_OK;
+}
+
+extern "C" int mre_set_trace(mre_env* e, float* out, int nenv, int max_steps) {
+  if (!e) return fail(MRE_ERR_ARG, "null handle");
+  if (out) {
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, out) != hipSuccess || at.type != hipMemoryTypeDevice) {
+      (void)hipGetLastError();
+      return fail(MRE_ERR_ARG, "mre_set_trace: trace buffer must be a device pointer");
+    }
+    if (nenv <= 0 || nenv > e->N || max_steps <= 0) return fail(MRE_ERR_ARG, "mre_set_trace: bad sizes");
+  }
+  e->trace = out; e->trace_nenv = out ? nenv : 0; e->trace_max = out ? max_steps : 0; e->trace_pos = 0;
+  return MRE_OK;
+}
+
+extern "C" int mre_osc_configure(mre_env* e, const float* gains, const float* null_q, const float* thr,
+                                 int pinv_always) {
+  if (!e) return fail(MRE_ERR_ARG, "null handle");
+  if (gains) {
+    e->osc.kp_pos = gains[0]; e->osc.kd_pos = gains[1]; e->osc.kp_ori = gains[2];
+    e->osc.kd_ori = gains[3]; e->osc.kp_null = gains[4]; e->osc.kd_null = gains[5];
+  }
+  if (null_q) for (int k = 0; k < 7; k++) e->osc.null_q[k] = null_q[k];
+  if (thr) { e->osc.pos_thresh = thr[0]; e->osc.ori_thresh = thr[1]; }
+  e->osc.pinv_always = pinv_always;
+  return MRE_OK;
+}
+
+extern "C" int mre_gripper_set(mre_env* e, const uint8_t* closed) {
+  if (!e || !closed) return fail(MRE_ERR_ARG, "null");
+  return copy_in(e, e->grip_closed, closed, (size_t)e->N);
+}
+
+extern "C" int mre_get_sites(mre_env* e, float* tcp_pos, float* eef_pose, float* prop_pose) {
+  if (!e) return fail(MRE_ERR_ARG, "null handle");
+  // refresh site poses for the current state (0 physics steps = kinematics only)
+  StepArgs a;
+  fill_args(e, a);
+  a.nsteps = 0; a.trace = nullptr;
+  mre_launch_step(&a, e->stream);
+  HIPCHK(hipGetLastError());
+  const size_t N = (size_t)e->N;
+  std::vector<float> hs(N * 16), hq;
+  int rc = copy_out(e, hs.data(), e->sites, N * 64);
+  if (rc) return rc;
+  if (prop_pose) {
+    hq.resize(N * NQP);
+    rc = copy_out(e, hq.data(), e->qpos, N * NQP * 4);
+    if (rc) return rc;
+  }
+  // gather on the host into temporaries, then copy to the (host or device) destinations
+  std::vector<float> t3(N * 3), t7(N * 7), tp(N * NPROP * 7);
+  for (size_t i = 0; i < N; i++) {
+    for (int k = 0; k < 3; k++) t3[i * 3 + k] = hs[i * 16 + k];
+    for (int k = 0; k < 7; k++) t7[i * 7 + k] = hs[i * 16 + 3 + k];
+    if (prop_pose)
+      for (int p = 0; p < NPROP; p++)
+        for (int k = 0; k < 7; k++) tp[(i * NPROP + p) * 7 + k] = hq[i * NQP + NRV + 7 * p + k];
+  }
+  if (tcp_pos) { rc = copy_out(e, tcp_pos, t3.data(), N * 12); if (rc) return rc; }
+  if (eef_pose) { rc = copy_out(e, eef_pose, t7.data(), N * 28); if (rc) return rc; }
+  if (prop_pose) { rc = copy_out(e, prop_pose, tp.data(), N * NPROP * 28); if (rc) return rc; }
+  return MRE_OK;
+}
+
+extern "C" int mre_get_status(mre_env* e, uint32_t* status) {
+  if (!e || !status) return fail(MRE_ERR_ARG, "null");
+  return copy_out(e, status, e->status, (size_t)e->N * 4);
+}
+extern "C" int mre_get_solver_stats(mre_env* e, int32_t* stats) {
+  if (!e || !stats) return fail(MRE_ERR_ARG, "null");
+  return copy_out(e, stats, e->stats, (size_t)e->N * 16);
+}
+
+extern "C" int mre_osc_set_target(mre_env* e, const float* pos, const float* quat, const float* vel,
+                                  const float* angvel, const uint8_t* mask) {
+  if (!e) return fail(MRE_ERR_ARG, "null handle");
+  // small host-side merge: targets persist per env, NULL keeps the old value
+  const size_t N = (size_t)e->N;
+  std::vector<float> t(N * 16);
+  int rc = copy_out(e, t.data(), e->osc_target, N * 64);
+  if (rc) return rc;
+  std::vector<float> hp, hq, hv, hw;
+  std::vector<uint8_t> hm;
+  auto fetch = [&](const float* src, int w, std::vector<float>& dst) -> int {
+    if (!src) return MRE_OK;
+    dst.resize(N * w);
+    return copy_out(e, dst.data(), src, N * w * 4);
+  };
+  if ((rc = fetch(pos, 3, hp)) || (rc = fetch(quat, 4, hq)) || (rc = fetch(vel, 3, hv)) ||
+      (rc = fetch(angvel, 3, hw)))
+    return rc;
+  if (mask) { hm.resize(N); rc = copy_out(e, hm.data(), mask, N); if (rc) return rc; }
+  for (size_t i = 0; i < N; i++) {
+    if (mask && !hm[i]) continue;
+    float* r = &t[i * 16];
+    if (pos) for (int k = 0; k < 3; k++) r[k] = hp[i * 3 + k];
+    if (quat) for (int k = 0; k < 4; k++) r[3 + k] = hq[i * 4 + k];
+    if (vel) for (int k = 0; k < 3; k++) r[7 + k] = hv[i * 3 + k];
+    if (angvel) for (int k = 0; k < 3; k++) r[10 + k] = hw[i * 3 + k];
+  }
+  rc = copy_in(e, e->osc_target, t.data(), N * 64);
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(e->stream));  // t goes out of scope
+  return MRE_OK;
+}
+
+extern "C" int mre_run_controller(mre_env* e, int nticks, int control_steps, uint8_t* converged_out) {
+  if (!e || nticks < 0 || control_steps < 1) return fail(MRE_ERR_ARG, "mre_run_controller: bad argument");
+  StepArgs a;
+  fill_args(e, a);
+  a.nsteps = nticks * control_steps; a.control_steps = control_steps; a.mode = CTRL_OSC;
+  a.converged = e->converged;
+  mre_launch_step(&a, e->stream);
+  HIPCHK(hipGetLastError());
+  if (e->trace) e->trace_pos += a.nsteps;
+  if (converged_out) return copy_out(e, converged_out, e->converged, (size_t)e->N);
+  return MRE_OK;
+}
+
+extern "C" int mre_place_props(mre_env* e, const uint8_t* mask, uint64_t seed, const float* ws_min,
+                               const float* ws_max, int max_attempts, int settle_steps) {
+  if (!e || !ws_min || !ws_max) return fail(MRE_ERR_ARG, "mre_place_props: null");
+  const uint8_t* dmask;
+  int rc = stage_mask(e, mask, &dmask);
+  if (rc) return rc;
+  float ws[6] = {ws_min[0], ws_min[1], ws_min[2], ws_max[0], ws_max[1], ws_max[2]};
+  StepArgs a;
+  fill_args(e, a);
+  a.trace = nullptr;
+  mre_launch_place(&a, dmask, seed, ws, max_attempts, e->stream);
+  HIPCHK(hipGetLastError());
+  // settle with the robot frozen (JointStaticIsolator); fixed count keeps envs in lockstep
+  if (settle_steps > 0) {
+    a.nsteps = settle_steps; a.flags = F_FREEZE_ROBOT;
+    mre_launch_step(&a, e->stream);
+    HIPCHK(hipGetLastError());
+  }
+  return MRE_OK;
+}

@@ -1,0 +1,111 @@
+// mre_dev.h -- device-side model constants and compile-time dimensions of the
+// RearrangementEnv scene (fp32).  Filled on the host by mre_api.cpp from the
+// model blob (mujoco_robot_environments_amd/model/compile.py) and uploaded once.
+#pragma once
+#include <stdint.h>
+
+namespace mre {
+
+// Scene topology the kernels are specialised for (verified against the blob
+// in mre_create; mismatch -> MRE_ERR_MODEL).
+constexpr int NB = 20;     // bodies incl. world: 7 arm + 8 gripper + 4 cubes
+constexpr int NRB = 16;    // world + robot bodies (ids 0..15)
+constexpr int NV = 39;
+constexpr int NRV = 15;    // robot dofs (ids 0..14), cube p owns dofs 15+6p..
+constexpr int NQ = 43;
+constexpr int NQP = 44;    // padded qpos row
+constexpr int NVP = 40;    // padded qvel row
+constexpr int NU = 8;
+constexpr int NPROP = 4;
+constexpr int NG = 16;     // geoms
+constexpr int NPAIR = 64;  // static collision pair table: one lane per pair
+constexpr int NMR = 96;    // entries of the robot block of the sparse mass matrix
+constexpr int NSITE = 2;
+constexpr int NEQ = 3;
+constexpr int MAXCHAIN = 9;   // longest dof chain root->leaf (7 arm + 2 finger)
+constexpr int MAXFAC = 45;    // (i,j) ancestor pairs touched by one elimination step
+constexpr int NCON_MAX = 36;  // active contacts kept per env
+constexpr int NEFC_MAX = 128; // constraint rows per env
+constexpr int NRROW_MAX = 64; // rows with a robot part
+
+struct DevModel {
+  // ---- bodies (index = body id)
+  int body_parent[NB], body_level[NB], body_jnttype[NB], body_dofadr[NB], body_qposadr[NB];
+  int body_propid[NB];
+  unsigned body_desc_mask[NB];   // bit c set: body c is in the subtree of b (incl. b)
+  int chain_len[NB];             // dofs root->body (robot bodies; cubes: 0, handled apart)
+  int chain_dof[NB][MAXCHAIN];
+  float body_pos[NB][3], body_quat[NB][4], body_ipos[NB][3], body_iquat[NB][4];
+  float body_mass[NB], body_inertia[NB][3], body_invweight0[NB][2];
+  float jnt_pos[NB][3], jnt_axis[NB][3], jnt_range[NB][2], jnt_stiffness[NB], jnt_springref[NB];
+  float jnt_solref[NB][2], jnt_solimp[NB][5];
+  int jnt_limited[NB];
+  // ---- dofs
+  int dof_body[NV], dof_parent[NV], dof_Madr[NV + 1];
+  float dof_armature[NV], dof_damping[NV], dof_invweight0[NV], qpos0[NQP];
+  // ---- robot mass-matrix structure
+  int M_i[NMR], M_j[NMR];        // entry e = M(i, j), j ancestor-or-self of i
+  int fac_n[NRV];                // elimination step k: number of (i,j) updates
+  uint8_t fac_dst[NRV][MAXFAC], fac_a[NRV][MAXFAC], fac_b[NRV][MAXFAC];
+  float robot_mass;              // sum of robot body masses (subtree mass of link1)
+  float M0_diag_robot_sum;       // sum_i M0(i,i) over robot dofs (meaninertia)
+  // ---- geoms / pairs / sites
+  int geom_type[NG], geom_body[NG], geom_propid[NG];
+  float geom_size[NG][3], geom_pos[NG][3], geom_quat[NG][4], geom_rbound[NG];
+  int pair_g1[NPAIR], pair_g2[NPAIR];
+  float pair_friction[NPAIR][3], pair_solref[NPAIR][2], pair_solimp[NPAIR][5];
+  float pair_margin[NPAIR], pair_gap[NPAIR];
+  int site_body[NSITE];
+  float site_pos[NSITE][3], site_quat[NSITE][4];
+  int eef_site, tcp_site;
+  // ---- equality / tendon / actuation
+  int eq_type[NEQ], eq_obj[NEQ][2];
+  float eq_data[NEQ][8], eq_solref[NEQ][2], eq_solimp[NEQ][5];
+  int ten_dof[2];
+  float ten_coef[2];
+  int act_dof[NU];
+  float act_ctrlrange[NU][2], grip_gainprm, grip_biasprm[3], grip_forcerange[2];
+  // ---- options
+  float timestep, gravity[3], impratio, tolerance;
+  int iterations;
+  float home_qpos[7];
+  float park_pos[NPROP][3];      // where inactive cube slots are parked
+};
+
+// OSC controller parameters (config/robots/arm/controller_config/osc.yaml:5-22)
+struct OscConfig {
+  float kp_pos, kd_pos, kp_ori, kd_ori, kp_null, kd_null;
+  float null_q[7];
+  float pos_thresh, ori_thresh;
+  int pinv_always;
+};
+
+enum StepFlags : unsigned { F_NO_CONSTRAINTS = 1u, F_FREEZE_ROBOT = 2u };
+enum CtrlMode : int { CTRL_HELD = 0, CTRL_SEQ = 1, CTRL_OSC = 2 };
+
+struct StepArgs {
+  const DevModel* M;
+  int N;
+  float* qpos;            // [N][NQP]
+  float* qvel;            // [N][NVP]
+  float* qacc_ws;         // [N][NVP]
+  float* ctrl;            // [N][NU]  (held control / last applied control)
+  const float* ctrl_seq;  // [T][N][NU] or null
+  const int* nprops;      // [N]
+  const float* prop_size; // [N][NPROP][3]
+  int nsteps, control_steps, mode;
+  unsigned flags;
+  // OSC
+  OscConfig osc;
+  const float* osc_target;   // [N][16]: pos3 quat4 vel3 angvel3 pad3
+  const uint8_t* grip_closed;  // [N]
+  uint8_t* converged;        // [N] or null
+  // outputs
+  float* sites;              // [N][16]: tcp_pos3, eef_pos3, eef_quat4, pad
+  uint32_t* status;          // [N]
+  int* stats;                // [N][4]
+  float* trace;              // [max_steps][trace_nenv][NQP] or null
+  int trace_nenv, trace_max, trace_base;
+};
+
+}  // namespace mre

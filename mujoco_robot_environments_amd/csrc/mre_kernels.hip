@@ -1,0 +1,525 @@
+// mre_kernels.hip -- gfx950 (MI355X) kernels for the batched RearrangementEnv step.
+//
+// One environment per 64-lane wavefront (block = 64 threads), whole per-env
+// working set in LDS, state rows read/written once per launch with coalesced
+// accesses.  A launch runs `nsteps` physics steps of dt = 1 ms:
+//     per step:  S1 (position + velocity stage)  ->  [control at tick boundary]
+//                -> S2 (actuation, smooth acceleration, constraint solve, integrate)
+// which is the reference's dm_control legacy step (mj_step2 then mj_step1,
+// models/robot_arm.py:77-81) with the trailing mj_step1 of step k evaluated at
+// the head of step k+1 (same state, same result).
+//
+// Lane mappings: lane = body for tree quantities, lane = dof for generalized
+// vectors, lane = mass-matrix entry for CRB, lane = (i,j) pair for the sparse
+// L'DL elimination step, lane = collision pair for the narrow phase,
+// lane = constraint row for assembly.
+#include <hip/hip_runtime.h>
+
+#include "mre_dev.h"
+#include "mre_math.h"
+
+namespace mre {
+
+struct Sm {
+  // state
+  float qpos[NQP], qvel[NVP], qacc_ws[NVP], ctrl[NU];
+  // generalized vectors
+  float qfrc_smooth[NVP], qacc_smooth[NVP], qacc[NVP], qfrc_bias[NVP], qfrc_con[NVP];
+  // body frames
+  float xpos[NB][3], xquat[NB][4], xmat[NB][9];
+  float cinert[NB][10], crb[NB][10];
+  float cdof[NV][6], cdof_dot[NV][6];
+  float cvel[NB][6], cfrc[NB][6];
+  float com_robot[3];
+  float site_xpos[NSITE][3], site_xmat[NSITE][9];
+  // robot block of the sparse mass matrix and its factors
+  float qM[NMR], qLD[NMR], qLDinv[NRV + 1], qH[NMR], qHinv[NRV + 1];
+  // per-env cube constants
+  float prop_mass[NPROP], prop_inertia[NPROP][3], prop_size[NPROP][3];
+  float scratch[64];
+  int nprops;
+};
+
+struct BodyRegs {
+  float anchor[3], axis[3], xipos[3], ximat[9];
+};
+
+MRE_DEV bool body_is_active(const DevModel* M, const Sm& s, int b) {
+  int p = M->body_propid[b];
+  return p < 0 || p < s.nprops;
+}
+
+// ------------------------------------------------------------ mj_kinematics
+MRE_DEV void kinematics(const DevModel* M, Sm& s, int l, BodyRegs& br) {
+  if (l == 0) {
+    v3zero(s.xpos[0]);
+    s.xquat[0][0] = 1.f; s.xquat[0][1] = s.xquat[0][2] = s.xquat[0][3] = 0.f;
+    for (int k = 0; k < 9; k++) s.xmat[0][k] = (k % 4 == 0) ? 1.f : 0.f;
+  }
+  __syncthreads();
+  const int lvl = (l < NB) ? M->body_level[l] : -1;
+  for (int level = 1; level <= MAXCHAIN; ++level) {
+    if (lvl == level) {
+      const int b = l, qa = M->body_qposadr[b];
+      float xp[3], xq[4];
+      if (M->body_jnttype[b] == 2) {
+        v3copy(xp, &s.qpos[qa]);
+        for (int k = 0; k < 4; k++) xq[k] = s.qpos[qa + 3 + k];
+        qnormalize(xq);
+        for (int k = 0; k < 4; k++) s.qpos[qa + 3 + k] = xq[k];
+        v3copy(br.anchor, xp);
+        br.axis[0] = 0.f; br.axis[1] = 0.f; br.axis[2] = 1.f;
+      } else {
+        const int p = M->body_parent[b];
+        float tmp[3], q0[4], ql[4];
+        m3mulv(tmp, s.xmat[p], M->body_pos[b]);
+        v3add(xp, s.xpos[p], tmp);
+        qmul(q0, s.xquat[p], M->body_quat[b]);
+        qrotv(tmp, q0, M->jnt_pos[b]);
+        v3add(br.anchor, xp, tmp);
+        qrotv(br.axis, q0, M->jnt_axis[b]);
+        axisangle2q(ql, M->jnt_axis[b], s.qpos[qa] - M->qpos0[qa]);
+        qmul(xq, q0, ql);
+        qnormalize(xq);
+        qrotv(tmp, xq, M->jnt_pos[b]);
+        v3sub(xp, br.anchor, tmp);
+      }
+      float xm[9], qi[4], tmp[3];
+      q2mat(xm, xq);
+      v3copy(s.xpos[b], xp);
+      for (int k = 0; k < 4; k++) s.xquat[b][k] = xq[k];
+      for (int k = 0; k < 9; k++) s.xmat[b][k] = xm[k];
+      m3mulv(tmp, xm, M->body_ipos[b]);
+      v3add(br.xipos, xp, tmp);
+      qmul(qi, xq, M->body_iquat[b]);
+      q2mat(br.ximat, qi);
+    }
+    __syncthreads();
+  }
+  // sites (lane = site)
+  if (l < NSITE) {
+    const int b = M->site_body[l];
+    float tmp[3], q[4];
+    m3mulv(tmp, s.xmat[b], M->site_pos[l]);
+    v3add(s.site_xpos[l], s.xpos[b], tmp);
+    qmul(q, s.xquat[b], M->site_quat[l]);
+    q2mat(s.site_xmat[l], q);
+  }
+}
+
+// ---------------------------------------------------------------- mj_comPos
+MRE_DEV void com_pos(const DevModel* M, Sm& s, int l, const BodyRegs& br) {
+  const bool robot = (l >= 1 && l < NRB);
+  float mass = 0.f;
+  if (l < NB) mass = (M->body_propid[l] >= 0) ? s.prop_mass[M->body_propid[l]] : M->body_mass[l];
+  float c0 = robot ? mass * br.xipos[0] : 0.f;
+  float c1 = robot ? mass * br.xipos[1] : 0.f;
+  float c2 = robot ? mass * br.xipos[2] : 0.f;
+  c0 = wave_sum(c0); c1 = wave_sum(c1); c2 = wave_sum(c2);
+  const float inv = 1.0f / M->robot_mass;
+  float com[3] = {c0 * inv, c1 * inv, c2 * inv};
+  if (l == 0) v3copy(s.com_robot, com);
+  if (l >= 1 && l < NB) {
+    const int b = l, pid = M->body_propid[b];
+    if (pid >= 0) v3copy(com, br.xipos);  // each cube is its own tree: subtree COM = own COM
+    float inertia[3];
+    if (pid >= 0) v3copy(inertia, s.prop_inertia[pid]); else v3copy(inertia, M->body_inertia[b]);
+    float dif[3], tmp[9];
+    v3sub(dif, br.xipos, com);
+    const float* mat = br.ximat;
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int c = 0; c < 3; c++)
+        tmp[3 * r + c] = mat[3 * r] * inertia[0] * mat[3 * c] + mat[3 * r + 1] * inertia[1] * mat[3 * c + 1] +
+                         mat[3 * r + 2] * inertia[2] * mat[3 * c + 2];
+    float* ci = s.cinert[b];
+    ci[0] = tmp[0] + mass * (dif[1] * dif[1] + dif[2] * dif[2]);
+    ci[1] = tmp[4] + mass * (dif[0] * dif[0] + dif[2] * dif[2]);
+    ci[2] = tmp[8] + mass * (dif[0] * dif[0] + dif[1] * dif[1]);
+    ci[3] = tmp[1] - mass * dif[0] * dif[1];
+    ci[4] = tmp[2] - mass * dif[0] * dif[2];
+    ci[5] = tmp[5] - mass * dif[1] * dif[2];
+    ci[6] = mass * dif[0]; ci[7] = mass * dif[1]; ci[8] = mass * dif[2]; ci[9] = mass;
+    // cdof (mju_dofCom)
+    const int da = M->body_dofadr[b];
+    float off[3];
+    v3sub(off, com, br.anchor);
+    if (pid < 0) {
+      v3copy(s.cdof[da], br.axis);
+      v3cross(s.cdof[da] + 3, br.axis, off);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        float* t = s.cdof[da + k];
+        t[0] = t[1] = t[2] = 0.f; t[3] = t[4] = t[5] = 0.f;
+        t[3 + k] = 1.f;
+        float ax[3] = {s.xmat[b][k], s.xmat[b][3 + k], s.xmat[b][6 + k]};
+        v3copy(s.cdof[da + 3 + k], ax);
+        v3cross(s.cdof[da + 3 + k] + 3, ax, off);
+      }
+    }
+  }
+  if (l == 0) for (int k = 0; k < 10; k++) s.cinert[0][k] = 0.f;
+}
+
+// ------------------------------------------------------- mj_crb (robot block)
+MRE_DEV void crb_mass_matrix(const DevModel* M, Sm& s, int l) {
+  if (l >= 1 && l < NRB) {
+    const unsigned mask = M->body_desc_mask[l];
+    float acc[10];
+#pragma unroll
+    for (int k = 0; k < 10; k++) acc[k] = s.cinert[l][k];
+    for (int c = l + 1; c < NRB; c++)
+      if (mask & (1u << c)) {
+#pragma unroll
+        for (int k = 0; k < 10; k++) acc[k] += s.cinert[c][k];
+      }
+#pragma unroll
+    for (int k = 0; k < 10; k++) s.crb[l][k] = acc[k];
+  }
+  __syncthreads();
+  for (int e = l; e < NMR; e += 64) {
+    const int i = M->M_i[e], j = M->M_j[e];
+    float buf[6];
+    mul_inert_vec(buf, s.crb[M->dof_body[i]], s.cdof[i]);
+    float v = dot6(s.cdof[j], buf);
+    if (i == j) v += M->dof_armature[i];
+    s.qM[e] = v;
+  }
+}
+
+// sparse L'DL of the robot block: elimination steps k = NRV-1..0, lane = (i,j) update
+MRE_DEV void factor_robot(const DevModel* M, float* LD, float* dinv, int l) {
+  for (int k = NRV - 1; k >= 0; --k) {
+    const int akk = M->dof_Madr[k];
+    const int nup = M->fac_n[k];
+    const int nanc = M->dof_Madr[k + 1] - akk - 1;
+    const float dkk = LD[akk];
+    float a = 0.f, b = 0.f, old = 0.f;
+    int dst = -1;
+    if (l < nup) {
+      dst = M->fac_dst[k][l];
+      a = LD[akk + M->fac_a[k][l]];
+      b = LD[akk + M->fac_b[k][l]];
+      old = LD[dst];
+    }
+    float sc = 0.f;
+    const int ls = l - MAXFAC;
+    if (ls >= 0 && ls < nanc) sc = LD[akk + 1 + ls];
+    __syncthreads();
+    const float inv = 1.0f / dkk;
+    if (dst >= 0) LD[dst] = old - (a * inv) * b;
+    if (ls >= 0 && ls < nanc) LD[akk + 1 + ls] = sc * inv;
+    if (l == 0) dinv[k] = inv;
+    __syncthreads();
+  }
+}
+
+// x <- M^-1 x on the robot block (serial, one lane; x lives in LDS)
+MRE_DEV void solve_robot_serial(const DevModel* M, const float* LD, const float* dinv, float* x) {
+  for (int i = NRV - 1; i >= 0; --i) {
+    const float xi = x[i];
+    int a = M->dof_Madr[i] + 1;
+    for (int j = M->dof_parent[i]; j >= 0; j = M->dof_parent[j]) x[j] -= LD[a++] * xi;
+  }
+  for (int i = 0; i < NRV; ++i) x[i] *= dinv[i];
+  for (int i = 0; i < NRV; ++i) {
+    int a = M->dof_Madr[i] + 1;
+    float xi = x[i];
+    for (int j = M->dof_parent[i]; j >= 0; j = M->dof_parent[j]) xi -= LD[a++] * x[j];
+    x[i] = xi;
+  }
+}
+
+// ------------------------------------------------ mj_comVel + mj_rne + mj_passive
+MRE_DEV void velocity_stage(const DevModel* M, Sm& s, int l) {
+  // cvel, cdof_dot (lane = body; each lane re-accumulates its chain prefix)
+  float cv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (l >= 1 && l < NB) {
+    const int b = l;
+    if (M->body_propid[b] < 0) {
+      const int n = M->chain_len[b];
+      for (int k = 0; k < n; k++) {
+        const int j = M->chain_dof[b][k];
+        if (k == n - 1) cross_motion(s.cdof_dot[j], cv, s.cdof[j]);
+        const float qv = s.qvel[j];
+#pragma unroll
+        for (int t = 0; t < 6; t++) cv[t] += s.cdof[j][t] * qv;
+      }
+    } else {
+      const int da = M->body_dofadr[b];
+      for (int j = 0; j < 3; j++) {
+        for (int t = 0; t < 6; t++) s.cdof_dot[da + j][t] = 0.f;
+        const float qv = s.qvel[da + j];
+        for (int t = 0; t < 6; t++) cv[t] += s.cdof[da + j][t] * qv;
+      }
+      for (int j = 3; j < 6; j++) cross_motion(s.cdof_dot[da + j], cv, s.cdof[da + j]);
+      for (int j = 3; j < 6; j++) {
+        const float qv = s.qvel[da + j];
+        for (int t = 0; t < 6; t++) cv[t] += s.cdof[da + j][t] * qv;
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 6; t++) s.cvel[b][t] = cv[t];
+  }
+  __syncthreads();
+  // cacc, cfrc_body (lane = body)
+  if (l >= 1 && l < NB) {
+    const int b = l;
+    float ca[6] = {0.f, 0.f, 0.f, -M->gravity[0], -M->gravity[1], -M->gravity[2]};
+    if (M->body_propid[b] < 0) {
+      const int n = M->chain_len[b];
+      for (int k = 0; k < n; k++) {
+        const int j = M->chain_dof[b][k];
+        const float qv = s.qvel[j];
+#pragma unroll
+        for (int t = 0; t < 6; t++) ca[t] += s.cdof_dot[j][t] * qv;
+      }
+    } else {
+      const int da = M->body_dofadr[b];
+      for (int j = 3; j < 6; j++) {
+        const float qv = s.qvel[da + j];
+        for (int t = 0; t < 6; t++) ca[t] += s.cdof_dot[da + j][t] * qv;
+      }
+    }
+    float t0[6], t1[6], f[6];
+    mul_inert_vec(t0, s.cinert[b], cv);
+    cross_force(t1, cv, t0);
+    mul_inert_vec(f, s.cinert[b], ca);
+#pragma unroll
+    for (int t = 0; t < 6; t++) s.cfrc[b][t] = f[t] + t1[t];
+  }
+  __syncthreads();
+  // qfrc_bias (lane = dof): cdof . sum of cfrc over the subtree of the dof's body
+  if (l < NV) {
+    const int b = M->dof_body[l];
+    float tot[6];
+#pragma unroll
+    for (int t = 0; t < 6; t++) tot[t] = s.cfrc[b][t];
+    if (b < NRB) {
+      const unsigned mask = M->body_desc_mask[b];
+      for (int c = b + 1; c < NRB; c++)
+        if (mask & (1u << c)) {
+#pragma unroll
+          for (int t = 0; t < 6; t++) tot[t] += s.cfrc[c][t];
+        }
+    }
+    const bool act = body_is_active(M, s, b);
+    s.qfrc_bias[l] = act ? dot6(s.cdof[l], tot) : 0.f;
+  }
+}
+
+// ------------------------- mj_fwdActuation + mj_passive + mj_fwdAcceleration
+// returns (wave-uniform) whether the finger actuator force is clamped
+MRE_DEV bool smooth_forces(const DevModel* M, Sm& s, int l) {
+  const float ten_len = M->ten_coef[0] * s.qpos[M->ten_dof[0]] + M->ten_coef[1] * s.qpos[M->ten_dof[1]];
+  const float ten_vel = M->ten_coef[0] * s.qvel[M->ten_dof[0]] + M->ten_coef[1] * s.qvel[M->ten_dof[1]];
+  const float cg = clampf(s.ctrl[NU - 1], M->act_ctrlrange[NU - 1][0], M->act_ctrlrange[NU - 1][1]);
+  float fg = M->grip_gainprm * cg + M->grip_biasprm[0] + M->grip_biasprm[1] * ten_len + M->grip_biasprm[2] * ten_vel;
+  bool clamped = false;
+  if (fg <= M->grip_forcerange[0]) { fg = M->grip_forcerange[0]; clamped = true; }
+  if (fg >= M->grip_forcerange[1]) { fg = M->grip_forcerange[1]; clamped = true; }
+  if (l < NV) {
+    const int b = M->dof_body[l];
+    float f = 0.f;
+    if (b < NRB) {
+      // passive: spring + damper of the hinge
+      f = -M->jnt_stiffness[b] * (s.qpos[l] - M->jnt_springref[b]) - M->dof_damping[l] * s.qvel[l];
+      if (l < 7) f += clampf(s.ctrl[l], M->act_ctrlrange[l][0], M->act_ctrlrange[l][1]);
+      if (l == M->ten_dof[0]) f += M->ten_coef[0] * fg;
+      if (l == M->ten_dof[1]) f += M->ten_coef[1] * fg;
+    }
+    const bool act = body_is_active(M, s, b);
+    f = act ? f - s.qfrc_bias[l] : 0.f;
+    s.qfrc_smooth[l] = f;
+    s.qacc_smooth[l] = f;
+  }
+  __syncthreads();
+  if (l == 0) solve_robot_serial(M, s.qLD, s.qLDinv, s.qacc_smooth);
+  if (l >= NRV && l < NV) {
+    const int p = (l - NRV) / 6, k = (l - NRV) % 6;
+    const float md = (k < 3) ? s.prop_mass[p] : s.prop_inertia[p][k - 3];
+    s.qacc_smooth[l] = s.qacc_smooth[l] / md;
+  }
+  __syncthreads();
+  return clamped;
+}
+
+// ------------------------------------------- mj_implicit (implicitfast) + advance
+MRE_DEV void integrate(const DevModel* M, Sm& s, int l, bool grip_clamped, unsigned flags) {
+  const float h = M->timestep;
+  if (l < NVP) s.qacc_ws[l] = (l < NV) ? s.qacc[l] : 0.f;
+  // MH = M - h*dF/dv restricted to M's pattern (diagonal terms only here)
+  for (int e = l; e < NMR; e += 64) {
+    float v = s.qM[e];
+    const int i = M->M_i[e];
+    if (i == M->M_j[e]) {
+      v += h * M->dof_damping[i];
+      if (!grip_clamped) {
+        if (i == M->ten_dof[0]) v -= h * M->grip_biasprm[2] * M->ten_coef[0] * M->ten_coef[0];
+        if (i == M->ten_dof[1]) v -= h * M->grip_biasprm[2] * M->ten_coef[1] * M->ten_coef[1];
+      }
+    }
+    s.qH[e] = v;
+  }
+  if (l < NRV) s.scratch[l] = s.qfrc_smooth[l] + s.qfrc_con[l];
+  __syncthreads();
+  factor_robot(M, s.qH, s.qHinv, l);
+  if (l == 0) solve_robot_serial(M, s.qH, s.qHinv, s.scratch);
+  __syncthreads();
+  const bool freeze = (flags & F_FREEZE_ROBOT) != 0;
+  if (l < NV) {
+    const int b = M->dof_body[l];
+    if (b < NRB) {
+      if (!freeze) s.qvel[l] += h * s.scratch[l];
+    } else if (body_is_active(M, s, b)) {
+      s.qvel[l] += h * s.qacc[l];  // free joints carry no damping: MH = M on cube blocks
+    }
+  }
+  __syncthreads();
+  if (l >= 1 && l < NB) {
+    const int b = l, qa = M->body_qposadr[b], da = M->body_dofadr[b];
+    if (b < NRB) {
+      if (!freeze) s.qpos[qa] += h * s.qvel[da];
+    } else if (body_is_active(M, s, b)) {
+      for (int k = 0; k < 3; k++) s.qpos[qa + k] += h * s.qvel[da + k];
+      float w[3] = {s.qvel[da + 3], s.qvel[da + 4], s.qvel[da + 5]};
+      const float ang = v3normalize(w) * h;
+      float qr[4], qn[4], q0[4];
+      axisangle2q(qr, w, ang);
+      for (int k = 0; k < 4; k++) q0[k] = s.qpos[qa + 3 + k];
+      qmul(qn, q0, qr);
+      qnormalize(qn);
+      for (int k = 0; k < 4; k++) s.qpos[qa + 3 + k] = qn[k];
+    }
+  }
+  __syncthreads();
+}
+
+// =========================================================================
+__global__ __launch_bounds__(64) void k_step(StepArgs a) {
+  __shared__ Sm s;
+  const int env = blockIdx.x;
+  const int l = threadIdx.x;
+  if (env >= a.N) return;
+  const DevModel* M = a.M;
+
+  // ---- load state (one coalesced row per array)
+  if (l < NQP) s.qpos[l] = a.qpos[(size_t)env * NQP + l];
+  if (l < NVP) {
+    s.qvel[l] = a.qvel[(size_t)env * NVP + l];
+    s.qacc_ws[l] = a.qacc_ws[(size_t)env * NVP + l];
+    s.qfrc_con[l] = 0.f;
+    s.qacc[l] = 0.f;
+  }
+  if (l < NU) s.ctrl[l] = a.ctrl[(size_t)env * NU + l];
+  if (l == 0) s.nprops = a.nprops[env];
+  if (l < NPROP * 3) {
+    const float sz = a.prop_size[(size_t)env * NPROP * 3 + l];
+    s.prop_size[l / 3][l % 3] = sz;
+  }
+  __syncthreads();
+  if (l < NPROP) {
+    const float m = M->body_mass[NRB + l];
+    const float* z = s.prop_size[l];
+    s.prop_mass[l] = m;
+    s.prop_inertia[l][0] = m / 3.f * (z[1] * z[1] + z[2] * z[2]);
+    s.prop_inertia[l][1] = m / 3.f * (z[0] * z[0] + z[2] * z[2]);
+    s.prop_inertia[l][2] = m / 3.f * (z[0] * z[0] + z[1] * z[1]);
+  }
+  __syncthreads();
+
+  BodyRegs br;
+  for (int step = 0; step < a.nsteps; ++step) {
+    // ------------------------------------------------ S1: position stage
+    kinematics(M, s, l, br);
+    com_pos(M, s, l, br);
+    __syncthreads();
+    crb_mass_matrix(M, s, l);
+    __syncthreads();
+    for (int e = l; e < NMR; e += 64) s.qLD[e] = s.qM[e];
+    __syncthreads();
+    factor_robot(M, s.qLD, s.qLDinv, l);
+    // ------------------------------------------------ S1: velocity stage
+    velocity_stage(M, s, l);
+    __syncthreads();
+    // ------------------------------------------------ control at tick boundary
+    if (a.mode == CTRL_SEQ && (step % a.control_steps) == 0) {
+      const int tick = step / a.control_steps;
+      if (l < NU) s.ctrl[l] = a.ctrl_seq[((size_t)tick * a.N + env) * NU + l];
+      __syncthreads();
+    }
+    // ------------------------------------------------ S2
+    const bool clamped = smooth_forces(M, s, l);
+    if (l < NVP) { s.qacc[l] = s.qacc_smooth[l]; s.qfrc_con[l] = 0.f; }
+    __syncthreads();
+    integrate(M, s, l, clamped, a.flags);
+    if (a.trace != nullptr && env < a.trace_nenv && (a.trace_base + step) < a.trace_max) {
+      if (l < NQP)
+        a.trace[((size_t)(a.trace_base + step) * a.trace_nenv + env) * NQP + l] = s.qpos[l];
+    }
+  }
+  // ---- final kinematics for site queries
+  kinematics(M, s, l, br);
+  __syncthreads();
+  if (a.sites != nullptr) {
+    float* o = a.sites + (size_t)env * 16;
+    if (l < 3) o[l] = s.site_xpos[M->tcp_site][l];
+    if (l >= 3 && l < 6) o[l] = s.site_xpos[M->eef_site][l - 3];
+    if (l == 6) {
+      float q[4];
+      mat2q(q, s.site_xmat[M->eef_site]);
+      o[6] = q[0]; o[7] = q[1]; o[8] = q[2]; o[9] = q[3];
+    }
+  }
+  // ---- store state
+  if (l < NQP) a.qpos[(size_t)env * NQP + l] = s.qpos[l];
+  if (l < NVP) {
+    a.qvel[(size_t)env * NVP + l] = s.qvel[l];
+    a.qacc_ws[(size_t)env * NVP + l] = s.qacc_ws[l];
+  }
+  if (l < NU) a.ctrl[(size_t)env * NU + l] = s.ctrl[l];
+  if (l == 0 && a.status != nullptr) {
+    unsigned st = 0;
+    for (int k = 0; k < NQ; k++) if (!isfinite(s.qpos[k])) st |= 2u;
+    a.status[env] |= st;
+  }
+}
+
+// Physics.reset() + arm home pose (tasks/rearrangement.py:302-306); cubes parked
+__global__ __launch_bounds__(64) void k_reset(const DevModel* M, int N, float* qpos, float* qvel,
+                                              float* qacc_ws, float* ctrl, uint32_t* status,
+                                              const uint8_t* mask) {
+  const int env = blockIdx.x, l = threadIdx.x;
+  if (env >= N) return;
+  if (mask != nullptr && mask[env] == 0) return;
+  if (l < NQP) {
+    float v = (l < NQ) ? M->qpos0[l] : 0.f;
+    if (l < 7) v = M->home_qpos[l];
+    if (l >= NRV && l < NQ) {
+      const int p = (l - NRV) / 7, k = (l - NRV) % 7;
+      v = (k < 3) ? M->park_pos[p][k] : (k == 3 ? 1.f : 0.f);
+    }
+    qpos[(size_t)env * NQP + l] = v;
+  }
+  if (l < NVP) { qvel[(size_t)env * NVP + l] = 0.f; qacc_ws[(size_t)env * NVP + l] = 0.f; }
+  if (l < NU) ctrl[(size_t)env * NU + l] = 0.f;
+  if (l == 0) status[env] = 0u;
+}
+
+}  // namespace mre
+
+extern "C" void mre_launch_reset(const mre::DevModel* M, int N, float* qpos, float* qvel, float* qacc_ws,
+                                 float* ctrl, uint32_t* status, const uint8_t* mask, hipStream_t stream) {
+  hipLaunchKernelGGL(mre::k_reset, dim3(N), dim3(64), 0, stream, M, N, qpos, qvel, qacc_ws, ctrl, status, mask);
+}
+
+extern "C" void mre_launch_place(const mre::StepArgs* args, const uint8_t* mask, uint64_t seed,
+                                 const float* ws, int max_attempts, hipStream_t stream) {
+  (void)args; (void)mask; (void)seed; (void)ws; (void)max_attempts; (void)stream;
+}
+
+extern "C" void mre_launch_step(const mre::StepArgs* args, hipStream_t stream) {
+  hipLaunchKernelGGL(mre::k_step, dim3(args->N), dim3(64), 0, stream, *args);
+}

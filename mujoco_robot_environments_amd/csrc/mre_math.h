@@ -1,0 +1,126 @@
+// mre_math.h -- small fp32 vector / quaternion / spatial-algebra helpers for
+// the gfx950 kernels (per-lane scalar code; cross-lane work lives in the kernels).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define MRE_DEV __device__ __forceinline__
+
+namespace mre {
+
+constexpr float kMinVal = 1e-15f;
+
+MRE_DEV void v3copy(float* r, const float* a) { r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; }
+MRE_DEV void v3zero(float* r) { r[0] = r[1] = r[2] = 0.f; }
+MRE_DEV void v3add(float* r, const float* a, const float* b) {
+  r[0] = a[0] + b[0]; r[1] = a[1] + b[1]; r[2] = a[2] + b[2];
+}
+MRE_DEV void v3sub(float* r, const float* a, const float* b) {
+  r[0] = a[0] - b[0]; r[1] = a[1] - b[1]; r[2] = a[2] - b[2];
+}
+MRE_DEV float v3dot(const float* a, const float* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+MRE_DEV void v3cross(float* r, const float* a, const float* b) {
+  float x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+MRE_DEV void v3addscl(float* r, const float* a, float s) { r[0] += a[0] * s; r[1] += a[1] * s; r[2] += a[2] * s; }
+MRE_DEV float v3norm(const float* a) { return sqrtf(v3dot(a, a)); }
+MRE_DEV float v3normalize(float* a) {
+  float n = v3norm(a);
+  if (n < kMinVal) { a[0] = 1.f; a[1] = 0.f; a[2] = 0.f; return n; }
+  float inv = 1.0f / n;
+  a[0] *= inv; a[1] *= inv; a[2] *= inv;
+  return n;
+}
+// r = M(3x3 row-major) v
+MRE_DEV void m3mulv(float* r, const float* m, const float* v) {
+  float x = m[0] * v[0] + m[1] * v[1] + m[2] * v[2];
+  float y = m[3] * v[0] + m[4] * v[1] + m[5] * v[2];
+  float z = m[6] * v[0] + m[7] * v[1] + m[8] * v[2];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+MRE_DEV void m3tmulv(float* r, const float* m, const float* v) {
+  float x = m[0] * v[0] + m[3] * v[1] + m[6] * v[2];
+  float y = m[1] * v[0] + m[4] * v[1] + m[7] * v[2];
+  float z = m[2] * v[0] + m[5] * v[1] + m[8] * v[2];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+MRE_DEV void qmul(float* r, const float* a, const float* b) {
+  float w = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+  float x = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+  float y = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
+  float z = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+  r[0] = w; r[1] = x; r[2] = y; r[3] = z;
+}
+MRE_DEV void qnormalize(float* q) {
+  float n = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  if (n < kMinVal) { q[0] = 1.f; q[1] = q[2] = q[3] = 0.f; return; }
+  float inv = 1.0f / n;
+  q[0] *= inv; q[1] *= inv; q[2] *= inv; q[3] *= inv;
+}
+MRE_DEV void q2mat(float* m, const float* q) {
+  float w = q[0], x = q[1], y = q[2], z = q[3];
+  m[0] = w * w + x * x - y * y - z * z; m[1] = 2 * (x * y - w * z); m[2] = 2 * (x * z + w * y);
+  m[3] = 2 * (x * y + w * z); m[4] = w * w - x * x + y * y - z * z; m[5] = 2 * (y * z - w * x);
+  m[6] = 2 * (x * z - w * y); m[7] = 2 * (y * z + w * x); m[8] = w * w - x * x - y * y + z * z;
+}
+MRE_DEV void qrotv(float* r, const float* q, const float* v) {
+  float m[9];
+  q2mat(m, q);
+  m3mulv(r, m, v);
+}
+MRE_DEV void axisangle2q(float* q, const float* axis, float angle) {
+  float s, c;
+  sincosf(0.5f * angle, &s, &c);
+  q[0] = c; q[1] = axis[0] * s; q[2] = axis[1] * s; q[3] = axis[2] * s;
+}
+MRE_DEV void mat2q(float* q, const float* m) {
+  float t = m[0] + m[4] + m[8];
+  if (t > 0) {
+    float s = sqrtf(t + 1.0f) * 2;
+    q[0] = 0.25f * s; q[1] = (m[7] - m[5]) / s; q[2] = (m[2] - m[6]) / s; q[3] = (m[3] - m[1]) / s;
+  } else if (m[0] > m[4] && m[0] > m[8]) {
+    float s = sqrtf(1.0f + m[0] - m[4] - m[8]) * 2;
+    q[0] = (m[7] - m[5]) / s; q[1] = 0.25f * s; q[2] = (m[1] + m[3]) / s; q[3] = (m[2] + m[6]) / s;
+  } else if (m[4] > m[8]) {
+    float s = sqrtf(1.0f + m[4] - m[0] - m[8]) * 2;
+    q[0] = (m[2] - m[6]) / s; q[1] = (m[1] + m[3]) / s; q[2] = 0.25f * s; q[3] = (m[5] + m[7]) / s;
+  } else {
+    float s = sqrtf(1.0f + m[8] - m[0] - m[4]) * 2;
+    q[0] = (m[3] - m[1]) / s; q[1] = (m[2] + m[6]) / s; q[2] = (m[5] + m[7]) / s; q[3] = 0.25f * s;
+  }
+  qnormalize(q);
+}
+// spatial inertia (10) times motion vector (6): [rot; lin]
+MRE_DEV void mul_inert_vec(float* r, const float* i, const float* v) {
+  r[0] = i[0] * v[0] + i[3] * v[1] + i[4] * v[2] - i[8] * v[4] + i[7] * v[5];
+  r[1] = i[3] * v[0] + i[1] * v[1] + i[5] * v[2] + i[8] * v[3] - i[6] * v[5];
+  r[2] = i[4] * v[0] + i[5] * v[1] + i[2] * v[2] - i[7] * v[3] + i[6] * v[4];
+  r[3] = i[8] * v[1] - i[7] * v[2] + i[9] * v[3];
+  r[4] = i[6] * v[2] - i[8] * v[0] + i[9] * v[4];
+  r[5] = i[7] * v[0] - i[6] * v[1] + i[9] * v[5];
+}
+MRE_DEV void cross_motion(float* r, const float* vel, const float* v) {
+  float a[3], b[3];
+  v3cross(r, vel, v);
+  v3cross(a, vel, v + 3);
+  v3cross(b, vel + 3, v);
+  v3add(r + 3, a, b);
+}
+MRE_DEV void cross_force(float* r, const float* vel, const float* f) {
+  float a[3], b[3];
+  v3cross(a, vel, f);
+  v3cross(b, vel + 3, f + 3);
+  v3add(r, a, b);
+  v3cross(r + 3, vel, f + 3);
+}
+MRE_DEV float dot6(const float* a, const float* b) {
+  return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3] + a[4] * b[4] + a[5] * b[5];
+}
+MRE_DEV float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+MRE_DEV float clampf(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+}  // namespace mre

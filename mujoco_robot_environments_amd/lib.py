@@ -1,0 +1,104 @@
+"""ctypes binding of the C-ABI library ``libmre.so`` (include/mre.h).
+
+The HIP path has no CPU fallback: a missing library or a missing GPU raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import shutil
+import subprocess
+from typing import Optional
+
+_CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+_SO = os.path.join(_CSRC, "libmre.so")
+_SOURCES = ["mre_kernels.hip", "mre_api.cpp"]
+_HEADERS = ["mre_dev.h", "mre_math.h", "mre_collide.h", "mre_solver.h", "mre_osc.h",
+            os.path.join("..", "..", "include", "mre.h")]
+_LIB: Optional[C.CDLL] = None
+
+MRE_NQ, MRE_NV, MRE_NU, MRE_NQ_PAD, MRE_NV_PAD, MRE_MAX_PROPS = 43, 39, 8, 44, 40, 4
+
+EXPORTS = [
+    "mre_create", "mre_destroy", "mre_last_error", "mre_num_envs", "mre_stream", "mre_sync",
+    "mre_set_props", "mre_reset", "mre_place_props", "mre_set_state", "mre_get_state",
+    "mre_set_warmstart", "mre_get_warmstart", "mre_set_ctrl", "mre_step", "mre_rollout",
+    "mre_set_trace", "mre_osc_set_target", "mre_osc_configure", "mre_gripper_set",
+    "mre_run_controller", "mre_get_sites", "mre_get_status", "mre_get_solver_stats",
+]
+
+
+class MreError(RuntimeError):
+    pass
+
+
+def needs_build() -> bool:
+    if not os.path.exists(_SO):
+        return True
+    t = os.path.getmtime(_SO)
+    for f in _SOURCES + _HEADERS:
+        p = os.path.join(_CSRC, f)
+        if os.path.exists(p) and os.path.getmtime(p) > t:
+            return True
+    return False
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile the HIP kernels + C-ABI host code for gfx950 in-tree."""
+    if not force and not needs_build():
+        return _SO
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
+           "-Wno-unused-value", "-o", _SO] + [os.path.join(_CSRC, s) for s in _SOURCES]
+    if verbose:
+        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+    subprocess.check_call(cmd)
+    return _SO
+
+
+def lib() -> C.CDLL:
+    """Load libmre.so (never builds implicitly on a GPU box: the .so travels in-tree)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(_SO):
+        raise MreError(f"{_SO} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(the HIP extension is the only implementation of the step)")
+    L = C.CDLL(_SO)
+    vp, ci, cu, fp = C.c_void_p, C.c_int, C.c_uint, C.c_void_p
+    L.mre_create.argtypes = [C.c_char_p, C.c_size_t, ci, ci, C.POINTER(vp)]
+    L.mre_destroy.argtypes = [vp]
+    L.mre_last_error.restype = C.c_char_p
+    L.mre_num_envs.argtypes = [vp]
+    L.mre_stream.restype = vp
+    L.mre_stream.argtypes = [vp]
+    L.mre_sync.argtypes = [vp]
+    L.mre_set_props.argtypes = [vp, fp, fp]
+    L.mre_reset.argtypes = [vp, fp]
+    L.mre_place_props.argtypes = [vp, fp, C.c_uint64, fp, fp, ci, ci]
+    L.mre_set_state.argtypes = [vp, fp, fp]
+    L.mre_get_state.argtypes = [vp, fp, fp]
+    L.mre_set_warmstart.argtypes = [vp, fp]
+    L.mre_get_warmstart.argtypes = [vp, fp]
+    L.mre_set_ctrl.argtypes = [vp, fp]
+    L.mre_step.argtypes = [vp, ci, cu]
+    L.mre_rollout.argtypes = [vp, fp, ci, ci, cu]
+    L.mre_set_trace.argtypes = [vp, fp, ci, ci]
+    L.mre_osc_set_target.argtypes = [vp, fp, fp, fp, fp, fp]
+    L.mre_osc_configure.argtypes = [vp, fp, fp, fp, ci]
+    L.mre_gripper_set.argtypes = [vp, fp]
+    L.mre_run_controller.argtypes = [vp, ci, ci, fp]
+    L.mre_get_sites.argtypes = [vp, fp, fp, fp]
+    L.mre_get_status.argtypes = [vp, fp]
+    L.mre_get_solver_stats.argtypes = [vp, fp]
+    for name in EXPORTS:
+        if name not in ("mre_last_error", "mre_stream"):
+            getattr(L, name).restype = ci
+    _LIB = L
+    return L
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().mre_last_error()
+        raise MreError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")

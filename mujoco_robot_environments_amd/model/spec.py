@@ -1,0 +1,287 @@
+"""Scene specification for the RearrangementEnv hot path.
+
+This is the *model data* the reference obtains at run time by loading MJCF
+files that are NOT present under /root/reference:
+
+* arena / table / props / camera: in-tree facts, cited per element below
+  (reference paths relative to /root/reference/mujoco_robot_environments/).
+* Franka Panda (``panda_nohand.xml``) and Robotiq 2F-85 (``2f85.xml``): come
+  from mujoco_menagerie through a robot_descriptions wheel that is empty in
+  the reference checkout (pyproject.toml:45, .gitmodules:7-9).  The numbers
+  below are restated from the published menagerie models and are flagged
+  ``unverified`` -- every parity claim in this repo is relative to THIS spec.
+* collision *meshes* of the robot are not recoverable; they are replaced by
+  conservative box hulls (``hull=True`` geoms).  Only the gripper pads (real
+  box geoms in the menagerie model) are exact.
+
+The spec is a plain tree of dicts; ``compile.py`` flattens it (fusing
+joint-less bodies into their parents exactly as MuJoCo's ``fusestatic`` does)
+into the arrays consumed by the HIP kernels and by the CPU oracle.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence
+
+SQ2 = math.sqrt(0.5)
+
+# MuJoCo defaults (mjmodel.h / XML reference "default" column)
+DEFAULT_SOLREF = (0.02, 1.0)
+DEFAULT_SOLIMP = (0.9, 0.95, 0.001, 0.5, 2.0)
+DEFAULT_FRICTION = (1.0, 0.005, 0.0001)
+
+
+def body(name, pos=(0, 0, 0), quat=(1, 0, 0, 0), inertial=None, joint=None,
+         geoms=None, sites=None, children=None):
+    return dict(name=name, pos=tuple(pos), quat=tuple(quat), inertial=inertial,
+                joint=joint, geoms=list(geoms or []), sites=list(sites or []),
+                children=list(children or []))
+
+
+def inertial(mass, pos, fullinertia=None, quat=None, diaginertia=None):
+    return dict(mass=mass, pos=tuple(pos), fullinertia=fullinertia, quat=quat,
+                diaginertia=diaginertia)
+
+
+def hinge(name, axis, rng, armature, damping, pos=(0, 0, 0), stiffness=0.0,
+          springref=0.0, solreflimit=DEFAULT_SOLREF, solimplimit=DEFAULT_SOLIMP):
+    return dict(name=name, type="hinge", axis=tuple(axis), pos=tuple(pos),
+                range=tuple(rng), armature=armature, damping=damping,
+                stiffness=stiffness, springref=springref,
+                solreflimit=tuple(solreflimit), solimplimit=tuple(solimplimit))
+
+
+def free(name):
+    return dict(name=name, type="free")
+
+
+def box(name, size, pos=(0, 0, 0), quat=(1, 0, 0, 0), friction=DEFAULT_FRICTION,
+        priority=0, condim=3, margin=0.0, gap=0.0, solref=DEFAULT_SOLREF,
+        solimp=DEFAULT_SOLIMP, mass=None, hull=False, contype=1, conaffinity=1,
+        group="robot"):
+    return dict(name=name, type="box", size=tuple(size), pos=tuple(pos),
+                quat=tuple(quat), friction=tuple(friction), priority=priority,
+                condim=condim, margin=margin, gap=gap, solref=tuple(solref),
+                solimp=tuple(solimp), mass=mass, hull=hull, contype=contype,
+                conaffinity=conaffinity, group=group)
+
+
+def plane(name, friction=DEFAULT_FRICTION):
+    g = box(name, (0, 0, 0), friction=friction, group="ground")
+    g["type"] = "plane"
+    return g
+
+
+# --------------------------------------------------------------------------
+# Franka Emika Panda (menagerie franka_emika_panda/panda_nohand.xml) [3P,
+# unverified].  Kinematic offsets: SURVEY.md App. A.3; the attachment frame
+# is confirmed in-tree at models/arms/franka_emika.py:52-57; joint ranges are
+# confirmed by config/robots/arm/actuator_config/position.yaml:5,19,33,47.
+# Class defaults: armature 0.1, damping 1, axis 0 0 1.
+# --------------------------------------------------------------------------
+_PANDA_RANGES = [(-2.8973, 2.8973), (-1.7628, 1.7628), (-2.8973, 2.8973),
+                 (-3.0718, -0.0698), (-2.8973, 2.8973), (-0.0175, 3.7525),
+                 (-2.8973, 2.8973)]
+
+_PANDA_LINKS = [
+    # name, pos, quat, mass, com, fullinertia (xx yy zz xy xz yz)
+    ("link1", (0, 0, 0.333), (1, 0, 0, 0), 4.970684,
+     (0.003875, 0.002081, -0.04762),
+     (0.70337, 0.70661, 0.0091170, -0.00013900, 0.0067720, 0.019169)),
+    ("link2", (0, 0, 0), (SQ2, -SQ2, 0, 0), 0.646926,
+     (-0.003141, -0.02872, 0.003495),
+     (0.0079620, 0.02811, 0.025995, -0.003925, 0.010254, 0.000704)),
+    ("link3", (0, -0.316, 0), (SQ2, SQ2, 0, 0), 3.228604,
+     (0.027518, 0.039252, -0.066502),
+     (0.037242, 0.036155, 0.01083, -0.004761, -0.011396, -0.012805)),
+    ("link4", (0.0825, 0, 0), (SQ2, SQ2, 0, 0), 3.587895,
+     (-0.05317, 0.104419, 0.027454),
+     (0.025853, 0.019552, 0.028323, 0.007796, -0.001332, 0.008641)),
+    ("link5", (-0.0825, 0.384, 0), (SQ2, -SQ2, 0, 0), 1.225946,
+     (-0.011953, 0.041065, -0.038437),
+     (0.035549, 0.029474, 0.008627, -0.002117, -0.004037, 0.000229)),
+    ("link6", (0, 0, 0), (SQ2, SQ2, 0, 0), 1.666555,
+     (0.060149, -0.014117, -0.010517),
+     (0.001964, 0.004354, 0.005433, 0.000109, -0.001158, 0.000341)),
+    ("link7", (0.088, 0, 0), (SQ2, SQ2, 0, 0), 0.735522,
+     (0.010517, -0.004252, 0.061597),
+     (0.012516, 0.010027, 0.004815, -0.000428, -0.001196, -0.000741)),
+]
+
+# box hulls standing in for the link collision meshes (deviation, see header)
+_PANDA_HULLS = {
+    "link5": dict(size=(0.055, 0.07, 0.11), pos=(0.0, 0.04, -0.12)),
+    "link6": dict(size=(0.065, 0.055, 0.06), pos=(0.045, 0.0, 0.0)),
+    "link7": dict(size=(0.05, 0.05, 0.04), pos=(0.0, 0.0, 0.07)),
+}
+
+
+def panda_spec(gripper: Optional[dict] = None) -> dict:
+    """Body tree of the arm, rooted at link0 (welded to the robot base site)."""
+    attachment = body("attachment", pos=(0, 0, 0.107),
+                      quat=(0.3826834, 0, 0, 0.9238795),
+                      sites=[dict(name="attachment_site", pos=(0, 0, 0), quat=(1, 0, 0, 0))],
+                      children=[gripper] if gripper is not None else [])
+    child = attachment
+    for i in range(6, -1, -1):
+        name, pos, quat, mass, com, full = _PANDA_LINKS[i]
+        geoms = []
+        if name in _PANDA_HULLS:
+            h = _PANDA_HULLS[name]
+            geoms.append(box(f"{name}_hull", h["size"], pos=h["pos"], hull=True))
+        child = body(name, pos=pos, quat=quat,
+                     inertial=inertial(mass, com, fullinertia=full),
+                     joint=hinge(f"joint{i + 1}", (0, 0, 1), _PANDA_RANGES[i],
+                                 armature=0.1, damping=1.0),
+                     geoms=geoms, children=[child])
+    link0 = body("link0", inertial=inertial(
+        0.629769, (-0.041018, -0.00014, 0.049974),
+        fullinertia=(0.00315, 0.00388, 0.004285, 8.2904e-7, 0.00015, 8.2299e-6)),
+        children=[child])
+    return link0
+
+
+# --------------------------------------------------------------------------
+# Robotiq 2F-85 (menagerie robotiq_2f85/2f85.xml) [3P, unverified; the
+# reference loads a private "_v4" fork, models/end_effectors/robotiq_2f85.py:7].
+# option cone=elliptic impratio=10; class defaults restated per joint below.
+# --------------------------------------------------------------------------
+_LIM_SOLREF = (0.005, 1.0)
+_LIM_SOLIMP = (0.95, 0.99, 0.001, 0.5, 2.0)
+_PAD_SOLREF = (0.004, 1.0)
+_PAD_SOLIMP = (0.95, 0.99, 0.001, 0.5, 2.0)
+
+
+def _finger(side: str, mirrored: bool) -> List[dict]:
+    q = (0, 0, 0, 1) if mirrored else (1, 0, 0, 0)
+    sgn = -1.0 if mirrored else 1.0
+    pad = body(f"{side}_pad", pos=(0, -0.0189, 0.01352),
+               inertial=inertial(0.0035, (0, -0.0025, 0.0185),
+                                 quat=(SQ2, 0, 0, SQ2),
+                                 diaginertia=(4.73958e-07, 3.64583e-07, 1.23958e-07)),
+               geoms=[
+                   box(f"{side}_pad1", (0.011, 0.004, 0.009375), pos=(0, -0.0026, 0.028125),
+                       friction=(0.7, 0.005, 0.0001), priority=1, solref=_PAD_SOLREF,
+                       solimp=_PAD_SOLIMP, group="pad"),
+                   box(f"{side}_pad2", (0.011, 0.004, 0.009375), pos=(0, -0.0026, 0.009375),
+                       friction=(0.6, 0.005, 0.0001), priority=1, solref=_PAD_SOLREF,
+                       solimp=_PAD_SOLIMP, group="pad"),
+               ])
+    follower = body(f"{side}_follower", pos=(0, 0.055, 0.0375),
+                    inertial=inertial(0.0125222, (0, -0.011046, 0.0124786),
+                                      quat=(1, 0.1664, 0, 0),
+                                      diaginertia=(2.67415e-06, 2.4559e-06, 6.02031e-07)),
+                    joint=hinge(f"{side}_follower_joint", (1, 0, 0), (-0.872664, 0.872664),
+                                armature=0.001, damping=0.0, pos=(0, -0.018, 0.0065),
+                                solreflimit=_LIM_SOLREF, solimplimit=_LIM_SOLIMP),
+                    geoms=[box(f"{side}_follower_hull", (0.010, 0.005, 0.022),
+                               pos=(0, 0.0005, 0.018), hull=True)],
+                    children=[pad])
+    spring_link = body(f"{side}_spring_link", pos=(0, sgn * 0.0132, 0.0609), quat=q,
+                       inertial=inertial(0.0221642, (-8.65005e-09, 0.0181624, 0.0212658),
+                                         quat=(0.663403, -0.244737, 0.244737, 0.663403),
+                                         diaginertia=(8.96853e-06, 6.71733e-06, 2.63931e-06)),
+                       joint=hinge(f"{side}_spring_link_joint", (1, 0, 0), (-0.29670597283, 0.8),
+                                   armature=0.001, damping=0.00125, stiffness=0.05,
+                                   springref=2.62),
+                       children=[follower])
+    coupler = body(f"{side}_coupler", pos=(0, 0.0315, -0.0041),
+                   inertial=inertial(0.0140974, (0, 0.00301209, 0.0232175),
+                                     quat=(0.705636, -0.0455904, 0.0455904, 0.705636),
+                                     diaginertia=(4.16206e-06, 3.52216e-06, 8.88131e-07)),
+                   joint=hinge(f"{side}_coupler_joint", (1, 0, 0), (-1.57, 0.0),
+                               armature=0.001, damping=0.0,
+                               solreflimit=_LIM_SOLREF, solimplimit=_LIM_SOLIMP))
+    driver = body(f"{side}_driver", pos=(0, sgn * 0.0306011, 0.054904), quat=q,
+                  inertial=inertial(0.00899563, (2.96931e-12, 0.0177547, 0.00107314),
+                                    quat=(0.681301, 0.732003, 0, 0),
+                                    diaginertia=(1.72352e-06, 1.60906e-06, 3.22006e-07)),
+                  joint=hinge(f"{side}_driver_joint", (1, 0, 0), (0.0, 0.8),
+                              armature=0.005, damping=0.1,
+                              solreflimit=_LIM_SOLREF, solimplimit=_LIM_SOLIMP),
+                  children=[coupler])
+    return [driver, spring_link]
+
+
+def robotiq_spec() -> dict:
+    base = body("base", pos=(0, 0, 0.0038), quat=(SQ2, 0, 0, -SQ2),
+                inertial=inertial(0.777441, (0, -2.70394e-05, 0.0354675),
+                                  quat=(1, -0.00152849, 0, 0),
+                                  diaginertia=(0.000260285, 0.000225381, 0.000152708)),
+                geoms=[box("gripper_base_hull", (0.032, 0.038, 0.045), pos=(0, 0, 0.04),
+                           hull=True)],
+                sites=[dict(name="pinch", pos=(0, 0, 0.145), quat=(1, 0, 0, 0))],
+                children=_finger("right", False) + _finger("left", True))
+    return body("base_mount", pos=(0, 0, 0.007), children=[base])
+
+
+ROBOTIQ_EQUALITY = [
+    # 2f85.xml <equality>: follower<->coupler closure of each 4-bar + driver sync
+    dict(type="connect", body1="right_follower", body2="right_coupler", anchor=(0, 0, 0),
+         solref=(0.005, 1.0), solimp=(0.95, 0.99, 0.001, 0.5, 2.0)),
+    dict(type="connect", body1="left_follower", body2="left_coupler", anchor=(0, 0, 0),
+         solref=(0.005, 1.0), solimp=(0.95, 0.99, 0.001, 0.5, 2.0)),
+    dict(type="joint", joint1="right_driver_joint", joint2="left_driver_joint",
+         polycoef=(0, 1, 0, 0, 0), solref=(0.005, 1.0),
+         solimp=(0.95, 0.99, 0.001, 0.5, 2.0)),
+]
+
+ROBOTIQ_TENDON = dict(name="split", joints=("right_driver_joint", "left_driver_joint"),
+                      coef=(0.5, 0.5))
+
+
+def default_scene(cfg: Optional[Dict] = None, max_props: int = 4) -> dict:
+    """Full scene = arena + table + robot + ``max_props`` cube slots.
+
+    Mirrors RearrangementEnv.__init__ (tasks/rearrangement.py:73-210):
+    ground plane friction 0.4 (models/arenas/empty_assets/arena.xml:14-15);
+    table = box half-size (0.9,1.0,0.2) at (0.4,0,0.2), priority 10, margin/gap 0
+    (tasks/rearrangement.py:86-101; the friction kw is not forwarded so the
+    geom keeps (1,0.005,0.0001): environment/props.py:242-254,194-210);
+    robot base at (0,0,0.4) (tasks/rearrangement.py:121-126); props are cubes
+    with a free joint, mass 0.1, margin = gap = 0.15, priority 10
+    (environment/props.py:238-240,194-210,258-304).
+    Per-env prop count / half-size are *runtime* parameters of the batch.
+    """
+    cfg = cfg or {}
+    motor = cfg.get("motor_ctrlrange",
+                    [87.0, 87.0, 87.0, 87.0, 12.0, 12.0, 12.0])  # motor.yaml:2-13
+    arm = panda_spec(gripper=robotiq_spec())
+    robot_base = body("robot_base", pos=(0, 0, 0.4), children=[arm])
+    table = body("table", pos=(0.4, 0.0, 0.2), geoms=[
+        box("table", (0.9, 1.0, 0.2), priority=10, margin=0.0, gap=0.0, mass=10.0,
+            group="table")])
+    props = []
+    for i in range(max_props):
+        props.append(body(f"prop_{i}", joint=free(f"prop_{i}_free"), geoms=[
+            box(f"prop_{i}", (0.0155, 0.0155, 0.0155), priority=10, margin=0.15, gap=0.15,
+                mass=0.1, group="prop")]))
+    world = body("world", geoms=[plane("ground", friction=(0.4, 0.005, 0.0001))],
+                 children=[table, robot_base] + props)
+    actuators = []
+    for i in range(7):
+        actuators.append(dict(name=f"actuator{i + 1}", kind="motor", joint=f"joint{i + 1}",
+                              ctrlrange=(-motor[i], motor[i])))
+    # models/end_effectors/robotiq_2f85.py:41-48 overwrites forcerange to +-1.5
+    actuators.append(dict(name="fingers_actuator", kind="general_tendon", tendon="split",
+                          gainprm=0.3137255, biasprm=(0.0, -100.0, -10.0),
+                          ctrlrange=(0.0, 255.0), forcerange=(-1.5, 1.5)))
+    return dict(
+        world=world,
+        equality=ROBOTIQ_EQUALITY,
+        tendon=ROBOTIQ_TENDON,
+        actuators=actuators,
+        option=dict(
+            timestep=float(cfg.get("physics_dt", 0.001)),       # config/rearrangement.yaml:2
+            gravity=tuple(cfg.get("gravity", (0.0, 0.0, -9.8))),  # config/rearrangement.yaml:4
+            integrator="implicitfast",   # inherited from panda_nohand.xml [3P]
+            cone="elliptic", impratio=10.0,  # inherited from 2f85.xml [3P]
+            solver="PGS",                 # BASELINE.json north_star (MuJoCo default: Newton)
+            iterations=100, tolerance=1e-8,  # MuJoCo defaults
+        ),
+        arm_joints=[f"joint{i + 1}" for i in range(7)],
+        eef_site="attachment_site",   # models/robot_arm.py:38
+        tcp_site="pinch",             # models/robot_arm.py:57
+        home=tuple(cfg.get("home", (0, -0.785, 0, -2.356, 0, 1.571, 0.785))),
+        unverified=True,
+    )

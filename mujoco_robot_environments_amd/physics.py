@@ -1,0 +1,218 @@
+"""BatchedPhysics: host-side mirror of the ``dm_control.mjcf.Physics`` members the
+reference's hot path touches, batched over ``num_envs``
+environments and backed by the HIP kernels through the C ABI (include/mre.h).
+
+reference member                       -> this class
+  physics.step() (robot_arm.py:79)     -> step(nsubsteps)
+  physics.set_control(u) (:78)         -> set_control(u[N,8])
+  physics.reset() (rearrangement.py:302) + arm.set_joint_angles(home) -> reset(mask)
+  physics.bind(joints).qpos/.qvel      -> qpos() / qvel() / set_state()
+  physics.data.site_xpos[pinch]        -> sites()
+PyTorch is used only to own device memory handed across the boundary.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import lib as _lib
+from .lib import MRE_NQ, MRE_NQ_PAD, MRE_NU, MRE_NV, MRE_NV_PAD, MRE_MAX_PROPS, check
+from .model import compile as _compile
+
+FLAG_NO_CONSTRAINTS = 1
+FLAG_FREEZE_ROBOT = 2
+
+
+def _ptr(t) -> Optional[int]:
+    if t is None:
+        return None
+    if isinstance(t, torch.Tensor):
+        assert t.is_contiguous()
+        return t.data_ptr()
+    if isinstance(t, np.ndarray):
+        assert t.flags["C_CONTIGUOUS"]
+        return t.ctypes.data
+    raise TypeError(type(t))
+
+
+class BatchedPhysics:
+    def __init__(self, num_envs: int, scene: Optional[dict] = None, device: int = 0,
+                 model: Optional[dict] = None):
+        self.model = model if model is not None else _compile.compile_scene(scene)
+        self.blob = _compile.to_blob(self.model)
+        self.num_envs = int(num_envs)
+        self.device_id = int(device)
+        self.device = torch.device("cuda", self.device_id)
+        self._h = C.c_void_p()
+        L = _lib.lib()
+        check(L.mre_create(self.blob, len(self.blob), self.num_envs, self.device_id,
+                           C.byref(self._h)), "mre_create")
+        self.timestep = float(self.model["opt_timestep"][0])
+        self._trace = None
+
+    # ------------------------------------------------------------ lifecycle
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            _lib.lib().mre_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        check(_lib.lib().mre_sync(self._h), "mre_sync")
+
+    @property
+    def stream_ptr(self) -> int:
+        return _lib.lib().mre_stream(self._h)
+
+    # --------------------------------------------------------------- scene
+    def set_props(self, nprops: Sequence[int], half_size) -> None:
+        n = np.ascontiguousarray(nprops, np.int32).reshape(self.num_envs)
+        s = np.ascontiguousarray(half_size, np.float32).reshape(self.num_envs, MRE_MAX_PROPS, 3)
+        check(_lib.lib().mre_set_props(self._h, _ptr(n), _ptr(s)), "mre_set_props")
+        self.sync()
+
+    def reset(self, mask=None) -> None:
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        check(_lib.lib().mre_reset(self._h, _ptr(m)), "mre_reset")
+        self.sync()
+
+    def place_props(self, seed: int, ws_min, ws_max, mask=None, max_attempts: int = 1000,
+                    settle_steps: int = 300) -> None:
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        lo = np.ascontiguousarray(ws_min, np.float32)
+        hi = np.ascontiguousarray(ws_max, np.float32)
+        check(_lib.lib().mre_place_props(self._h, _ptr(m), int(seed), _ptr(lo), _ptr(hi),
+                                         int(max_attempts), int(settle_steps)), "mre_place_props")
+        self.sync()
+
+    # --------------------------------------------------------------- state
+    def set_state(self, qpos=None, qvel=None) -> None:
+        def prep(x, w, wp):
+            if x is None:
+                return None
+            if isinstance(x, torch.Tensor):
+                x = x.detach().to(torch.float32)
+                if x.shape[-1] == w:
+                    x = torch.nn.functional.pad(x, (0, wp - w))
+                return x.contiguous()
+            x = np.asarray(x, np.float32)
+            if x.shape[-1] == w:
+                x = np.concatenate([x, np.zeros((x.shape[0], wp - w), np.float32)], axis=1)
+            return np.ascontiguousarray(x)
+        qp, qv = prep(qpos, MRE_NQ, MRE_NQ_PAD), prep(qvel, MRE_NV, MRE_NV_PAD)
+        check(_lib.lib().mre_set_state(self._h, _ptr(qp), _ptr(qv)), "mre_set_state")
+        self.sync()
+
+    def get_state(self) -> Tuple[np.ndarray, np.ndarray]:
+        qp = np.empty((self.num_envs, MRE_NQ_PAD), np.float32)
+        qv = np.empty((self.num_envs, MRE_NV_PAD), np.float32)
+        check(_lib.lib().mre_get_state(self._h, _ptr(qp), _ptr(qv)), "mre_get_state")
+        return qp[:, :MRE_NQ], qv[:, :MRE_NV]
+
+    def qpos(self) -> np.ndarray:
+        return self.get_state()[0]
+
+    def qvel(self) -> np.ndarray:
+        return self.get_state()[1]
+
+    def set_warmstart(self, w) -> None:
+        w = np.asarray(w, np.float32)
+        if w.shape[-1] == MRE_NV:
+            w = np.concatenate([w, np.zeros((w.shape[0], 1), np.float32)], axis=1)
+        w = np.ascontiguousarray(w)
+        check(_lib.lib().mre_set_warmstart(self._h, _ptr(w)), "mre_set_warmstart")
+        self.sync()
+
+    def set_control(self, ctrl) -> None:
+        if isinstance(ctrl, torch.Tensor):
+            c = ctrl.detach().to(torch.float32).contiguous()
+        else:
+            c = np.ascontiguousarray(ctrl, np.float32)
+        assert tuple(c.shape) == (self.num_envs, MRE_NU)
+        check(_lib.lib().mre_set_ctrl(self._h, _ptr(c)), "mre_set_ctrl")
+        if not isinstance(ctrl, torch.Tensor):
+            self.sync()
+
+    # ---------------------------------------------------------------- step
+    def step(self, nsubsteps: int = 1, flags: int = 0) -> None:
+        check(_lib.lib().mre_step(self._h, int(nsubsteps), int(flags)), "mre_step")
+
+    def rollout(self, ctrl_seq: torch.Tensor, control_steps: int = 5, flags: int = 0) -> None:
+        """ctrl_seq: cuda float32 [T, N, 8]; one launch for T*control_steps steps."""
+        assert ctrl_seq.is_cuda and ctrl_seq.dtype == torch.float32 and ctrl_seq.is_contiguous()
+        assert ctrl_seq.shape[1:] == (self.num_envs, MRE_NU)
+        check(_lib.lib().mre_rollout(self._h, ctrl_seq.data_ptr(), int(ctrl_seq.shape[0]),
+                                     int(control_steps), int(flags)), "mre_rollout")
+
+    def set_trace(self, nenv: int, max_steps: int) -> Optional[torch.Tensor]:
+        """Capture qpos of the first ``nenv`` envs after every step (parity tests)."""
+        if nenv <= 0:
+            self._trace = None
+            check(_lib.lib().mre_set_trace(self._h, None, 0, 0), "mre_set_trace")
+            return None
+        self._trace = torch.zeros((max_steps, nenv, MRE_NQ_PAD), dtype=torch.float32,
+                                  device=self.device)
+        check(_lib.lib().mre_set_trace(self._h, self._trace.data_ptr(), nenv, max_steps),
+              "mre_set_trace")
+        return self._trace
+
+    # ----------------------------------------------------------- controller
+    def osc_configure(self, gains=None, null_q=None, thresholds=None, pinv_always: bool = False):
+        g = None if gains is None else np.ascontiguousarray(gains, np.float32)
+        q = None if null_q is None else np.ascontiguousarray(null_q, np.float32)
+        t = None if thresholds is None else np.ascontiguousarray(thresholds, np.float32)
+        check(_lib.lib().mre_osc_configure(self._h, _ptr(g), _ptr(q), _ptr(t), int(pinv_always)),
+              "mre_osc_configure")
+
+    def osc_set_target(self, position=None, quat=None, velocity=None, angular_velocity=None,
+                       mask=None) -> None:
+        def prep(x, w):
+            if x is None:
+                return None
+            x = np.asarray(x, np.float32)
+            if x.ndim == 1:
+                x = np.tile(x, (self.num_envs, 1))
+            assert x.shape == (self.num_envs, w)
+            return np.ascontiguousarray(x)
+        p, q = prep(position, 3), prep(quat, 4)
+        v, w = prep(velocity, 3), prep(angular_velocity, 3)
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        check(_lib.lib().mre_osc_set_target(self._h, _ptr(p), _ptr(q), _ptr(v), _ptr(w), _ptr(m)),
+              "mre_osc_set_target")
+
+    def gripper_set(self, closed) -> None:
+        c = np.ascontiguousarray(np.broadcast_to(np.asarray(closed, np.uint8), (self.num_envs,)))
+        check(_lib.lib().mre_gripper_set(self._h, _ptr(c)), "mre_gripper_set")
+        self.sync()
+
+    def run_controller(self, nticks: int, control_steps: int = 5) -> np.ndarray:
+        conv = np.zeros(self.num_envs, np.uint8)
+        check(_lib.lib().mre_run_controller(self._h, int(nticks), int(control_steps), _ptr(conv)),
+              "mre_run_controller")
+        return conv.astype(bool)
+
+    # -------------------------------------------------------------- queries
+    def sites(self):
+        tcp = np.empty((self.num_envs, 3), np.float32)
+        eef = np.empty((self.num_envs, 7), np.float32)
+        props = np.empty((self.num_envs, MRE_MAX_PROPS, 7), np.float32)
+        check(_lib.lib().mre_get_sites(self._h, _ptr(tcp), _ptr(eef), _ptr(props)), "mre_get_sites")
+        return tcp, eef, props
+
+    def status(self) -> np.ndarray:
+        st = np.empty(self.num_envs, np.uint32)
+        check(_lib.lib().mre_get_status(self._h, _ptr(st)), "mre_get_status")
+        return st
+
+    def solver_stats(self) -> np.ndarray:
+        st = np.empty((self.num_envs, 4), np.int32)
+        check(_lib.lib().mre_get_solver_stats(self._h, _ptr(st)), "mre_get_solver_stats")
+        return st

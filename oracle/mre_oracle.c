@@ -1,0 +1,1524 @@
+/* mre_oracle.c -- TEST INFRASTRUCTURE (see mre_oracle.h header: PARITY UNPINNED).
+ *
+ * Plain C, fp64 restatement of the computation the reference performs per
+ * physics.step() (models/robot_arm.py:79; dm_control legacy step = mj_step2
+ * then mj_step1) and per OSC evaluation
+ * (tasks/rearrangement_mjx.py:59-135).  MuJoCo 3.2.7 itself is an absent
+ * third-party dependency (pyproject.toml:42): function names in comments
+ * (mj_kinematics, mj_crb, ...) name the published MuJoCo stage restated.
+ *
+ * Conventions follow MuJoCo: quaternions (w,x,y,z); spatial vectors
+ * [rot(3); lin(3)] expressed in the world-aligned frame centred at the
+ * subtree COM of each kinematic-tree root ("c-frame"); sparse mass matrix
+ * addressed by dof_Madr / dof_parentid; constraint rows ordered
+ * equality, limit, contact.
+ */
+#include "mre_oracle.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define MINVAL 1e-15
+#define JNT_HINGE 1
+#define JNT_FREE 2
+#define GEOM_PLANE 0
+#define GEOM_BOX 1
+#define EQ_CONNECT 0
+#define EQ_JOINT 1
+enum { EFC_EQ = 0, EFC_LIMIT = 1, EFC_CONTACT = 2 };
+
+struct mro_model {
+  int nbody, nv, nq, nM, ngeom, nsite, npair, neq, nprop;
+  int body_parentid[MRO_MAXB], body_rootid[MRO_MAXB], body_jnttype[MRO_MAXB];
+  int body_dofadr[MRO_MAXB], body_dofnum[MRO_MAXB], body_qposadr[MRO_MAXB], body_propid[MRO_MAXB];
+  double body_pos[MRO_MAXB][3], body_quat[MRO_MAXB][4], body_ipos[MRO_MAXB][3],
+      body_iquat[MRO_MAXB][4], body_mass[MRO_MAXB], body_inertia[MRO_MAXB][3],
+      body_invweight0[MRO_MAXB][2];
+  double jnt_pos[MRO_MAXB][3], jnt_axis[MRO_MAXB][3], jnt_range[MRO_MAXB][2],
+      jnt_stiffness[MRO_MAXB], jnt_springref[MRO_MAXB], jnt_solref[MRO_MAXB][2],
+      jnt_solimp[MRO_MAXB][5];
+  int jnt_limited[MRO_MAXB];
+  int dof_bodyid[MRO_MAXV], dof_parentid[MRO_MAXV], dof_Madr[MRO_MAXV + 1];
+  double dof_armature[MRO_MAXV], dof_damping[MRO_MAXV], dof_invweight0[MRO_MAXV],
+      qpos0[MRO_MAXQ], M0_diag[MRO_MAXV];
+  int geom_type[MRO_MAXG], geom_bodyid[MRO_MAXG], geom_propid[MRO_MAXG];
+  double geom_size[MRO_MAXG][3], geom_pos[MRO_MAXG][3], geom_quat[MRO_MAXG][4],
+      geom_rbound[MRO_MAXG];
+  int pair_geom[MRO_MAXPAIR][2];
+  double pair_friction[MRO_MAXPAIR][3], pair_solref[MRO_MAXPAIR][2], pair_solimp[MRO_MAXPAIR][5],
+      pair_margin[MRO_MAXPAIR], pair_gap[MRO_MAXPAIR];
+  int site_bodyid[MRO_MAXS];
+  double site_pos[MRO_MAXS][3], site_quat[MRO_MAXS][4];
+  int eq_type[MRO_MAXEQ], eq_obj[MRO_MAXEQ][2];
+  double eq_data[MRO_MAXEQ][8], eq_solref[MRO_MAXEQ][2], eq_solimp[MRO_MAXEQ][5];
+  int ten_dof[2];
+  double ten_coef[2];
+  int act_dof[MRO_NU];
+  double act_ctrlrange[MRO_NU][2], grip_gainprm, grip_biasprm[3], grip_forcerange[2];
+  double timestep, gravity[3], impratio, tolerance;
+  int iterations;
+  int arm_dof[7], eef_site, tcp_site, prop_bodyid[MRO_MAXPROP];
+  double home_qpos[7];
+};
+
+typedef struct {
+  double pos[3], frame[9], dist, includemargin, friction[5], solref[2], solimp[5], mu;
+  int geom1, geom2, body1, body2, efc_address;
+} mro_contact_t;
+
+struct mro_data {
+  /* per-env model parameters */
+  int nprops, freeze_robot, no_constraints, ncon_cap, nefc_cap;
+  int body_active[MRO_MAXB], dof_active[MRO_MAXV];
+  double body_mass[MRO_MAXB], body_inertia[MRO_MAXB][3], body_invweight0[MRO_MAXB][2],
+      dof_invweight0[MRO_MAXV], geom_size[MRO_MAXG][3], geom_rbound[MRO_MAXG];
+  double meaninertia;
+  int nv_active;
+  /* state */
+  double qpos[MRO_MAXQ], qvel[MRO_MAXV], ctrl[MRO_NU], qacc_warmstart[MRO_MAXV], time;
+  /* position stage */
+  double xpos[MRO_MAXB][3], xquat[MRO_MAXB][4], xmat[MRO_MAXB][9], xipos[MRO_MAXB][3],
+      ximat[MRO_MAXB][9], xanchor[MRO_MAXB][3], xaxis[MRO_MAXB][3];
+  double geom_xpos[MRO_MAXG][3], geom_xmat[MRO_MAXG][9], site_xpos[MRO_MAXS][3],
+      site_xmat[MRO_MAXS][9];
+  double subtree_com[MRO_MAXB][3], cinert[MRO_MAXB][10], crb[MRO_MAXB][10], cdof[MRO_MAXV][6];
+  double ten_length, ten_velocity;
+  double qM[MRO_MAXM], qLD[MRO_MAXM], qLDiagInv[MRO_MAXV];
+  int ncon, nefc, ne, nl;
+  mro_contact_t contact[MRO_MAXCON];
+  int efc_type[MRO_MAXEFC], efc_id[MRO_MAXEFC];
+  double efc_J[MRO_MAXEFC][MRO_MAXV], efc_pos[MRO_MAXEFC], efc_margin[MRO_MAXEFC],
+      efc_diagApprox[MRO_MAXEFC], efc_R[MRO_MAXEFC], efc_D[MRO_MAXEFC], efc_KBIP[MRO_MAXEFC][4],
+      efc_vel[MRO_MAXEFC], efc_aref[MRO_MAXEFC], efc_b[MRO_MAXEFC], efc_force[MRO_MAXEFC];
+  double* efc_AR; /* nefc x nefc, MRO_MAXEFC stride */
+  double (*efc_B)[MRO_MAXV]; /* M^-1 J' rows (scratch of mj_projectConstraint) */
+  /* velocity stage */
+  double cvel[MRO_MAXB][6], cdof_dot[MRO_MAXV][6], qfrc_bias[MRO_MAXV], qfrc_passive[MRO_MAXV];
+  /* acceleration stage */
+  double actuator_force[MRO_NU], qfrc_actuator[MRO_MAXV], qfrc_smooth[MRO_MAXV],
+      qacc_smooth[MRO_MAXV], qfrc_constraint[MRO_MAXV], qacc[MRO_MAXV];
+  int grip_clamped;
+  int solver_iters;
+};
+
+/* ------------------------------------------------------------------ vec3 */
+static inline void v3copy(double* r, const double* a) { r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; }
+static inline void v3zero(double* r) { r[0] = r[1] = r[2] = 0; }
+static inline void v3add(double* r, const double* a, const double* b) {
+  r[0] = a[0] + b[0]; r[1] = a[1] + b[1]; r[2] = a[2] + b[2];
+}
+static inline void v3sub(double* r, const double* a, const double* b) {
+  r[0] = a[0] - b[0]; r[1] = a[1] - b[1]; r[2] = a[2] - b[2];
+}
+static inline double v3dot(const double* a, const double* b) {
+  return a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+}
+static inline void v3cross(double* r, const double* a, const double* b) {
+  double x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+static inline void v3addscl(double* r, const double* a, double s) {
+  r[0] += a[0] * s; r[1] += a[1] * s; r[2] += a[2] * s;
+}
+static inline double v3norm(const double* a) { return sqrt(v3dot(a, a)); }
+static inline double v3normalize(double* a) {
+  double n = v3norm(a);
+  if (n < MINVAL) { a[0] = 1; a[1] = 0; a[2] = 0; return n; }
+  a[0] /= n; a[1] /= n; a[2] /= n;
+  return n;
+}
+/* r = M(3x3 row-major) * v */
+static inline void m3mulv(double* r, const double* m, const double* v) {
+  double x = m[0] * v[0] + m[1] * v[1] + m[2] * v[2];
+  double y = m[3] * v[0] + m[4] * v[1] + m[5] * v[2];
+  double z = m[6] * v[0] + m[7] * v[1] + m[8] * v[2];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+/* r = M^T * v */
+static inline void m3tmulv(double* r, const double* m, const double* v) {
+  double x = m[0] * v[0] + m[3] * v[1] + m[6] * v[2];
+  double y = m[1] * v[0] + m[4] * v[1] + m[7] * v[2];
+  double z = m[2] * v[0] + m[5] * v[1] + m[8] * v[2];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+/* ------------------------------------------------------------------ quat */
+static void qmul(double* r, const double* a, const double* b) {
+  double w = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+  double x = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+  double y = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
+  double z = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+  r[0] = w; r[1] = x; r[2] = y; r[3] = z;
+}
+static void qnormalize(double* q) {
+  double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  if (n < MINVAL) { q[0] = 1; q[1] = q[2] = q[3] = 0; return; }
+  q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n;
+}
+static void q2mat(double* m, const double* q) {
+  double w = q[0], x = q[1], y = q[2], z = q[3];
+  m[0] = w * w + x * x - y * y - z * z; m[1] = 2 * (x * y - w * z); m[2] = 2 * (x * z + w * y);
+  m[3] = 2 * (x * y + w * z); m[4] = w * w - x * x + y * y - z * z; m[5] = 2 * (y * z - w * x);
+  m[6] = 2 * (x * z - w * y); m[7] = 2 * (y * z + w * x); m[8] = w * w - x * x - y * y + z * z;
+}
+static void qrotv(double* r, const double* q, const double* v) {
+  double m[9];
+  q2mat(m, q);
+  m3mulv(r, m, v);
+}
+static void axisangle2q(double* q, const double* axis, double angle) {
+  double s = sin(angle * 0.5);
+  q[0] = cos(angle * 0.5); q[1] = axis[0] * s; q[2] = axis[1] * s; q[3] = axis[2] * s;
+}
+/* mju_mat2Quat */
+static void mat2q(double* q, const double* m) {
+  double t = m[0] + m[4] + m[8];
+  if (t > 0) {
+    double s = sqrt(t + 1.0) * 2;
+    q[0] = 0.25 * s; q[1] = (m[7] - m[5]) / s; q[2] = (m[2] - m[6]) / s; q[3] = (m[3] - m[1]) / s;
+  } else if (m[0] > m[4] && m[0] > m[8]) {
+    double s = sqrt(1.0 + m[0] - m[4] - m[8]) * 2;
+    q[0] = (m[7] - m[5]) / s; q[1] = 0.25 * s; q[2] = (m[1] + m[3]) / s; q[3] = (m[2] + m[6]) / s;
+  } else if (m[4] > m[8]) {
+    double s = sqrt(1.0 + m[4] - m[0] - m[8]) * 2;
+    q[0] = (m[2] - m[6]) / s; q[1] = (m[1] + m[3]) / s; q[2] = 0.25 * s; q[3] = (m[5] + m[7]) / s;
+  } else {
+    double s = sqrt(1.0 + m[8] - m[0] - m[4]) * 2;
+    q[0] = (m[3] - m[1]) / s; q[1] = (m[2] + m[6]) / s; q[2] = (m[5] + m[7]) / s; q[3] = 0.25 * s;
+  }
+  qnormalize(q);
+}
+
+/* --------------------------------------------------------- spatial algebra */
+static void mul_inert_vec(double* r, const double* i, const double* v) {
+  r[0] = i[0] * v[0] + i[3] * v[1] + i[4] * v[2] - i[8] * v[4] + i[7] * v[5];
+  r[1] = i[3] * v[0] + i[1] * v[1] + i[5] * v[2] + i[8] * v[3] - i[6] * v[5];
+  r[2] = i[4] * v[0] + i[5] * v[1] + i[2] * v[2] - i[7] * v[3] + i[6] * v[4];
+  r[3] = i[8] * v[1] - i[7] * v[2] + i[9] * v[3];
+  r[4] = i[6] * v[2] - i[8] * v[0] + i[9] * v[4];
+  r[5] = i[7] * v[0] - i[6] * v[1] + i[9] * v[5];
+}
+static void cross_motion(double* r, const double* vel, const double* v) {
+  double a[3], b[3];
+  v3cross(r, vel, v);
+  v3cross(a, vel, v + 3);
+  v3cross(b, vel + 3, v);
+  v3add(r + 3, a, b);
+}
+static void cross_force(double* r, const double* vel, const double* f) {
+  double a[3], b[3];
+  v3cross(a, vel, f);
+  v3cross(b, vel + 3, f + 3);
+  v3add(r, a, b);
+  v3cross(r + 3, vel, f + 3);
+}
+static inline double dot6(const double* a, const double* b) {
+  return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3] + a[4] * b[4] + a[5] * b[5];
+}
+
+/* -------------------------------------------------------------- blob load */
+typedef struct { char name[32]; uint32_t code, count; uint64_t off; } blob_entry;
+static int blob_find(const unsigned char* blob, const char* name, blob_entry* e) {
+  uint32_t n;
+  memcpy(&n, blob + 8, 4);
+  const unsigned char* t = blob + 16;
+  for (uint32_t k = 0; k < n; k++, t += 48) {
+    if (strncmp((const char*)t, name, 32) == 0) {
+      memcpy(e->name, t, 32); memcpy(&e->code, t + 32, 4); memcpy(&e->count, t + 36, 4);
+      memcpy(&e->off, t + 40, 8);
+      return 1;
+    }
+  }
+  return 0;
+}
+static int blob_i(const unsigned char* blob, const char* name, int* dst, int maxn) {
+  blob_entry e;
+  if (!blob_find(blob, name, &e) || e.code != 0 || (int)e.count > maxn) {
+    fprintf(stderr, "mro: bad int entry %s\n", name);
+    return -1;
+  }
+  memcpy(dst, blob + e.off, 4 * (size_t)e.count);
+  return (int)e.count;
+}
+static int blob_d(const unsigned char* blob, const char* name, double* dst, int maxn) {
+  blob_entry e;
+  if (!blob_find(blob, name, &e) || e.code != 1 || (int)e.count > maxn) {
+    fprintf(stderr, "mro: bad f64 entry %s\n", name);
+    return -1;
+  }
+  memcpy(dst, blob + e.off, 8 * (size_t)e.count);
+  return (int)e.count;
+}
+#define LI(field, max) if (blob_i(b, #field, (int*)m->field, max) < 0) goto fail
+#define LD(field, max) if (blob_d(b, #field, (double*)m->field, max) < 0) goto fail
+#define LI1(field, name) if (blob_i(b, name, &m->field, 1) < 0) goto fail
+#define LD1(field, name) if (blob_d(b, name, &m->field, 1) < 0) goto fail
+
+mro_model* mro_model_load(const void* blob, size_t nbytes) {
+  const unsigned char* b = (const unsigned char*)blob;
+  uint32_t magic;
+  if (nbytes < 16) return NULL;
+  memcpy(&magic, b, 4);
+  if (magic != 0x4D524542u) return NULL;
+  mro_model* m = (mro_model*)calloc(1, sizeof(mro_model));
+  LI1(nbody, "nbody"); LI1(nv, "nv"); LI1(nq, "nq"); LI1(nM, "nM"); LI1(ngeom, "ngeom");
+  LI1(nsite, "nsite"); LI1(npair, "npair"); LI1(neq, "neq"); LI1(nprop, "nprop");
+  if (m->nbody > MRO_MAXB || m->nv > MRO_MAXV - 1 || m->nq > MRO_MAXQ || m->nM > MRO_MAXM ||
+      m->ngeom > MRO_MAXG || m->npair > MRO_MAXPAIR || m->neq > MRO_MAXEQ ||
+      m->nsite > MRO_MAXS || m->nprop > MRO_MAXPROP)
+    goto fail;
+  LI(body_parentid, MRO_MAXB); LI(body_rootid, MRO_MAXB); LI(body_jnttype, MRO_MAXB);
+  LI(body_dofadr, MRO_MAXB); LI(body_dofnum, MRO_MAXB); LI(body_qposadr, MRO_MAXB);
+  LI(body_propid, MRO_MAXB);
+  LD(body_pos, MRO_MAXB * 3); LD(body_quat, MRO_MAXB * 4); LD(body_ipos, MRO_MAXB * 3);
+  LD(body_iquat, MRO_MAXB * 4); LD(body_mass, MRO_MAXB); LD(body_inertia, MRO_MAXB * 3);
+  LD(body_invweight0, MRO_MAXB * 2);
+  LD(jnt_pos, MRO_MAXB * 3); LD(jnt_axis, MRO_MAXB * 3); LD(jnt_range, MRO_MAXB * 2);
+  LD(jnt_stiffness, MRO_MAXB); LD(jnt_springref, MRO_MAXB); LD(jnt_solref, MRO_MAXB * 2);
+  LD(jnt_solimp, MRO_MAXB * 5); LI(jnt_limited, MRO_MAXB);
+  LI(dof_bodyid, MRO_MAXV); LI(dof_parentid, MRO_MAXV); LI(dof_Madr, MRO_MAXV);
+  m->dof_Madr[m->nv] = m->nM;
+  LD(dof_armature, MRO_MAXV); LD(dof_damping, MRO_MAXV); LD(dof_invweight0, MRO_MAXV);
+  LD(qpos0, MRO_MAXQ); LD(M0_diag, MRO_MAXV);
+  LI(geom_type, MRO_MAXG); LI(geom_bodyid, MRO_MAXG); LI(geom_propid, MRO_MAXG);
+  LD(geom_size, MRO_MAXG * 3); LD(geom_pos, MRO_MAXG * 3); LD(geom_quat, MRO_MAXG * 4);
+  LD(geom_rbound, MRO_MAXG);
+  LI(pair_geom, MRO_MAXPAIR * 2); LD(pair_friction, MRO_MAXPAIR * 3);
+  LD(pair_solref, MRO_MAXPAIR * 2); LD(pair_solimp, MRO_MAXPAIR * 5);
+  LD(pair_margin, MRO_MAXPAIR); LD(pair_gap, MRO_MAXPAIR);
+  LI(site_bodyid, MRO_MAXS); LD(site_pos, MRO_MAXS * 3); LD(site_quat, MRO_MAXS * 4);
+  LI(eq_type, MRO_MAXEQ); LI(eq_obj, MRO_MAXEQ * 2); LD(eq_data, MRO_MAXEQ * 8);
+  LD(eq_solref, MRO_MAXEQ * 2); LD(eq_solimp, MRO_MAXEQ * 5);
+  LI(ten_dof, 2); LD(ten_coef, 2); LI(act_dof, MRO_NU); LD(act_ctrlrange, MRO_NU * 2);
+  LD1(grip_gainprm, "grip_gainprm"); LD(grip_biasprm, 3); LD(grip_forcerange, 2);
+  LD1(timestep, "opt_timestep"); if (blob_d(b, "opt_gravity", m->gravity, 3) < 0) goto fail;
+  LD1(impratio, "opt_impratio"); LD1(tolerance, "opt_tolerance");
+  LI1(iterations, "opt_iterations");
+  LI(arm_dof, 7); LI1(eef_site, "eef_site"); LI1(tcp_site, "tcp_site");
+  if (blob_i(b, "prop_bodyid", m->prop_bodyid, MRO_MAXPROP) < 0) goto fail;
+  LD(home_qpos, 7);
+  return m;
+fail:
+  free(m);
+  return NULL;
+}
+void mro_model_free(mro_model* m) { free(m); }
+
+mro_data* mro_data_new(const mro_model* m, int nprops, const double* prop_size) {
+  mro_data* d = (mro_data*)calloc(1, sizeof(mro_data));
+  d->efc_AR = (double*)calloc((size_t)MRO_MAXEFC * MRO_MAXEFC, sizeof(double));
+  d->efc_B = (double(*)[MRO_MAXV])calloc((size_t)MRO_MAXEFC, sizeof(double[MRO_MAXV]));
+  d->nprops = nprops;
+  memcpy(d->body_mass, m->body_mass, sizeof(d->body_mass));
+  memcpy(d->body_inertia, m->body_inertia, sizeof(d->body_inertia));
+  memcpy(d->body_invweight0, m->body_invweight0, sizeof(d->body_invweight0));
+  memcpy(d->dof_invweight0, m->dof_invweight0, sizeof(d->dof_invweight0));
+  memcpy(d->geom_size, m->geom_size, sizeof(d->geom_size));
+  memcpy(d->geom_rbound, m->geom_rbound, sizeof(d->geom_rbound));
+  double msum = 0;
+  int nva = 0;
+  for (int b = 0; b < m->nbody; b++) {
+    int p = m->body_propid[b];
+    d->body_active[b] = (p < 0) || (p < nprops);
+    if (p >= 0 && p < nprops && prop_size) {
+      /* cube of geom mass body_mass (environment/props.py:238): box inertia */
+      const double* s = prop_size + 3 * p;
+      double mass = m->body_mass[b];
+      d->body_inertia[b][0] = mass / 3 * (s[1] * s[1] + s[2] * s[2]);
+      d->body_inertia[b][1] = mass / 3 * (s[0] * s[0] + s[2] * s[2]);
+      d->body_inertia[b][2] = mass / 3 * (s[0] * s[0] + s[1] * s[1]);
+      double ir = (1 / d->body_inertia[b][0] + 1 / d->body_inertia[b][1] + 1 / d->body_inertia[b][2]) / 3;
+      d->body_invweight0[b][0] = 1 / mass;
+      d->body_invweight0[b][1] = ir;
+      int da = m->body_dofadr[b];
+      for (int k = 0; k < 3; k++) { d->dof_invweight0[da + k] = 1 / mass; d->dof_invweight0[da + 3 + k] = ir; }
+    }
+  }
+  for (int g = 0; g < m->ngeom; g++) {
+    int p = m->geom_propid[g];
+    if (p >= 0 && p < nprops && prop_size) {
+      for (int k = 0; k < 3; k++) d->geom_size[g][k] = prop_size[3 * p + k];
+      d->geom_rbound[g] = sqrt(v3dot(d->geom_size[g], d->geom_size[g]));
+    }
+  }
+  for (int i = 0; i < m->nv; i++) {
+    d->dof_active[i] = d->body_active[m->dof_bodyid[i]];
+    if (d->dof_active[i]) {
+      int b = m->dof_bodyid[i];
+      int k = i - m->body_dofadr[b];
+      double diag = m->M0_diag[i];
+      if (m->body_propid[b] >= 0) diag = (k < 3) ? d->body_mass[b] : d->body_inertia[b][k - 3];
+      msum += diag;
+      nva++;
+    }
+  }
+  d->nv_active = nva;
+  d->meaninertia = msum / (nva > 0 ? nva : 1); /* mj_setConst: stat.meaninertia */
+  mro_reset(m, d);
+  return d;
+}
+void mro_data_free(mro_data* d) {
+  if (d) { free(d->efc_AR); free(d->efc_B); free(d); }
+}
+void mro_set_freeze_robot(mro_data* d, int f) { d->freeze_robot = f; }
+void mro_set_no_constraints(mro_data* d, int f) { d->no_constraints = f; }
+void mro_set_caps(mro_data* d, int ncon_cap, int nefc_cap) { d->ncon_cap = ncon_cap; d->nefc_cap = nefc_cap; }
+int mro_solver_iters(const mro_data* d) { return d->solver_iters; }
+int mro_ncon(const mro_data* d) { return d->ncon; }
+int mro_nefc(const mro_data* d) { return d->nefc; }
+void mro_contact(const mro_data* d, int i, double* out) {
+  const mro_contact_t* c = &d->contact[i];
+  memcpy(out, c->pos, 24); memcpy(out + 3, c->frame, 72);
+  out[12] = c->dist; out[13] = c->geom1; out[14] = c->geom2;
+}
+
+void mro_reset(const mro_model* m, mro_data* d) {
+  memcpy(d->qpos, m->qpos0, sizeof(double) * m->nq);
+  for (int p = 0; p < m->nprop; p++) {
+    /* park cube slots on a grid well below the ground plane; inactive ones stay there */
+    int qa = m->body_qposadr[m->prop_bodyid[p]];
+    d->qpos[qa] = 2.0 + 0.5 * p; d->qpos[qa + 1] = 2.0; d->qpos[qa + 2] = -5.0;
+    d->qpos[qa + 3] = 1; d->qpos[qa + 4] = d->qpos[qa + 5] = d->qpos[qa + 6] = 0;
+  }
+  memset(d->qvel, 0, sizeof(d->qvel));
+  memset(d->ctrl, 0, sizeof(d->ctrl));
+  memset(d->qacc_warmstart, 0, sizeof(d->qacc_warmstart));
+  memset(d->qacc, 0, sizeof(d->qacc));
+  d->time = 0;
+}
+
+/* ---------------------------------------------------------- mj_kinematics */
+static void kinematics(const mro_model* m, mro_data* d) {
+  v3zero(d->xpos[0]);
+  d->xquat[0][0] = 1; d->xquat[0][1] = d->xquat[0][2] = d->xquat[0][3] = 0;
+  q2mat(d->xmat[0], d->xquat[0]);
+  v3zero(d->xipos[0]);
+  q2mat(d->ximat[0], d->xquat[0]);
+  for (int b = 1; b < m->nbody; b++) {
+    int p = m->body_parentid[b], qa = m->body_qposadr[b];
+    double* xp = d->xpos[b];
+    double* xq = d->xquat[b];
+    if (m->body_jnttype[b] == JNT_FREE) {
+      v3copy(xp, d->qpos + qa);
+      qnormalize(d->qpos + qa + 3); /* MuJoCo normalises qpos quaternions in place */
+      memcpy(xq, d->qpos + qa + 3, 32);
+      v3copy(d->xanchor[b], xp);
+      d->xaxis[b][0] = 0; d->xaxis[b][1] = 0; d->xaxis[b][2] = 1;
+    } else {
+      double tmp[3];
+      m3mulv(tmp, d->xmat[p], m->body_pos[b]);
+      v3add(xp, d->xpos[p], tmp);
+      qmul(xq, d->xquat[p], m->body_quat[b]);
+      /* hinge: anchor/axis in world, rotate, correct off-centre rotation */
+      qrotv(tmp, xq, m->jnt_pos[b]);
+      v3add(d->xanchor[b], xp, tmp);
+      qrotv(d->xaxis[b], xq, m->jnt_axis[b]);
+      double ql[4], qn[4];
+      axisangle2q(ql, m->jnt_axis[b], d->qpos[qa] - m->qpos0[qa]);
+      qmul(qn, xq, ql);
+      memcpy(xq, qn, 32);
+      qrotv(tmp, xq, m->jnt_pos[b]);
+      v3sub(xp, d->xanchor[b], tmp);
+    }
+    qnormalize(xq);
+    q2mat(d->xmat[b], xq);
+    double tmp[3], qi[4];
+    m3mulv(tmp, d->xmat[b], m->body_ipos[b]);
+    v3add(d->xipos[b], xp, tmp);
+    qmul(qi, xq, m->body_iquat[b]);
+    q2mat(d->ximat[b], qi);
+  }
+  for (int g = 0; g < m->ngeom; g++) {
+    int b = m->geom_bodyid[g];
+    double tmp[3], q[4];
+    m3mulv(tmp, d->xmat[b], m->geom_pos[g]);
+    v3add(d->geom_xpos[g], d->xpos[b], tmp);
+    qmul(q, d->xquat[b], m->geom_quat[g]);
+    q2mat(d->geom_xmat[g], q);
+  }
+  for (int s = 0; s < m->nsite; s++) {
+    int b = m->site_bodyid[s];
+    double tmp[3], q[4];
+    m3mulv(tmp, d->xmat[b], m->site_pos[s]);
+    v3add(d->site_xpos[s], d->xpos[b], tmp);
+    qmul(q, d->xquat[b], m->site_quat[s]);
+    q2mat(d->site_xmat[s], q);
+  }
+}
+
+/* -------------------------------------------------------------- mj_comPos */
+static void com_pos(const mro_model* m, mro_data* d) {
+  double smass[MRO_MAXB];
+  for (int b = 0; b < m->nbody; b++) {
+    double ms = d->body_active[b] ? d->body_mass[b] : 0.0;
+    smass[b] = ms;
+    for (int k = 0; k < 3; k++) d->subtree_com[b][k] = ms * d->xipos[b][k];
+  }
+  for (int b = m->nbody - 1; b > 0; b--) {
+    int p = m->body_parentid[b];
+    v3add(d->subtree_com[p], d->subtree_com[p], d->subtree_com[b]);
+    smass[p] += smass[b];
+  }
+  for (int b = 0; b < m->nbody; b++) {
+    if (smass[b] < MINVAL) v3copy(d->subtree_com[b], d->xipos[b]);
+    else for (int k = 0; k < 3; k++) d->subtree_com[b][k] /= smass[b];
+  }
+  /* cinert: mju_inertCom about the subtree COM of the tree root */
+  for (int b = 1; b < m->nbody; b++) {
+    double dif[3], tmp[9], mass = d->body_mass[b];
+    const double* mat = d->ximat[b];
+    const double* in = d->body_inertia[b];
+    v3sub(dif, d->xipos[b], d->subtree_com[m->body_rootid[b]]);
+    /* tmp = mat * diag(in) * mat' */
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++)
+        tmp[3 * r + c] = mat[3 * r] * in[0] * mat[3 * c] + mat[3 * r + 1] * in[1] * mat[3 * c + 1] +
+                         mat[3 * r + 2] * in[2] * mat[3 * c + 2];
+    double* ci = d->cinert[b];
+    ci[0] = tmp[0] + mass * (dif[1] * dif[1] + dif[2] * dif[2]);
+    ci[1] = tmp[4] + mass * (dif[0] * dif[0] + dif[2] * dif[2]);
+    ci[2] = tmp[8] + mass * (dif[0] * dif[0] + dif[1] * dif[1]);
+    ci[3] = tmp[1] - mass * dif[0] * dif[1];
+    ci[4] = tmp[2] - mass * dif[0] * dif[2];
+    ci[5] = tmp[5] - mass * dif[1] * dif[2];
+    ci[6] = mass * dif[0]; ci[7] = mass * dif[1]; ci[8] = mass * dif[2]; ci[9] = mass;
+  }
+  memset(d->cinert[0], 0, sizeof(d->cinert[0]));
+  /* cdof: mju_dofCom */
+  for (int b = 1; b < m->nbody; b++) {
+    int da = m->body_dofadr[b];
+    double off[3];
+    v3sub(off, d->subtree_com[m->body_rootid[b]], d->xanchor[b]);
+    if (m->body_jnttype[b] == JNT_HINGE) {
+      v3copy(d->cdof[da], d->xaxis[b]);
+      v3cross(d->cdof[da] + 3, d->xaxis[b], off);
+    } else {
+      for (int k = 0; k < 3; k++) {
+        memset(d->cdof[da + k], 0, 48);
+        d->cdof[da + k][3 + k] = 1;
+        double ax[3] = {d->xmat[b][k], d->xmat[b][3 + k], d->xmat[b][6 + k]};
+        v3copy(d->cdof[da + 3 + k], ax);
+        v3cross(d->cdof[da + 3 + k] + 3, ax, off);
+      }
+    }
+  }
+}
+
+/* ------------------------------------------------- mj_tendon (fixed only) */
+static void tendon(const mro_model* m, mro_data* d) {
+  /* hinge dofs of the robot precede the free joints: qpos index == dof index */
+  d->ten_length = m->ten_coef[0] * d->qpos[m->ten_dof[0]] + m->ten_coef[1] * d->qpos[m->ten_dof[1]];
+}
+
+/* ----------------------------------------------------- mj_crb, mj_factorM */
+static void crb(const mro_model* m, mro_data* d) {
+  memcpy(d->crb, d->cinert, sizeof(d->crb));
+  for (int b = m->nbody - 1; b > 0; b--) {
+    int p = m->body_parentid[b];
+    if (p > 0) for (int k = 0; k < 10; k++) d->crb[p][k] += d->crb[b][k];
+  }
+  memset(d->qM, 0, sizeof(double) * m->nM);
+  for (int i = 0; i < m->nv; i++) {
+    int adr = m->dof_Madr[i];
+    if (!d->dof_active[i]) { d->qM[adr] = 1.0; continue; }
+    double buf[6];
+    mul_inert_vec(buf, d->crb[m->dof_bodyid[i]], d->cdof[i]);
+    d->qM[adr] += m->dof_armature[i];
+    for (int j = i; j >= 0; j = m->dof_parentid[j]) d->qM[adr++] += dot6(d->cdof[j], buf);
+  }
+}
+static void factor_ld(const mro_model* m, double* LD, double* diaginv) {
+  for (int k = m->nv - 1; k >= 0; k--) {
+    int akk = m->dof_Madr[k], aki = akk + 1;
+    for (int i = m->dof_parentid[k]; i >= 0; i = m->dof_parentid[i], aki++) {
+      double tmp = LD[aki] / LD[akk];
+      int cnt = m->dof_Madr[i + 1] - m->dof_Madr[i];
+      for (int t = 0; t < cnt; t++) LD[m->dof_Madr[i] + t] -= tmp * LD[aki + t];
+      LD[aki] = tmp;
+    }
+    diaginv[k] = 1.0 / LD[akk];
+  }
+}
+static void solve_ld(const mro_model* m, const double* LD, const double* diaginv, double* x) {
+  int nv = m->nv;
+  for (int i = nv - 1; i >= 0; i--) {
+    if (x[i] == 0) continue;
+    int a = m->dof_Madr[i] + 1;
+    for (int j = m->dof_parentid[i]; j >= 0; j = m->dof_parentid[j]) x[j] -= LD[a++] * x[i];
+  }
+  for (int i = 0; i < nv; i++) x[i] *= diaginv[i];
+  for (int i = 0; i < nv; i++) {
+    int a = m->dof_Madr[i] + 1;
+    for (int j = m->dof_parentid[i]; j >= 0; j = m->dof_parentid[j]) x[i] -= LD[a++] * x[j];
+  }
+}
+static void factor_m(const mro_model* m, mro_data* d) {
+  memcpy(d->qLD, d->qM, sizeof(double) * m->nM);
+  factor_ld(m, d->qLD, d->qLDiagInv);
+}
+/* ---------------------------------------------------------- narrow phase */
+/* Sutherland-Hodgman clip of polygon (x,y,z=depth) against |x|<=sx, |y|<=sy */
+static int clip_poly(double (*p)[3], int n, double sx, double sy) {
+  double q[16][3];
+  for (int e = 0; e < 4; e++) {
+    int ax = e >> 1;                 /* 0: x, 1: y */
+    double sg = (e & 1) ? -1.0 : 1.0; /* keep sg*coord <= lim */
+    double lim = ax ? sy : sx;
+    int nq = 0;
+    for (int i = 0; i < n; i++) {
+      const double* a = p[i];
+      const double* b = p[(i + 1) % n];
+      double da = sg * a[ax] - lim, db = sg * b[ax] - lim;
+      if (da <= 0) { memcpy(q[nq++], a, 24); }
+      if ((da <= 0) != (db <= 0)) {
+        double t = da / (da - db);
+        for (int k = 0; k < 3; k++) q[nq][k] = a[k] + t * (b[k] - a[k]);
+        nq++;
+      }
+      if (nq >= 15) break;
+    }
+    n = nq;
+    memcpy(p, q, sizeof(double) * 3 * (size_t)n);
+    if (n == 0) return 0;
+  }
+  return n;
+}
+
+int mro_boxbox(const double* p1, const double* R1, const double* s1, const double* p2,
+               const double* R2, const double* s2, double margin, double* normal, double* pos,
+               double* dist) {
+  double A[3][3], B[3][3], dv[3], C[3][3], aC[3][3];
+  for (int i = 0; i < 3; i++)
+    for (int k = 0; k < 3; k++) { A[i][k] = R1[3 * k + i]; B[i][k] = R2[3 * k + i]; }
+  v3sub(dv, p2, p1);
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) { C[i][j] = v3dot(A[i], B[j]); aC[i][j] = fabs(C[i][j]); }
+  double tA[3], tB[3];
+  for (int i = 0; i < 3; i++) { tA[i] = v3dot(dv, A[i]); tB[i] = v3dot(dv, B[i]); }
+  double best_face = -1e30;
+  int face_code = -1;
+  for (int i = 0; i < 3; i++) {
+    double sep = fabs(tA[i]) - (s1[i] + s2[0] * aC[i][0] + s2[1] * aC[i][1] + s2[2] * aC[i][2]);
+    if (sep > best_face) { best_face = sep; face_code = i; }
+  }
+  for (int j = 0; j < 3; j++) {
+    double sep = fabs(tB[j]) - (s2[j] + s1[0] * aC[0][j] + s1[1] * aC[1][j] + s1[2] * aC[2][j]);
+    if (sep > best_face) { best_face = sep; face_code = 3 + j; }
+  }
+  if (best_face > margin) return 0;
+  double best_edge = -1e30;
+  int ei = -1, ej = -1;
+  double en[3] = {0, 0, 0};
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      double L[3];
+      v3cross(L, A[i], B[j]);
+      double len = v3norm(L);
+      if (len < 1e-6) continue;
+      int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+      double rA = s1[i1] * aC[i2][j] + s1[i2] * aC[i1][j];
+      double rB = s2[j1] * aC[i][j2] + s2[j2] * aC[i][j1];
+      double t = v3dot(dv, L);
+      double sep = (fabs(t) - rA - rB) / len;
+      if (sep > margin) return 0;
+      if (sep > best_edge) {
+        best_edge = sep; ei = i; ej = j;
+        double sg = (t >= 0 ? 1.0 : -1.0) / len;
+        en[0] = L[0] * sg; en[1] = L[1] * sg; en[2] = L[2] * sg;
+      }
+    }
+  int use_edge = (ei >= 0) && (best_edge - best_face > 0.05 * fabs(best_face) + 1e-7);
+  if (use_edge) {
+    /* supporting edges: on box1 furthest along +n, on box2 furthest along -n */
+    double c1[3], c2[3];
+    v3copy(c1, p1);
+    v3copy(c2, p2);
+    for (int k = 0; k < 3; k++) {
+      if (k != ei) v3addscl(c1, A[k], (v3dot(en, A[k]) >= 0 ? 1.0 : -1.0) * s1[k]);
+      if (k != ej) v3addscl(c2, B[k], (v3dot(en, B[k]) >= 0 ? -1.0 : 1.0) * s2[k]);
+    }
+    /* closest points of lines c1 + a*A[ei], c2 + b*B[ej] */
+    double w[3];
+    v3sub(w, c1, c2);
+    double uu = 1.0, vv = 1.0, uv = C[ei][ej], uw = v3dot(A[ei], w), vw = v3dot(B[ej], w);
+    double den = uu * vv - uv * uv;
+    double a = 0, bb = 0;
+    if (den > 1e-12) { a = (uv * vw - vv * uw) / den; bb = (uu * vw - uv * uw) / den; }
+    double q1[3], q2[3];
+    v3copy(q1, c1); v3addscl(q1, A[ei], a);
+    v3copy(q2, c2); v3addscl(q2, B[ej], bb);
+    v3copy(normal, en);
+    for (int k = 0; k < 3; k++) pos[k] = 0.5 * (q1[k] + q2[k]);
+    double df[3];
+    v3sub(df, q2, q1);
+    dist[0] = v3dot(df, en);
+    return dist[0] <= margin ? 1 : 0;
+  }
+  /* face contact: reference box owns the separating face */
+  const double *pr, *pi, *sr, *si;
+  double (*Ar)[3], (*Ai)[3];
+  int a;
+  double nr[3];
+  if (face_code < 3) {
+    a = face_code; pr = p1; pi = p2; sr = s1; si = s2; Ar = A; Ai = B;
+    double sg = tA[a] >= 0 ? 1.0 : -1.0;
+    for (int k = 0; k < 3; k++) { nr[k] = A[a][k] * sg; normal[k] = nr[k]; }
+  } else {
+    a = face_code - 3; pr = p2; pi = p1; sr = s2; si = s1; Ar = B; Ai = A;
+    double sg = tB[a] >= 0 ? -1.0 : 1.0; /* ref normal points from box2 toward box1 */
+    for (int k = 0; k < 3; k++) { nr[k] = B[a][k] * sg; normal[k] = -nr[k]; }
+  }
+  /* incident face: most anti-parallel to nr */
+  int kk = 0;
+  double bestd = -1;
+  for (int k = 0; k < 3; k++) {
+    double dd = fabs(v3dot(nr, Ai[k]));
+    if (dd > bestd) { bestd = dd; kk = k; }
+  }
+  double isg = v3dot(nr, Ai[kk]) >= 0 ? -1.0 : 1.0;
+  int ku = (kk + 1) % 3, kv = (kk + 2) % 3;
+  double ci[3];
+  v3copy(ci, pi);
+  v3addscl(ci, Ai[kk], isg * si[kk]);
+  int au = (a + 1) % 3, av = (a + 2) % 3;
+  double cr[3];
+  v3copy(cr, pr);
+  v3addscl(cr, nr, sr[a]);
+  static const double su_[4] = {1, -1, -1, 1}, sv_[4] = {1, 1, -1, -1};
+  double poly[16][3];
+  for (int v = 0; v < 4; v++) {
+    double w[3];
+    v3copy(w, ci);
+    v3addscl(w, Ai[ku], su_[v] * si[ku]);
+    v3addscl(w, Ai[kv], sv_[v] * si[kv]);
+    v3sub(w, w, cr);
+    poly[v][0] = v3dot(w, Ar[au]);
+    poly[v][1] = v3dot(w, Ar[av]);
+    poly[v][2] = v3dot(w, nr);
+  }
+  int n = clip_poly(poly, 4, sr[au], sr[av]);
+  int nc = 0;
+  for (int v = 0; v < n && nc < 8; v++) {
+    double dep = poly[v][2];
+    if (dep > margin) continue;
+    for (int k = 0; k < 3; k++)
+      pos[3 * nc + k] = cr[k] + poly[v][0] * Ar[au][k] + poly[v][1] * Ar[av][k] + 0.5 * dep * nr[k];
+    dist[nc] = dep;
+    nc++;
+  }
+  return nc;
+}
+
+/* mju_makeFrame: frame[0:3] given (unit); build tangents */
+static void make_frame(double* f) {
+  double y[3] = {0, 0, 0};
+  if (f[1] < 0.5 && f[1] > -0.5) y[1] = 1; else y[2] = 1;
+  double t = v3dot(f, y);
+  v3addscl(y, f, -t);
+  v3normalize(y);
+  v3copy(f + 3, y);
+  v3cross(f + 6, f, f + 3);
+}
+
+static void add_contact(const mro_model* m, mro_data* d, int pair, const double* pos,
+                        const double* normal, double dist) {
+  if (d->ncon >= MRO_MAXCON) return;
+  mro_contact_t* c = &d->contact[d->ncon++];
+  v3copy(c->pos, pos);
+  v3copy(c->frame, normal);
+  make_frame(c->frame);
+  c->dist = dist;
+  c->includemargin = m->pair_margin[pair] - m->pair_gap[pair];
+  const double* fr = m->pair_friction[pair];
+  c->friction[0] = fr[0]; c->friction[1] = fr[0]; c->friction[2] = fr[1];
+  c->friction[3] = fr[2]; c->friction[4] = fr[2];
+  memcpy(c->solref, m->pair_solref[pair], 16);
+  memcpy(c->solimp, m->pair_solimp[pair], 40);
+  c->geom1 = m->pair_geom[pair][0];
+  c->geom2 = m->pair_geom[pair][1];
+  c->body1 = m->geom_bodyid[c->geom1];
+  c->body2 = m->geom_bodyid[c->geom2];
+  c->mu = 0;
+  c->efc_address = -1;
+}
+
+/* mj_collision over the static pair table (engine_collision_driver.c filters
+ * are applied at compile time; here: bounding-sphere prune + narrow phase) */
+static void collision(const mro_model* m, mro_data* d) {
+  d->ncon = 0;
+  for (int k = 0; k < m->npair; k++) {
+    int g1 = m->pair_geom[k][0], g2 = m->pair_geom[k][1];
+    int b1 = m->geom_bodyid[g1], b2 = m->geom_bodyid[g2];
+    if (!d->body_active[b1] || !d->body_active[b2]) continue;
+    double margin = m->pair_margin[k];
+    if (m->geom_type[g1] == GEOM_PLANE) {
+      const double* pm = d->geom_xmat[g1];
+      double n[3] = {pm[2], pm[5], pm[8]}, df[3];
+      v3sub(df, d->geom_xpos[g2], d->geom_xpos[g1]);
+      double cd = v3dot(df, n);
+      if (cd - d->geom_rbound[g2] > margin) continue;
+      /* mjc_PlaneBox: corners below margin, at most 4 */
+      int cnt = 0;
+      const double* bm = d->geom_xmat[g2];
+      const double* s = d->geom_size[g2];
+      for (int c = 0; c < 8 && cnt < 4; c++) {
+        double loc[3] = {(c & 1 ? s[0] : -s[0]), (c & 2 ? s[1] : -s[1]), (c & 4 ? s[2] : -s[2])};
+        double w[3];
+        m3mulv(w, bm, loc);
+        v3add(w, w, d->geom_xpos[g2]);
+        double wd[3];
+        v3sub(wd, w, d->geom_xpos[g1]);
+        double ds = v3dot(wd, n);
+        if (ds > margin) continue;
+        v3addscl(w, n, -0.5 * ds);
+        add_contact(m, d, k, w, n, ds);
+        cnt++;
+      }
+    } else {
+      double df[3];
+      v3sub(df, d->geom_xpos[g2], d->geom_xpos[g1]);
+      double r = d->geom_rbound[g1] + d->geom_rbound[g2] + margin;
+      if (v3dot(df, df) > r * r) continue;
+      double normal[3], pos[24], dist[8];
+      int n = mro_boxbox(d->geom_xpos[g1], d->geom_xmat[g1], d->geom_size[g1], d->geom_xpos[g2],
+                         d->geom_xmat[g2], d->geom_size[g2], margin, normal, pos, dist);
+      for (int c = 0; c < n; c++) add_contact(m, d, k, pos + 3 * c, normal, dist[c]);
+    }
+  }
+}
+
+/* ---------------------------------------------------------- mj_jac (point) */
+static void jac_point(const mro_model* m, const mro_data* d, int body, const double* point,
+                      double* jacp /*3 x nv*/, double* jacr /*3 x nv or NULL*/) {
+  int nv = m->nv;
+  memset(jacp, 0, sizeof(double) * 3 * nv);
+  if (jacr) memset(jacr, 0, sizeof(double) * 3 * nv);
+  if (body == 0) return;
+  double off[3];
+  v3sub(off, point, d->subtree_com[m->body_rootid[body]]);
+  int i = m->body_dofadr[body] + m->body_dofnum[body] - 1;
+  for (; i >= 0; i = m->dof_parentid[i]) {
+    const double* c = d->cdof[i];
+    double t[3];
+    v3cross(t, c, off);
+    for (int k = 0; k < 3; k++) {
+      jacp[k * nv + i] = c[3 + k] + t[k];
+      if (jacr) jacr[k * nv + i] = c[k];
+    }
+  }
+}
+
+/* ------------------------------------------------------ mj_makeConstraint */
+static int add_row(mro_data* d, int type, int id, const double* J, int nv, double pos,
+                   double margin, double diagApprox) {
+  if (d->nefc >= MRO_MAXEFC) return -1;
+  int r = d->nefc++;
+  d->efc_type[r] = type; d->efc_id[r] = id;
+  memcpy(d->efc_J[r], J, sizeof(double) * nv);
+  d->efc_pos[r] = pos; d->efc_margin[r] = margin; d->efc_diagApprox[r] = diagApprox;
+  return r;
+}
+
+static void make_constraint(const mro_model* m, mro_data* d) {
+  int nv = m->nv;
+  double jp1[3 * MRO_MAXV], jp2[3 * MRO_MAXV], J[MRO_MAXV];
+  d->nefc = 0;
+  /* equality (mj_instantiateEquality) */
+  for (int e = 0; e < m->neq; e++) {
+    if (m->eq_type[e] == EQ_CONNECT) {
+      int b1 = m->eq_obj[e][0], b2 = m->eq_obj[e][1];
+      double p1[3], p2[3], cpos[3];
+      m3mulv(p1, d->xmat[b1], m->eq_data[e]);
+      v3add(p1, p1, d->xpos[b1]);
+      m3mulv(p2, d->xmat[b2], m->eq_data[e] + 3);
+      v3add(p2, p2, d->xpos[b2]);
+      v3sub(cpos, p1, p2);
+      jac_point(m, d, b1, p1, jp1, NULL);
+      jac_point(m, d, b2, p2, jp2, NULL);
+      double da = d->body_invweight0[b1][0] + d->body_invweight0[b2][0];
+      for (int k = 0; k < 3; k++) {
+        for (int i = 0; i < nv; i++) J[i] = jp1[k * nv + i] - jp2[k * nv + i];
+        add_row(d, EFC_EQ, e, J, nv, cpos[k], 0.0, da);
+      }
+    } else {
+      int b1 = m->eq_obj[e][0], b2 = m->eq_obj[e][1];
+      int d1 = m->body_dofadr[b1], d2 = m->body_dofadr[b2];
+      int q1 = m->body_qposadr[b1], q2 = m->body_qposadr[b2];
+      const double* pc = m->eq_data[e];
+      double dif = d->qpos[q2] - m->qpos0[q2];
+      double pos = d->qpos[q1] - m->qpos0[q1] - (pc[0] + pc[1] * dif + pc[2] * dif * dif +
+                                                 pc[3] * dif * dif * dif + pc[4] * dif * dif * dif * dif);
+      double deriv = pc[1] + 2 * pc[2] * dif + 3 * pc[3] * dif * dif + 4 * pc[4] * dif * dif * dif;
+      memset(J, 0, sizeof(double) * nv);
+      J[d1] = 1; J[d2] = -deriv;
+      add_row(d, EFC_EQ, e, J, nv, pos, 0.0, d->dof_invweight0[d1] + d->dof_invweight0[d2]);
+    }
+  }
+  d->ne = d->nefc;
+  /* joint limits (mj_instantiateLimit), hinge only, margin 0 */
+  for (int b = 1; b < m->nbody; b++) {
+    if (m->body_jnttype[b] != JNT_HINGE || !m->jnt_limited[b]) continue;
+    int da = m->body_dofadr[b];
+    double q = d->qpos[m->body_qposadr[b]];
+    for (int side = -1; side <= 1; side += 2) {
+      double dist = side * (m->jnt_range[b][(side + 1) / 2] - q);
+      if (dist < 0) {
+        memset(J, 0, sizeof(double) * nv);
+        J[da] = -(double)side;
+        add_row(d, EFC_LIMIT, b, J, nv, dist, 0.0, d->dof_invweight0[da]);
+      }
+    }
+  }
+  d->nl = d->nefc - d->ne;
+  /* contacts (mj_instantiateContact, elliptic cones, condim 3) */
+  for (int c = 0; c < d->ncon; c++) {
+    mro_contact_t* con = &d->contact[c];
+    con->efc_address = -1;
+    if (con->dist >= con->includemargin) continue;
+    if (d->nefc + 3 > MRO_MAXEFC) break;
+    jac_point(m, d, con->body1, con->pos, jp1, NULL);
+    jac_point(m, d, con->body2, con->pos, jp2, NULL);
+    double da = d->body_invweight0[con->body1][0] + d->body_invweight0[con->body2][0];
+    con->efc_address = d->nefc;
+    for (int r = 0; r < 3; r++) {
+      const double* ax = con->frame + 3 * r;
+      for (int i = 0; i < nv; i++)
+        J[i] = ax[0] * (jp2[i] - jp1[i]) + ax[1] * (jp2[nv + i] - jp1[nv + i]) +
+               ax[2] * (jp2[2 * nv + i] - jp1[2 * nv + i]);
+      add_row(d, EFC_CONTACT, c, J, nv, r == 0 ? con->dist : 0.0,
+              r == 0 ? con->includemargin : 0.0, da);
+    }
+  }
+}
+
+static inline double clampd(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
+/* getimpedance (engine_core_constraint.c) */
+static double impedance(const double* solimp, double pos, double margin) {
+  double dmin = solimp[0], dmax = solimp[1], width = solimp[2], mid = solimp[3], power = solimp[4];
+  dmin = clampd(dmin, 0.0001, 0.9999);
+  dmax = clampd(dmax, 0.0001, 0.9999);
+  if (width < MINVAL) width = MINVAL;
+  mid = clampd(mid, 0.0001, 0.9999);
+  if (power < 1) power = 1;
+  if (dmin == dmax) return 0.5 * (dmin + dmax);
+  double x = fabs((pos - margin) / width);
+  if (x >= 1) return dmax;
+  if (x <= 0) return dmin;
+  double y;
+  if (power == 1) y = x;
+  else if (x <= mid) y = pow(x, power) / pow(mid, power - 1);
+  else y = 1 - pow(1 - x, power) / pow(1 - mid, power - 1);
+  return dmin + y * (dmax - dmin);
+}
+
+/* mj_makeImpedance: R, D, KBIP per row; contact blocks share the normal row's impedance */
+static void make_impedance(const mro_model* m, mro_data* d) {
+  for (int i = 0; i < d->nefc;) {
+    int type = d->efc_type[i], id = d->efc_id[i], dim = 1;
+    const double *solref, *solimp;
+    double pos;
+    if (type == EFC_EQ) {
+      solref = m->eq_solref[id]; solimp = m->eq_solimp[id];
+      if (m->eq_type[id] == EQ_CONNECT) {
+        dim = 3;
+        pos = sqrt(d->efc_pos[i] * d->efc_pos[i] + d->efc_pos[i + 1] * d->efc_pos[i + 1] +
+                   d->efc_pos[i + 2] * d->efc_pos[i + 2]);
+      } else pos = d->efc_pos[i];
+    } else if (type == EFC_LIMIT) {
+      solref = m->jnt_solref[id]; solimp = m->jnt_solimp[id];
+      pos = d->efc_pos[i];
+    } else {
+      solref = d->contact[id].solref; solimp = d->contact[id].solimp;
+      dim = 3;
+      pos = d->efc_pos[i];
+    }
+    double imp = impedance(solimp, pos, d->efc_margin[i]);
+    /* stiffness / damping (standard solref; refsafe: timeconst >= 2*dt) */
+    double tc = solref[0], dr = solref[1], dmax = solimp[1];
+    dmax = clampd(dmax, 0.0001, 0.9999);
+    double K, B;
+    if (tc > 0) {
+      if (tc < 2 * m->timestep) tc = 2 * m->timestep;
+      K = 1.0 / (dmax * dmax * tc * tc * dr * dr);
+      B = 2.0 / (dmax * tc);
+    } else { K = -tc / (dmax * dmax); B = -dr / dmax; }
+    for (int j = 0; j < dim; j++) {
+      double R = (1 - imp) * d->efc_diagApprox[i + j] / imp;
+      d->efc_R[i + j] = R > MINVAL ? R : MINVAL;
+      d->efc_KBIP[i + j][0] = (type == EFC_CONTACT && j > 0) ? 0.0 : K;
+      d->efc_KBIP[i + j][1] = B;
+      d->efc_KBIP[i + j][2] = imp;
+      d->efc_KBIP[i + j][3] = 0;
+    }
+    if (type == EFC_CONTACT) {
+      /* elliptic friction rows: R1 = R0/impratio; mu of regularised cone */
+      mro_contact_t* con = &d->contact[id];
+      double ir = m->impratio > MINVAL ? m->impratio : MINVAL;
+      d->efc_R[i + 1] = d->efc_R[i] / ir;
+      con->mu = con->friction[0] * sqrt(d->efc_R[i + 1] / d->efc_R[i]);
+      d->efc_R[i + 2] = d->efc_R[i + 1] * con->friction[0] * con->friction[0] /
+                        (con->friction[1] * con->friction[1]);
+    }
+    for (int j = 0; j < dim; j++) d->efc_D[i + j] = 1.0 / d->efc_R[i + j];
+    i += dim;
+  }
+}
+
+/* mj_projectConstraint: AR = J M^-1 J' + diag(R) */
+static void project_constraint(const mro_model* m, mro_data* d) {
+  int nv = m->nv, n = d->nefc;
+  double (*Bm)[MRO_MAXV] = d->efc_B;
+  for (int i = 0; i < n; i++) {
+    memcpy(Bm[i], d->efc_J[i], sizeof(double) * nv);
+    solve_ld(m, d->qLD, d->qLDiagInv, Bm[i]);
+  }
+  for (int i = 0; i < n; i++)
+    for (int j = i; j < n; j++) {
+      double s = 0;
+      for (int k = 0; k < nv; k++) s += d->efc_J[i][k] * Bm[j][k];
+      d->efc_AR[i * MRO_MAXEFC + j] = s;
+      d->efc_AR[j * MRO_MAXEFC + i] = s;
+    }
+  for (int i = 0; i < n; i++) d->efc_AR[i * MRO_MAXEFC + i] += d->efc_R[i];
+}
+
+/* --------------------------------------------------------- position stage */
+static void fwd_position(const mro_model* m, mro_data* d) {
+  kinematics(m, d);
+  com_pos(m, d);
+  tendon(m, d);
+  crb(m, d);
+  factor_m(m, d);
+  collision(m, d);
+  make_constraint(m, d);
+  make_impedance(m, d);
+  project_constraint(m, d);
+}
+
+/* --------------------------------------------------------- velocity stage */
+static void com_vel(const mro_model* m, mro_data* d) {
+  memset(d->cvel[0], 0, 48);
+  for (int b = 1; b < m->nbody; b++) {
+    int da = m->body_dofadr[b];
+    double cv[6];
+    memcpy(cv, d->cvel[m->body_parentid[b]], 48);
+    if (m->body_jnttype[b] == JNT_HINGE) {
+      cross_motion(d->cdof_dot[da], cv, d->cdof[da]);
+      for (int k = 0; k < 6; k++) cv[k] += d->cdof[da][k] * d->qvel[da];
+    } else {
+      for (int j = 0; j < 3; j++) {
+        memset(d->cdof_dot[da + j], 0, 48);
+        for (int k = 0; k < 6; k++) cv[k] += d->cdof[da + j][k] * d->qvel[da + j];
+      }
+      for (int j = 3; j < 6; j++) cross_motion(d->cdof_dot[da + j], cv, d->cdof[da + j]);
+      for (int j = 3; j < 6; j++)
+        for (int k = 0; k < 6; k++) cv[k] += d->cdof[da + j][k] * d->qvel[da + j];
+    }
+    memcpy(d->cvel[b], cv, 48);
+  }
+}
+static void passive(const mro_model* m, mro_data* d) {
+  for (int i = 0; i < m->nv; i++) d->qfrc_passive[i] = 0;
+  for (int b = 1; b < m->nbody; b++) {
+    if (m->body_jnttype[b] != JNT_HINGE) continue;
+    int da = m->body_dofadr[b], qa = m->body_qposadr[b];
+    d->qfrc_passive[da] = -m->jnt_stiffness[b] * (d->qpos[qa] - m->jnt_springref[b]) -
+                          m->dof_damping[da] * d->qvel[da];
+  }
+}
+static void rne(const mro_model* m, mro_data* d) {
+  double cacc[MRO_MAXB][6], cfrc[MRO_MAXB][6];
+  memset(cacc[0], 0, 48);
+  for (int k = 0; k < 3; k++) cacc[0][3 + k] = -m->gravity[k];
+  memset(cfrc[0], 0, 48);
+  for (int b = 1; b < m->nbody; b++) {
+    int da = m->body_dofadr[b];
+    memcpy(cacc[b], cacc[m->body_parentid[b]], 48);
+    for (int j = 0; j < m->body_dofnum[b]; j++)
+      for (int k = 0; k < 6; k++) cacc[b][k] += d->cdof_dot[da + j][k] * d->qvel[da + j];
+    double t0[6], t1[6];
+    mul_inert_vec(t0, d->cinert[b], d->cvel[b]);
+    cross_force(t1, d->cvel[b], t0);
+    mul_inert_vec(cfrc[b], d->cinert[b], cacc[b]);
+    for (int k = 0; k < 6; k++) cfrc[b][k] += t1[k];
+  }
+  for (int b = m->nbody - 1; b > 0; b--) {
+    int p = m->body_parentid[b];
+    if (p > 0) for (int k = 0; k < 6; k++) cfrc[p][k] += cfrc[b][k];
+  }
+  for (int i = 0; i < m->nv; i++)
+    d->qfrc_bias[i] = d->dof_active[i] ? dot6(d->cdof[i], cfrc[m->dof_bodyid[i]]) : 0.0;
+}
+/* mj_referenceConstraint */
+static void reference_constraint(const mro_model* m, mro_data* d) {
+  for (int i = 0; i < d->nefc; i++) {
+    double v = 0;
+    for (int k = 0; k < m->nv; k++) v += d->efc_J[i][k] * d->qvel[k];
+    d->efc_vel[i] = v;
+    d->efc_aref[i] = -d->efc_KBIP[i][1] * v -
+                     d->efc_KBIP[i][0] * d->efc_KBIP[i][2] * (d->efc_pos[i] - d->efc_margin[i]);
+  }
+}
+static void fwd_velocity(const mro_model* m, mro_data* d) {
+  d->ten_velocity = m->ten_coef[0] * d->qvel[m->ten_dof[0]] + m->ten_coef[1] * d->qvel[m->ten_dof[1]];
+  com_vel(m, d);
+  passive(m, d);
+  reference_constraint(m, d);
+  rne(m, d);
+}
+
+/* ------------------------------------------------------- mj_fwdActuation */
+static void fwd_actuation(const mro_model* m, mro_data* d) {
+  for (int i = 0; i < m->nv; i++) d->qfrc_actuator[i] = 0;
+  for (int a = 0; a < MRO_NU; a++) {
+    double c = d->ctrl[a];
+    if (c < m->act_ctrlrange[a][0]) c = m->act_ctrlrange[a][0];
+    if (c > m->act_ctrlrange[a][1]) c = m->act_ctrlrange[a][1];
+    if (m->act_dof[a] >= 0) {
+      d->actuator_force[a] = c; /* motor: gain 1, no bias */
+      d->qfrc_actuator[m->act_dof[a]] += c;
+    } else {
+      double f = m->grip_gainprm * c + m->grip_biasprm[0] + m->grip_biasprm[1] * d->ten_length +
+                 m->grip_biasprm[2] * d->ten_velocity;
+      d->grip_clamped = 0;
+      if (f <= m->grip_forcerange[0]) { f = m->grip_forcerange[0]; d->grip_clamped = 1; }
+      if (f >= m->grip_forcerange[1]) { f = m->grip_forcerange[1]; d->grip_clamped = 1; }
+      d->actuator_force[a] = f;
+      d->qfrc_actuator[m->ten_dof[0]] += m->ten_coef[0] * f;
+      d->qfrc_actuator[m->ten_dof[1]] += m->ten_coef[1] * f;
+    }
+  }
+}
+/* ---------------------------------------------------- mj_fwdAcceleration */
+static void fwd_acceleration(const mro_model* m, mro_data* d) {
+  for (int i = 0; i < m->nv; i++) {
+    d->qfrc_smooth[i] = d->dof_active[i]
+                            ? d->qfrc_passive[i] - d->qfrc_bias[i] + d->qfrc_actuator[i]
+                            : 0.0;
+    d->qacc_smooth[i] = d->qfrc_smooth[i];
+  }
+  solve_ld(m, d->qLD, d->qLDiagInv, d->qacc_smooth);
+}
+
+/* -------------------------------------------- mj_constraintUpdate (force) */
+static void constraint_update(const mro_model* m, mro_data* d, const double* jar, double* force) {
+  (void)m;
+  for (int i = 0; i < d->nefc;) {
+    int type = d->efc_type[i];
+    if (type == EFC_EQ) { force[i] = -d->efc_D[i] * jar[i]; i++; continue; }
+    if (type == EFC_LIMIT) { force[i] = jar[i] < 0 ? -d->efc_D[i] * jar[i] : 0.0; i++; continue; }
+    const mro_contact_t* con = &d->contact[d->efc_id[i]];
+    double mu = con->mu, U[3];
+    U[0] = jar[i] * mu; U[1] = jar[i + 1] * con->friction[0]; U[2] = jar[i + 2] * con->friction[1];
+    double N = U[0], T = sqrt(U[1] * U[1] + U[2] * U[2]);
+    if (mu * N >= T || (T <= 0 && N >= 0)) {
+      force[i] = force[i + 1] = force[i + 2] = 0;
+    } else if (N + mu * T <= 0 || (T <= 0 && N < 0)) {
+      for (int j = 0; j < 3; j++) force[i + j] = -d->efc_D[i + j] * jar[i + j];
+    } else {
+      double den = mu * mu * (1 + mu * mu);
+      double Dm = d->efc_D[i] / (den > MINVAL ? den : MINVAL);
+      double NT = N - mu * T;
+      force[i] = -Dm * NT * mu;
+      force[i + 1] = -force[i] / T * U[1] * con->friction[0];
+      force[i + 2] = -force[i] / T * U[2] * con->friction[1];
+    }
+    i += 3;
+  }
+}
+
+/* mju_QCQP2: min 0.5 x'Ax + x'b  s.t. sum (x_i/d_i)^2 <= r^2 ; returns active flag */
+static int qcqp2(double* res, const double* Ain, const double* bin, const double* dd, double r) {
+  double b1 = bin[0] * dd[0], b2 = bin[1] * dd[1];
+  double A11 = Ain[0] * dd[0] * dd[0], A22 = Ain[3] * dd[1] * dd[1], A12 = Ain[1] * dd[0] * dd[1];
+  double la = 0, v1 = 0, v2 = 0;
+  for (int iter = 0; iter < 20; iter++) {
+    double det = (A11 + la) * (A22 + la) - A12 * A12;
+    if (det < 1e-10) { res[0] = res[1] = 0; return 0; }
+    double P11 = (A22 + la) / det, P22 = (A11 + la) / det, P12 = -A12 / det;
+    v1 = -P11 * b1 - P12 * b2;
+    v2 = -P12 * b1 - P22 * b2;
+    double val = v1 * v1 + v2 * v2 - r * r;
+    if (val < 1e-10) break;
+    double pv1 = P11 * v1 + P12 * v2, pv2 = P12 * v1 + P22 * v2;
+    double deriv = -2.0 * (v1 * pv1 + v2 * pv2);
+    double delta = -val / deriv;
+    if (delta < 1e-10) break;
+    la += delta;
+  }
+  res[0] = v1 * dd[0];
+  res[1] = v2 * dd[1];
+  return la != 0;
+}
+
+/* ------------------------------------------------------------- mj_solPGS */
+static void sol_pgs(const mro_model* m, mro_data* d) {
+  int n = d->nefc;
+  const double* AR = d->efc_AR;
+  double* f = d->efc_force;
+  double scale = 1.0 / (d->meaninertia * (d->nv_active > 1 ? d->nv_active : 1));
+  d->solver_iters = 0;
+  for (int iter = 0; iter < m->iterations; iter++) {
+    double improvement = 0;
+    for (int i = 0; i < n;) {
+      int type = d->efc_type[i];
+      int dim = (type == EFC_CONTACT) ? 3 : 1;
+      double res[3], old[3];
+      for (int j = 0; j < dim; j++) {
+        double s = d->efc_b[i + j];
+        const double* row = AR + (size_t)(i + j) * MRO_MAXEFC;
+        for (int k = 0; k < n; k++) s += row[k] * f[k];
+        res[j] = s;
+        old[j] = f[i + j];
+      }
+      if (dim == 1) {
+        f[i] -= res[0] / AR[(size_t)i * MRO_MAXEFC + i];
+        if (type == EFC_LIMIT && f[i] < 0) f[i] = 0;
+      } else {
+        const mro_contact_t* con = &d->contact[d->efc_id[i]];
+        double At[9];
+        for (int r = 0; r < 3; r++)
+          for (int c = 0; c < 3; c++) At[3 * r + c] = AR[(size_t)(i + r) * MRO_MAXEFC + i + c];
+        /* normal or ray update */
+        if (f[i] < MINVAL) {
+          f[i] -= res[0] / At[0];
+          if (f[i] < 0) f[i] = 0;
+          f[i + 1] = f[i + 2] = 0;
+        } else {
+          double v[3] = {f[i], f[i + 1], f[i + 2]}, v1[3];
+          m3mulv(v1, At, v);
+          double denom = v3dot(v, v1);
+          if (denom >= MINVAL) {
+            double x = -v3dot(v, res) / denom;
+            if (f[i] + x * v[0] < 0) x = -f[i] / v[0];
+            for (int j = 0; j < 3; j++) f[i + j] += x * v[j];
+          }
+        }
+        /* friction update with normal fixed: QCQP over the cone section */
+        double Ac[4] = {At[4], At[5], At[7], At[8]}, bc[2];
+        for (int j = 0; j < 2; j++) {
+          bc[j] = res[1 + j];
+          for (int k = 0; k < 2; k++) bc[j] -= Ac[2 * j + k] * old[1 + k];
+          bc[j] += At[3 * (j + 1)] * (f[i] - old[0]);
+        }
+        if (f[i] < MINVAL) {
+          f[i + 1] = f[i + 2] = 0;
+        } else {
+          double v[2];
+          int active = qcqp2(v, Ac, bc, con->friction, f[i]);
+          if (active) {
+            double s = (v[0] / con->friction[0]) * (v[0] / con->friction[0]) +
+                       (v[1] / con->friction[1]) * (v[1] / con->friction[1]);
+            s = sqrt(f[i] * f[i] / (s > MINVAL ? s : MINVAL));
+            v[0] *= s; v[1] *= s;
+          }
+          f[i + 1] = v[0]; f[i + 2] = v[1];
+        }
+      }
+      /* costChange: 0.5*delta'*A*delta + delta'*res ; revert if it increases */
+      double delta[3], change = 0;
+      for (int j = 0; j < dim; j++) delta[j] = f[i + j] - old[j];
+      for (int j = 0; j < dim; j++) {
+        double s = 0;
+        for (int k = 0; k < dim; k++) s += AR[(size_t)(i + j) * MRO_MAXEFC + i + k] * delta[k];
+        change += delta[j] * (0.5 * s + res[j]);
+      }
+      if (change > 1e-10) {
+        for (int j = 0; j < dim; j++) f[i + j] = old[j];
+        change = 0;
+      }
+      improvement -= change;
+      i += dim;
+    }
+    d->solver_iters = iter + 1;
+    if (improvement * scale < m->tolerance) break;
+  }
+}
+
+/* --------------------------------------------------------- mj_fwdConstraint */
+static void fwd_constraint(const mro_model* m, mro_data* d) {
+  int nv = m->nv, n = d->nefc;
+  d->solver_iters = 0;
+  if (d->no_constraints) n = 0;
+  if (n == 0) {
+    memcpy(d->qacc, d->qacc_smooth, sizeof(double) * nv);
+    memset(d->qfrc_constraint, 0, sizeof(double) * nv);
+    return;
+  }
+  /* efc_b = J*qacc_smooth - aref */
+  for (int i = 0; i < n; i++) {
+    double s = 0;
+    for (int k = 0; k < nv; k++) s += d->efc_J[i][k] * d->qacc_smooth[k];
+    d->efc_b[i] = s - d->efc_aref[i];
+  }
+  /* warmstart: force from qacc_warmstart through the primal->dual map; keep if dual cost < 0 */
+  double jar[MRO_MAXEFC];
+  for (int i = 0; i < n; i++) {
+    double s = 0;
+    for (int k = 0; k < nv; k++) s += d->efc_J[i][k] * d->qacc_warmstart[k];
+    jar[i] = s - d->efc_aref[i];
+  }
+  constraint_update(m, d, jar, d->efc_force);
+  double cost = 0;
+  for (int i = 0; i < n; i++) {
+    double s = 0;
+    const double* row = d->efc_AR + (size_t)i * MRO_MAXEFC;
+    for (int k = 0; k < n; k++) s += row[k] * d->efc_force[k];
+    cost += d->efc_force[i] * (0.5 * s + d->efc_b[i]);
+  }
+  if (cost > 0) memset(d->efc_force, 0, sizeof(double) * n);
+  sol_pgs(m, d);
+  /* dual -> primal */
+  for (int k = 0; k < nv; k++) d->qfrc_constraint[k] = 0;
+  for (int i = 0; i < n; i++)
+    for (int k = 0; k < nv; k++) d->qfrc_constraint[k] += d->efc_J[i][k] * d->efc_force[i];
+  double tmp[MRO_MAXV];
+  memcpy(tmp, d->qfrc_constraint, sizeof(double) * nv);
+  solve_ld(m, d->qLD, d->qLDiagInv, tmp);
+  for (int k = 0; k < nv; k++) d->qacc[k] = d->qacc_smooth[k] + tmp[k];
+}
+
+/* ----------------------------------------------- mj_implicit (implicitfast) */
+static void integrate(const mro_model* m, mro_data* d) {
+  int nv = m->nv;
+  double h = m->timestep;
+  double MH[MRO_MAXM], diaginv[MRO_MAXV], qfrc[MRO_MAXV], qa[MRO_MAXV];
+  /* save warmstart */
+  memcpy(d->qacc_warmstart, d->qacc, sizeof(double) * nv);
+  /* MH = M - h*qDeriv restricted to M's sparsity: joint damping on the diagonal and the
+   * diagonal part of the tendon actuator's velocity bias (cross term right/left driver is
+   * not an ancestor pair, hence outside M's pattern); clamped actuator: no derivative */
+  memcpy(MH, d->qM, sizeof(double) * m->nM);
+  for (int i = 0; i < nv; i++) MH[m->dof_Madr[i]] += h * m->dof_damping[i];
+  if (!d->grip_clamped)
+    for (int k = 0; k < 2; k++)
+      MH[m->dof_Madr[m->ten_dof[k]]] += -h * m->grip_biasprm[2] * m->ten_coef[k] * m->ten_coef[k];
+  factor_ld(m, MH, diaginv);
+  for (int i = 0; i < nv; i++) qfrc[i] = d->qfrc_smooth[i] + d->qfrc_constraint[i];
+  memcpy(qa, qfrc, sizeof(double) * nv);
+  solve_ld(m, MH, diaginv, qa);
+  double rq[MRO_MAXQ], rv[MRO_MAXV];
+  if (d->freeze_robot) { memcpy(rq, d->qpos, sizeof(rq)); memcpy(rv, d->qvel, sizeof(rv)); }
+  for (int i = 0; i < nv; i++)
+    if (d->dof_active[i]) d->qvel[i] += h * qa[i];
+  /* mj_integratePos */
+  for (int b = 1; b < m->nbody; b++) {
+    if (!d->body_active[b]) continue;
+    int da = m->body_dofadr[b], qadr = m->body_qposadr[b];
+    if (m->body_jnttype[b] == JNT_HINGE) {
+      d->qpos[qadr] += h * d->qvel[da];
+    } else {
+      for (int k = 0; k < 3; k++) d->qpos[qadr + k] += h * d->qvel[da + k];
+      double w[3] = {d->qvel[da + 3], d->qvel[da + 4], d->qvel[da + 5]};
+      double ang = v3normalize(w) * h;
+      double qr[4], qn[4];
+      axisangle2q(qr, w, ang);
+      qmul(qn, d->qpos + qadr + 3, qr);
+      qnormalize(qn);
+      memcpy(d->qpos + qadr + 3, qn, 32);
+    }
+  }
+  if (d->freeze_robot) {
+    for (int b = 1; b < m->nbody; b++)
+      if (m->body_propid[b] < 0) {
+        int da = m->body_dofadr[b], qadr = m->body_qposadr[b];
+        d->qpos[qadr] = rq[qadr];
+        d->qvel[da] = rv[da];
+      }
+  }
+  d->time += h;
+}
+
+static void step1(const mro_model* m, mro_data* d) {
+  fwd_position(m, d);
+  fwd_velocity(m, d);
+}
+static void step2(const mro_model* m, mro_data* d) {
+  fwd_actuation(m, d);
+  fwd_acceleration(m, d);
+  fwd_constraint(m, d);
+  integrate(m, d);
+}
+void mro_forward(const mro_model* m, mro_data* d) {
+  step1(m, d);
+  fwd_actuation(m, d);
+  fwd_acceleration(m, d);
+  fwd_constraint(m, d);
+}
+void mro_step(const mro_model* m, mro_data* d, int nstep) {
+  for (int s = 0; s < nstep; s++) { step2(m, d); step1(m, d); }
+}
+
+/* ------------------------------------------------------------------- OSC */
+static void sym_eig(double* A, int n, double* w, double* V) {
+  /* cyclic Jacobi, A (n x n row-major) destroyed; V columns = eigenvectors */
+  for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) V[i * n + j] = (i == j);
+  for (int sweep = 0; sweep < 60; sweep++) {
+    double off = 0;
+    for (int i = 0; i < n; i++) for (int j = i + 1; j < n; j++) off += A[i * n + j] * A[i * n + j];
+    if (off < 1e-30) break;
+    for (int p = 0; p < n; p++)
+      for (int q = p + 1; q < n; q++) {
+        double apq = A[p * n + q];
+        if (fabs(apq) < 1e-300) continue;
+        double th = (A[q * n + q] - A[p * n + p]) / (2 * apq);
+        double t = (th >= 0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1));
+        double c = 1 / sqrt(t * t + 1), s = t * c;
+        for (int k = 0; k < n; k++) {
+          double akp = A[k * n + p], akq = A[k * n + q];
+          A[k * n + p] = c * akp - s * akq; A[k * n + q] = s * akp + c * akq;
+        }
+        for (int k = 0; k < n; k++) {
+          double apk = A[p * n + k], aqk = A[q * n + k];
+          A[p * n + k] = c * apk - s * aqk; A[q * n + k] = s * apk + c * aqk;
+        }
+        for (int k = 0; k < n; k++) {
+          double vkp = V[k * n + p], vkq = V[k * n + q];
+          V[k * n + p] = c * vkp - s * vkq; V[k * n + q] = s * vkp + c * vkq;
+        }
+      }
+  }
+  for (int i = 0; i < n; i++) w[i] = A[i * n + i];
+}
+
+static void osc_errors(const mro_model* m, const mro_data* d, const mro_osc* o, double* ep,
+                       double* eo) {
+  int s = m->eef_site;
+  v3sub(ep, o->target_pos, d->site_xpos[s]);
+  double q[4], qc[4], qe[4];
+  mat2q(q, d->site_xmat[s]);
+  qc[0] = q[0]; qc[1] = -q[1]; qc[2] = -q[2]; qc[3] = -q[3];
+  qmul(qe, o->target_quat, qc);
+  double sg = qe[0] > 0 ? 1.0 : (qe[0] < 0 ? -1.0 : 0.0);
+  eo[0] = sg * qe[1]; eo[1] = sg * qe[2]; eo[2] = sg * qe[3];
+}
+
+int mro_osc_compute(const mro_model* m, mro_data* d, const mro_osc* o, double* tau) {
+  int nv = m->nv, s = m->eef_site;
+  double jp[3 * MRO_MAXV], jr[3 * MRO_MAXV], J[6][7], M[49], Minv[49];
+  jac_point(m, d, m->site_bodyid[s], d->site_xpos[s], jp, jr);
+  for (int k = 0; k < 3; k++)
+    for (int a = 0; a < 7; a++) { J[k][a] = jp[k * nv + m->arm_dof[a]]; J[3 + k][a] = jr[k * nv + m->arm_dof[a]]; }
+  /* arm block of the full mass matrix (mj_fullM then [arm,arm]) */
+  for (int a = 0; a < 7; a++) {
+    int i = m->arm_dof[a], adr = m->dof_Madr[i];
+    for (int j = i; j >= 0; j = m->dof_parentid[j], adr++)
+      for (int c = 0; c < 7; c++)
+        if (m->arm_dof[c] == j) { M[a * 7 + c] = d->qM[adr]; M[c * 7 + a] = d->qM[adr]; }
+  }
+  /* 7x7 inverse via eigen-decomposition (SPD) */
+  {
+    double Mc[49], w[7], V[49];
+    memcpy(Mc, M, sizeof(Mc));
+    sym_eig(Mc, 7, w, V);
+    for (int i = 0; i < 7; i++)
+      for (int j = 0; j < 7; j++) {
+        double sum = 0;
+        for (int k = 0; k < 7; k++) sum += V[i * 7 + k] * V[j * 7 + k] / w[k];
+        Minv[i * 7 + j] = sum;
+      }
+  }
+  double MiJt[7][6], Li[36];
+  for (int i = 0; i < 7; i++)
+    for (int c = 0; c < 6; c++) {
+      double sum = 0;
+      for (int k = 0; k < 7; k++) sum += Minv[i * 7 + k] * J[c][k];
+      MiJt[i][c] = sum;
+    }
+  for (int r = 0; r < 6; r++)
+    for (int c = 0; c < 6; c++) {
+      double sum = 0;
+      for (int k = 0; k < 7; k++) sum += J[r][k] * MiJt[k][c];
+      Li[r * 6 + c] = sum;
+    }
+  /* Lambda = inv or pinv(rcond 1e-2) of J M^-1 J' */
+  double Lam[36];
+  {
+    double Lc[36], w[6], V[36];
+    memcpy(Lc, Li, sizeof(Lc));
+    sym_eig(Lc, 6, w, V);
+    double det = 1, wmax = 0;
+    for (int k = 0; k < 6; k++) { det *= w[k]; if (fabs(w[k]) > wmax) wmax = fabs(w[k]); }
+    int use_pinv = o->pinv_always || fabs(det) < 1e-2;
+    for (int i = 0; i < 6; i++)
+      for (int j = 0; j < 6; j++) {
+        double sum = 0;
+        for (int k = 0; k < 6; k++) {
+          if (use_pinv && fabs(w[k]) <= 1e-2 * wmax) continue;
+          sum += V[i * 6 + k] * V[j * 6 + k] / w[k];
+        }
+        Lam[i * 6 + j] = sum;
+      }
+  }
+  double qv[7], qp[7], xd[6];
+  for (int a = 0; a < 7; a++) { qv[a] = d->qvel[m->arm_dof[a]]; qp[a] = d->qpos[m->arm_dof[a]]; }
+  for (int r = 0; r < 6; r++) { xd[r] = 0; for (int a = 0; a < 7; a++) xd[r] += J[r][a] * qv[a]; }
+  double ep[3], eo[3], F[6];
+  osc_errors(m, d, o, ep, eo);
+  for (int k = 0; k < 3; k++) {
+    F[k] = o->kp_pos * ep[k] + o->kd_pos * (o->target_vel[k] - xd[k]);
+    F[3 + k] = o->kp_ori * eo[k] + o->kd_ori * (o->target_angvel[k] - xd[3 + k]);
+  }
+  double LF[6], tn[7], Jbar[7][6];
+  for (int r = 0; r < 6; r++) { LF[r] = 0; for (int c = 0; c < 6; c++) LF[r] += Lam[r * 6 + c] * F[c]; }
+  for (int a = 0; a < 7; a++) tn[a] = o->kp_null * (o->null_q[a] - qp[a]) + o->kd_null * (0 - qv[a]);
+  for (int i = 0; i < 7; i++)
+    for (int c = 0; c < 6; c++) {
+      double sum = 0;
+      for (int k = 0; k < 6; k++) sum += MiJt[i][k] * Lam[k * 6 + c];
+      Jbar[i][c] = sum;
+    }
+  double Jbt[6];
+  for (int c = 0; c < 6; c++) { Jbt[c] = 0; for (int a = 0; a < 7; a++) Jbt[c] += Jbar[a][c] * tn[a]; }
+  for (int a = 0; a < 7; a++) {
+    double t = 0, pj = 0;
+    for (int r = 0; r < 6; r++) { t += J[r][a] * LF[r]; pj += J[r][a] * Jbt[r]; }
+    tau[a] = t + (tn[a] - pj) + d->qfrc_bias[m->arm_dof[a]];
+  }
+  return 1;
+}
+int mro_osc_converged(const mro_model* m, mro_data* d, const mro_osc* o) {
+  double ep[3], eo[3];
+  osc_errors(m, d, o, ep, eo);
+  return v3norm(ep) < o->pos_thresh && v3norm(eo) < o->ori_thresh;
+}
+int mro_run_controller(const mro_model* m, mro_data* d, const mro_osc* o, double grip_ctrl,
+                       int nticks, int control_steps) {
+  int arm_converged = 0;
+  for (int t = 0; t < nticks; t++) {
+    double tau[7];
+    mro_osc_compute(m, d, o, tau);
+    for (int a = 0; a < 7; a++) d->ctrl[a] = tau[a];
+    d->ctrl[7] = grip_ctrl;
+    mro_step(m, d, control_steps);
+    if (mro_osc_converged(m, d, o)) arm_converged = 1;
+  }
+  return arm_converged;
+}
+
+/* ----------------------------------------------------------- named access */
+#define GET(nm, ptr, cnt) if (!strcmp(name, nm)) { *n = (cnt); return (double*)(ptr); }
+double* mro_get(mro_data* d, const char* name, int* n) {
+  GET("qpos", d->qpos, MRO_MAXQ) GET("qvel", d->qvel, MRO_MAXV) GET("ctrl", d->ctrl, MRO_NU)
+  GET("qacc", d->qacc, MRO_MAXV) GET("qacc_warmstart", d->qacc_warmstart, MRO_MAXV)
+  GET("qacc_smooth", d->qacc_smooth, MRO_MAXV) GET("qfrc_bias", d->qfrc_bias, MRO_MAXV)
+  GET("qfrc_passive", d->qfrc_passive, MRO_MAXV) GET("qfrc_actuator", d->qfrc_actuator, MRO_MAXV)
+  GET("qfrc_constraint", d->qfrc_constraint, MRO_MAXV) GET("qfrc_smooth", d->qfrc_smooth, MRO_MAXV)
+  GET("xpos", d->xpos, MRO_MAXB * 3) GET("xquat", d->xquat, MRO_MAXB * 4)
+  GET("xmat", d->xmat, MRO_MAXB * 9) GET("xipos", d->xipos, MRO_MAXB * 3)
+  GET("subtree_com", d->subtree_com, MRO_MAXB * 3) GET("cinert", d->cinert, MRO_MAXB * 10)
+  GET("cdof", d->cdof, MRO_MAXV * 6) GET("cvel", d->cvel, MRO_MAXB * 6)
+  GET("qM", d->qM, MRO_MAXM) GET("qLD", d->qLD, MRO_MAXM) GET("qLDiagInv", d->qLDiagInv, MRO_MAXV)
+  GET("geom_xpos", d->geom_xpos, MRO_MAXG * 3) GET("geom_xmat", d->geom_xmat, MRO_MAXG * 9)
+  GET("site_xpos", d->site_xpos, MRO_MAXS * 3) GET("site_xmat", d->site_xmat, MRO_MAXS * 9)
+  GET("efc_J", d->efc_J, MRO_MAXEFC * MRO_MAXV) GET("efc_pos", d->efc_pos, MRO_MAXEFC)
+  GET("efc_R", d->efc_R, MRO_MAXEFC) GET("efc_D", d->efc_D, MRO_MAXEFC)
+  GET("efc_aref", d->efc_aref, MRO_MAXEFC) GET("efc_b", d->efc_b, MRO_MAXEFC)
+  GET("efc_force", d->efc_force, MRO_MAXEFC) GET("efc_AR", d->efc_AR, MRO_MAXEFC * MRO_MAXEFC)
+  GET("efc_diagApprox", d->efc_diagApprox, MRO_MAXEFC)
+  GET("actuator_force", d->actuator_force, MRO_NU) GET("time", &d->time, 1)
+  GET("meaninertia", &d->meaninertia, 1)
+  *n = 0;
+  return NULL;
+}

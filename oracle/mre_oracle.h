@@ -1,0 +1,96 @@
+/* mre_oracle.h -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * fp64 single-threaded CPU restatement of the RearrangementEnv hot path
+ * (reference: mujoco_robot_environments/models/robot_arm.py:61-94 calling
+ * dm_control Physics.step() -> MuJoCo 3.2.7 mj_step2 + mj_step1, and the
+ * mujoco_controllers OSC law restated in tasks/rearrangement_mjx.py:59-135).
+ *
+ * PARITY UNPINNED: MuJoCo 3.2.7 (pyproject.toml:42), dm_control and
+ * mujoco_controllers are third-party dependencies absent from /root/reference
+ * and from this image; the reference ships no tests / golden vectors
+ * (SURVEY.md section 8c).  This file restates MuJoCo's published computation
+ * pipeline; it is pinned only by analytic known-answer tests (tests/).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * link or call this library.
+ */
+#ifndef MRE_ORACLE_H
+#define MRE_ORACLE_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MRO_MAXB 24
+#define MRO_MAXV 40
+#define MRO_MAXQ 44
+#define MRO_MAXM 200
+#define MRO_MAXG 24
+#define MRO_MAXS 4
+#define MRO_MAXPAIR 96
+#define MRO_MAXCON 96
+#define MRO_MAXEFC 360
+#define MRO_MAXEQ 4
+#define MRO_NU 8
+#define MRO_MAXPROP 4
+
+typedef struct mro_model mro_model;
+typedef struct mro_data mro_data;
+
+mro_model* mro_model_load(const void* blob, size_t nbytes);
+void mro_model_free(mro_model*);
+
+/* per-env instance: nprops active cubes with half sizes prop_size[4][3] */
+mro_data* mro_data_new(const mro_model*, int nprops, const double* prop_size);
+void mro_data_free(mro_data*);
+
+/* qpos = qpos0 (inactive props parked), qvel = 0, warmstart = 0, time = 0 */
+void mro_reset(const mro_model*, mro_data*);
+/* mj_forward: position, velocity, actuation, acceleration, constraint */
+void mro_forward(const mro_model*, mro_data*);
+/* dm_control legacy step: mj_step2 then mj_step1 */
+void mro_step(const mro_model*, mro_data*, int nstep);
+/* freeze_robot != 0 reproduces JointStaticIsolator (prop_initializer.py:246) */
+void mro_set_freeze_robot(mro_data*, int freeze);
+/* test switches: drop all constraints (smooth-dynamics parity slice); emulate the
+ * device capacity limits (active contacts / rows beyond the caps are dropped) */
+void mro_set_no_constraints(mro_data*, int flag);
+void mro_set_caps(mro_data*, int ncon_cap, int nefc_cap);
+/* solver telemetry of the last solve */
+int mro_solver_iters(const mro_data*);
+
+/* named access to mjData-like arrays ("qpos","qvel","ctrl","qacc",...);
+ * returns NULL if unknown; *n receives the element count */
+double* mro_get(mro_data*, const char* name, int* n);
+int mro_ncon(const mro_data*);
+int mro_nefc(const mro_data*);
+/* contact i: out[0:3]=pos, [3:12]=frame, [12]=dist, [13]=geom1, [14]=geom2 */
+void mro_contact(const mro_data*, int i, double* out);
+
+/* OSC --------------------------------------------------- */
+typedef struct mro_osc {
+  double kp_pos, kd_pos, kp_ori, kd_ori, kp_null, kd_null;
+  double null_q[7];
+  double pos_thresh, ori_thresh;
+  double target_pos[3], target_quat[4], target_vel[3], target_angvel[3];
+  int pinv_always; /* 1: pinv(rcond 1e-2) always (in-tree MJX form); 0: inv if |det|>=1e-2 */
+} mro_osc;
+/* tau[7] from the current (step1-fresh) state; returns 1 */
+int mro_osc_compute(const mro_model*, mro_data*, const mro_osc*, double* tau);
+int mro_osc_converged(const mro_model*, mro_data*, const mro_osc*);
+/* RobotArm.run_controller (models/robot_arm.py:61-94): nticks control ticks
+ * of (OSC torque + gripper command, control_steps physics steps).
+ * Returns arm_converged flag of the last tick evaluation semantics. */
+int mro_run_controller(const mro_model*, mro_data*, const mro_osc*, double grip_ctrl,
+                       int nticks, int control_steps);
+
+/* stand-alone narrow phase for unit tests: returns #contacts (<=8) */
+int mro_boxbox(const double* p1, const double* R1, const double* s1, const double* p2,
+               const double* R2, const double* s2, double margin, double* normal,
+               double* pos /*[8][3]*/, double* dist /*[8]*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,188 @@
+"""ctypes front-end of the CPU oracle -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import
+this module.  PARITY UNPINNED (see oracle/mre_oracle.h): the reference's
+arithmetic lives in MuJoCo 3.2.7 / mujoco_controllers, both absent here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB: Optional[C.CDLL] = None
+
+
+class OscParams(C.Structure):
+    _fields_ = [("kp_pos", C.c_double), ("kd_pos", C.c_double), ("kp_ori", C.c_double),
+                ("kd_ori", C.c_double), ("kp_null", C.c_double), ("kd_null", C.c_double),
+                ("null_q", C.c_double * 7), ("pos_thresh", C.c_double),
+                ("ori_thresh", C.c_double), ("target_pos", C.c_double * 3),
+                ("target_quat", C.c_double * 4), ("target_vel", C.c_double * 3),
+                ("target_angvel", C.c_double * 3), ("pinv_always", C.c_int)]
+
+
+def build(force: bool = False) -> str:
+    so = os.path.join(_HERE, "libmre_oracle.so")
+    srcs = [os.path.join(_HERE, f) for f in ("mre_oracle.c", "mre_oracle_batch.c", "mre_oracle.h")]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "libmre_oracle.so"])
+    return so
+
+
+def lib() -> C.CDLL:
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build())
+        L.mro_model_load.restype = C.c_void_p
+        L.mro_model_load.argtypes = [C.c_char_p, C.c_size_t]
+        L.mro_model_free.argtypes = [C.c_void_p]
+        L.mro_data_new.restype = C.c_void_p
+        L.mro_data_new.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double)]
+        L.mro_data_free.argtypes = [C.c_void_p]
+        for f in ("mro_reset", "mro_forward"):
+            getattr(L, f).argtypes = [C.c_void_p, C.c_void_p]
+        L.mro_step.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.mro_set_freeze_robot.argtypes = [C.c_void_p, C.c_int]
+        L.mro_solver_iters.argtypes = [C.c_void_p]
+        L.mro_set_no_constraints.argtypes = [C.c_void_p, C.c_int]
+        L.mro_set_caps.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.mro_get.restype = C.POINTER(C.c_double)
+        L.mro_get.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int)]
+        L.mro_ncon.argtypes = [C.c_void_p]
+        L.mro_nefc.argtypes = [C.c_void_p]
+        L.mro_contact.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double)]
+        L.mro_osc_compute.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(OscParams),
+                                      C.POINTER(C.c_double)]
+        L.mro_osc_converged.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(OscParams)]
+        L.mro_run_controller.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(OscParams),
+                                         C.c_double, C.c_int, C.c_int]
+        L.mro_boxbox.argtypes = [C.POINTER(C.c_double)] * 6 + [C.c_double] + [C.POINTER(C.c_double)] * 3
+        L.mro_batch_step.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int,
+                                     C.POINTER(C.c_double), C.c_int, C.c_int]
+        _LIB = L
+    return _LIB
+
+
+def _dp(a: np.ndarray):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class Model:
+    def __init__(self, blob: bytes):
+        self.blob = blob
+        self.ptr = lib().mro_model_load(blob, len(blob))
+        if not self.ptr:
+            raise RuntimeError("oracle: bad model blob")
+
+    def __del__(self):
+        if getattr(self, "ptr", None):
+            lib().mro_model_free(self.ptr)
+            self.ptr = None
+
+
+class Env:
+    """One oracle environment (mjData analogue)."""
+
+    def __init__(self, model: Model, nprops: int = 4, prop_size: Optional[Sequence] = None):
+        self.model = model
+        ps = np.full((4, 3), 0.0155) if prop_size is None else np.asarray(prop_size, np.float64).reshape(4, 3)
+        self._ps = np.ascontiguousarray(ps)
+        self.ptr = lib().mro_data_new(model.ptr, int(nprops), _dp(self._ps))
+
+    def __del__(self):
+        if getattr(self, "ptr", None):
+            lib().mro_data_free(self.ptr)
+            self.ptr = None
+
+    def arr(self, name: str) -> np.ndarray:
+        """Live view (no copy) of a named oracle array."""
+        n = C.c_int(0)
+        p = lib().mro_get(self.ptr, name.encode(), C.byref(n))
+        if not p:
+            raise KeyError(name)
+        return np.ctypeslib.as_array(p, shape=(n.value,))
+
+    def reset(self):
+        lib().mro_reset(self.model.ptr, self.ptr)
+
+    def forward(self):
+        lib().mro_forward(self.model.ptr, self.ptr)
+
+    def step(self, n: int = 1):
+        lib().mro_step(self.model.ptr, self.ptr, int(n))
+
+    def freeze_robot(self, flag: bool):
+        lib().mro_set_freeze_robot(self.ptr, int(flag))
+
+    def no_constraints(self, flag: bool):
+        lib().mro_set_no_constraints(self.ptr, int(flag))
+
+    def set_caps(self, ncon_cap: int, nefc_cap: int):
+        lib().mro_set_caps(self.ptr, int(ncon_cap), int(nefc_cap))
+
+    @property
+    def ncon(self):
+        return lib().mro_ncon(self.ptr)
+
+    @property
+    def nefc(self):
+        return lib().mro_nefc(self.ptr)
+
+    @property
+    def solver_iters(self):
+        return lib().mro_solver_iters(self.ptr)
+
+    def contacts(self) -> np.ndarray:
+        out = np.zeros((self.ncon, 15))
+        for i in range(self.ncon):
+            lib().mro_contact(self.ptr, i, _dp(out[i]))
+        return out
+
+    def osc(self, p: OscParams) -> np.ndarray:
+        tau = np.zeros(7)
+        lib().mro_osc_compute(self.model.ptr, self.ptr, C.byref(p), _dp(tau))
+        return tau
+
+    def osc_converged(self, p: OscParams) -> bool:
+        return bool(lib().mro_osc_converged(self.model.ptr, self.ptr, C.byref(p)))
+
+    def run_controller(self, p: OscParams, grip_ctrl: float, nticks: int, control_steps: int = 5) -> bool:
+        return bool(lib().mro_run_controller(self.model.ptr, self.ptr, C.byref(p), float(grip_ctrl),
+                                             int(nticks), int(control_steps)))
+
+
+def batch_step(model: Model, envs: Sequence[Env], ctrl: Optional[np.ndarray], nstep: int,
+               nthreads: int = 0) -> int:
+    ptrs = (C.c_void_p * len(envs))(*[e.ptr for e in envs])
+    cp = None
+    if ctrl is not None:
+        ctrl = np.ascontiguousarray(ctrl, np.float64)
+        cp = _dp(ctrl)
+    return lib().mro_batch_step(model.ptr, ptrs, len(envs), cp, int(nstep), int(nthreads))
+
+
+def boxbox(p1, R1, s1, p2, R2, s2, margin=0.0):
+    a = [np.ascontiguousarray(x, np.float64).ravel() for x in (p1, R1, s1, p2, R2, s2)]
+    normal, pos, dist = np.zeros(3), np.zeros(24), np.zeros(8)
+    n = lib().mro_boxbox(*[_dp(x) for x in a], float(margin), _dp(normal), _dp(pos), _dp(dist))
+    return n, normal, pos.reshape(8, 3)[:n], dist[:n]
+
+
+def make_osc(cfg: Optional[dict] = None) -> OscParams:
+    """Gains / thresholds of config/robots/arm/controller_config/osc.yaml:5-22."""
+    cfg = cfg or {}
+    p = OscParams()
+    p.kp_pos, p.kd_pos = cfg.get("kp_pos", 350.0), cfg.get("kd_pos", 20.0)
+    p.kp_ori, p.kd_ori = cfg.get("kp_ori", 500.0), cfg.get("kd_ori", 100.0)
+    p.kp_null, p.kd_null = cfg.get("kp_null", 200.0), cfg.get("kd_null", 30.0)
+    for i, v in enumerate(cfg.get("null_q", [0, -0.785, 0, -2.356, 0, 1.571, 0.785])):
+        p.null_q[i] = v
+    p.pos_thresh, p.ori_thresh = cfg.get("pos_thresh", 5e-3), cfg.get("ori_thresh", 68e-3)
+    p.pinv_always = int(cfg.get("pinv_always", 0))
+    p.target_quat[0] = 1.0
+    return p

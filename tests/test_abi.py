@@ -1,0 +1,48 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports
+every symbol include/mre.h declares; a missing GPU fails loudly (no fallback)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def libmre():
+    from mujoco_robot_environments_amd import lib
+    lib.build()
+    return lib.lib()
+
+
+def test_header_symbols_exported(libmre):
+    hdr = open(os.path.join(ROOT, "include", "mre.h")).read()
+    names = set(re.findall(r"\b(mre_[a-z_]+)\s*\(", hdr))
+    assert len(names) >= 20
+    for n in sorted(names):
+        assert hasattr(libmre, n), f"{n} declared in include/mre.h but not exported"
+
+
+def test_python_binding_lists_all(libmre):
+    from mujoco_robot_environments_amd import lib
+    hdr = open(os.path.join(ROOT, "include", "mre.h")).read()
+    names = set(re.findall(r"\b(mre_[a-z_]+)\s*\(", hdr))
+    assert names == set(lib.EXPORTS)
+
+
+def test_bad_blob_rejected(libmre):
+    h = C.c_void_p()
+    rc = libmre.mre_create(b"\0" * 64, 64, 4, 0, C.byref(h))
+    assert rc == -2 and b"magic" in libmre.mre_last_error()
+
+
+def test_no_gpu_fails_loudly(libmre, compiled_model):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    blob = compiled_model[1]
+    h = C.c_void_p()
+    rc = libmre.mre_create(blob, len(blob), 4, 0, C.byref(h))
+    assert rc == -4, "without a GPU the product path must refuse to run"
+    assert b"no CPU fallback" in libmre.mre_last_error()
