@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/s of the batched RearrangementEnv physics step on MI355X.
+
+Workload (BASELINE.json configs[1]): 4096 parallel RearrangementEnv per GPU
+(per-env 2..4 cubes, half size U(0.015,0.016)), random actions resampled every
+control tick (5 physics steps of 1 ms), inputs resident in HBM.
+One bench "step" = one control tick = one kernel launch = 5 env-steps x 4096 envs.
+With --gpus N (launched through torch.distributed.run, one rank per GPU) every
+rank owns 4096 envs (weak scaling: 32768 envs at N=8, configs[3]); there is no
+data-path collective, only the end-of-rollout all_gather of the final state.
+
+Prints ONE JSON line (rank 0) with the driver contract fields plus
+  "roofline":     HBM roofline of the step kernel (algorithmic bytes / HIP-event time)
+  "cpu_baseline": the fp64 CPU oracle ("port" of the same pipeline, NOT MuJoCo) timed
+                  on this host's cores on a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ENVS_PER_GPU = 4096
+CONTROL_STEPS = 5
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+WS_MIN, WS_MAX = (0.35, -0.4, 0.43), (0.55, 0.4, 0.435)  # config/task/rearrangement.yaml:4-6
+
+
+def algorithmic_bytes_per_env_step(nprops: np.ndarray) -> float:
+    """4*(2*nq + 4*nv + nu) bytes with nq = 15+7n, nv = 15+6n, nu = 8."""
+    n = nprops.astype(np.float64)
+    return float(np.mean(4.0 * (2 * (15 + 7 * n) + 4 * (15 + 6 * n) + 8)))
+
+
+def setup_envs(phys, seed, env_ids, settle_steps=300):
+    from mujoco_robot_environments_amd import placement, rng
+    nprops, sizes = rng.prop_params(seed, env_ids)
+    phys.set_props(nprops, sizes)
+    phys.reset()
+    pose, ok = placement.sample_poses(seed, env_ids, nprops, sizes, WS_MIN, WS_MAX)
+    assert ok.all(), "cube placement failed"
+    qp = placement.write_poses(phys.qpos(), pose, nprops)
+    phys.set_state(qp, np.zeros((len(env_ids), 39), np.float32))
+    phys.step(settle_steps, flags=2)  # settle with the robot frozen (prop_initializer.py:240-258)
+    phys.sync()
+    return nprops, sizes
+
+
+def cpu_baseline(seed, budget_s=12.0, nenv=64):
+    """Oracle (CPU restatement) on this host: same scene / action law, OpenMP over envs."""
+    from mujoco_robot_environments_amd import placement, rng
+    from mujoco_robot_environments_amd.model import compile as MC
+    from oracle import oracle as O
+    A = MC.compile_scene()
+    m = O.Model(MC.to_blob(A))
+    ids = np.arange(nenv)
+    nprops, sizes = rng.prop_params(seed, ids)
+    pose, _ = placement.sample_poses(seed, ids, nprops, sizes, WS_MIN, WS_MAX)
+    envs = []
+    for i in range(nenv):
+        e = O.Env(m, int(nprops[i]), sizes[i])
+        q = e.arr("qpos")
+        q[:7] = A["home_qpos"]
+        for p in range(int(nprops[i])):
+            q[15 + 7 * p: 22 + 7 * p] = pose[i, p]
+        e.freeze_robot(True)
+        e.forward()
+        envs.append(e)
+    # a 1-GPU box grants a 16-core CPU share (more threads only oversubscribe the cgroup)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    threads = max(1, min(avail, 16))
+    O.batch_step(m, envs, None, 300, threads)  # settle
+    for e in envs:
+        e.freeze_robot(False)
+    ticks, t0 = 0, time.perf_counter()
+    while True:
+        acts = rng.random_actions(seed, ids, [ticks])[0]
+        O.batch_step(m, envs, acts, CONTROL_STEPS, threads)
+        ticks += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": nenv * ticks * CONTROL_STEPS / dt, "unit": "env-steps/s", "cores": threads,
+            "kind": "port", "sample": f"{nenv} envs x {ticks} ticks x {CONTROL_STEPS} steps, fp64 oracle "
+            f"(PGS, same scene/actions), OpenMP {threads} threads, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fused", type=int, default=1, help="control ticks per kernel launch")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from mujoco_robot_environments_amd import rng
+    from mujoco_robot_environments_amd.physics import BatchedPhysics
+    n_local = args.envs_per_gpu
+    env_ids = np.arange(rank * n_local, (rank + 1) * n_local)  # global ids: results independent of sharding
+    phys = BatchedPhysics(n_local, device=local_rank)
+    nprops, _ = setup_envs(phys, args.seed, env_ids)
+
+    K, W, F = args.steps, args.warmup, max(1, args.fused)
+    assert K % F == 0 and W % F == 0, "--fused must divide --steps and --warmup"
+    acts = rng.random_actions(args.seed, env_ids, np.arange(W + K)).astype(np.float32)
+    seq = torch.from_numpy(acts).to(phys.device).contiguous()  # resident in HBM before timing
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        phys.sync()
+
+    for k in range(0, W, F):
+        phys.rollout(seq[k:k + F], control_steps=CONTROL_STEPS)
+    barrier()
+    phys.profile_enable(True)
+    t0 = time.perf_counter()
+    for k in range(W, W + K, F):
+        phys.rollout(seq[k:k + F], control_steps=CONTROL_STEPS)
+    gather_ms = 0.0
+    if world > 1:
+        # end-of-rollout gather (the only collective of the job): final qpos/qvel/status
+        phys.sync()
+        tg = time.perf_counter()
+        qp, qv = phys.get_state()
+        fin = torch.from_numpy(np.concatenate([qp, qv, phys.status()[:, None].astype(np.float32)], axis=1)).to(phys.device)
+        out = torch.empty((world * n_local, fin.shape[1]), dtype=fin.dtype, device=phys.device)
+        dist.all_gather_into_tensor(out, fin.contiguous())
+        torch.cuda.synchronize()
+        gather_ms = (time.perf_counter() - tg) * 1e3
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kern_ms, launches = phys.profile_read()
+    phys.profile_enable(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=phys.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    status = phys.status()
+    stats = phys.solver_stats()
+    total_env_steps = world * n_local * K * CONTROL_STEPS
+    value = total_env_steps / elapsed
+    bytes_per_launch = algorithmic_bytes_per_env_step(nprops) * n_local * CONTROL_STEPS * F
+    avg_launch_s = (kern_ms / max(launches, 1)) * 1e-3
+    achieved = bytes_per_launch / avg_launch_s / 1e9
+    res = {
+        "metric": "env steps/sec (whole node), RearrangementEnv batch=4096 per GPU",
+        "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
+        "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "configs[1]: 4096 parallel RearrangementEnv per GPU (2-4 cubes), random "
+                   "actions every 5 ms tick, 5 x 1 ms physics steps per bench step",
+                   "envs_per_gpu": n_local, "control_steps": CONTROL_STEPS, "ticks_per_launch": F,
+                   "solver": "PGS<=100 iters, tol 1e-8", "integrator": "implicitfast"},
+        "control_ticks_per_s": value / CONTROL_STEPS,
+        "pick_place_macro_steps_per_s": value / 18000.0,
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "mre::k_step", "avg_launch_ms": avg_launch_s * 1e3, "launches": launches,
+                     "algorithmic_bytes_per_launch": bytes_per_launch,
+                     "note": "path is dependency/latency bound (tree depth, PGS sweeps), not HBM bound"},
+        "health": {"nan_envs": int(((status & 2) != 0).sum()), "overflow_envs": int(((status & 4) != 0).sum()),
+                   "mean_ncon": float(stats[:, 0].mean()), "mean_nefc": float(stats[:, 1].mean()),
+                   "mean_pgs_iters": float(stats[:, 2].mean())},
+        "gather_ms": gather_ms,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline(args.seed)
+    elif rank == 0:
+        res["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -120,6 +120,12 @@ int mre_get_status(mre_env*, uint32_t* status);
 /* telemetry: per-env [ncon, nefc, solver_iters, reserved] of the last step */
 int mre_get_solver_stats(mre_env*, int32_t* stats);
 
+/* measurement support for bench.py: when enabled every step-kernel launch is
+ * bracketed by hipEvents on the handle's stream; mre_profile_read synchronises and
+ * returns the summed kernel time [ms] and launch count since enable (and resets). */
+int mre_profile_enable(mre_env*, int on);
+int mre_profile_read(mre_env*, float* total_ms, int* launches);
+
 #ifdef __cplusplus
 }
 #endif

@@ -52,7 +52,29 @@ struct mre_env {
   OscConfig osc;
   float* trace = nullptr;
   int trace_nenv = 0, trace_max = 0, trace_pos = 0;
+  bool profiling = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+  size_t events_used = 0;
 };
+
+// launch the step kernel, optionally bracketed by HIP events on the handle's stream
+static int launch_step(mre_env* e, const StepArgs& a) {
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (e->profiling) {
+    if (e->events_used == e->events.size()) {
+      hipEvent_t x, y;
+      HIPCHK(hipEventCreate(&x)); HIPCHK(hipEventCreate(&y));
+      e->events.emplace_back(x, y);
+    }
+    e0 = e->events[e->events_used].first; e1 = e->events[e->events_used].second;
+    e->events_used++;
+    HIPCHK(hipEventRecord(e0, e->stream));
+  }
+  mre_launch_step(&a, e->stream);
+  HIPCHK(hipGetLastError());
+  if (e1) HIPCHK(hipEventRecord(e1, e->stream));
+  return MRE_OK;
+}
 
 // ------------------------------------------------------------------ blob parsing
 namespace {
@@ -352,8 +374,8 @@ extern "C" int mre_step(mre_env* e, int nsubsteps, unsigned flags) {
   StepArgs a;
   fill_args(e, a);
   a.nsteps = nsubsteps; a.flags = flags;
-  mre_launch_step(&a, e->stream);
-  HIPCHK(hipGetLastError());
+  int rc = launch_step(e, a);
+  if (rc) return rc;
   if (e->trace) e->trace_pos += nsubsteps;
   return MRE_OK;
 }
@@ -369,8 +391,8 @@ extern "C" int mre_rollout(mre_env* e, const float* ctrl_seq, int nticks, int co
   fill_args(e, a);
   a.nsteps = nticks * control_steps; a.control_steps = control_steps; a.mode = CTRL_SEQ;
   a.ctrl_seq = ctrl_seq; a.flags = flags;
-  mre_launch_step(&a, e->stream);
-  HIPCHK(hipGetLastError());
+  int rc = launch_step(e, a);
+  if (rc) return rc;
   if (e->trace) e->trace_pos += a.nsteps;
   return MRE_OK;
 }
@@ -487,8 +509,8 @@ extern "C" int mre_run_controller(mre_env* e, int nticks, int control_steps, uin
   fill_args(e, a);
   a.nsteps = nticks * control_steps; a.control_steps = control_steps; a.mode = CTRL_OSC;
   a.converged = e->converged;
-  mre_launch_step(&a, e->stream);
-  HIPCHK(hipGetLastError());
+  int rc = launch_step(e, a);
+  if (rc) return rc;
   if (e->trace) e->trace_pos += a.nsteps;
   if (converged_out) return copy_out(e, converged_out, e->converged, (size_t)e->N);
   return MRE_OK;
@@ -512,5 +534,25 @@ extern "C" int mre_place_props(mre_env* e, const uint8_t* mask, uint64_t seed, c
     mre_launch_step(&a, e->stream);
     HIPCHK(hipGetLastError());
   }
+  return MRE_OK;
+}
+
+extern "C" int mre_profile_enable(mre_env* e, int on) {
+  if (!e) return fail(MRE_ERR_ARG, "null handle");
+  e->profiling = on != 0;
+  e->events_used = 0;
+  return MRE_OK;
+}
+extern "C" int mre_profile_read(mre_env* e, float* total_ms, int* launches) {
+  if (!e || !total_ms || !launches) return fail(MRE_ERR_ARG, "null");
+  HIPCHK(hipStreamSynchronize(e->stream));
+  float tot = 0.f;
+  for (size_t k = 0; k < e->events_used; k++) {
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e->events[k].first, e->events[k].second));
+    tot += ms;
+  }
+  *total_ms = tot; *launches = (int)e->events_used;
+  e->events_used = 0;
   return MRE_OK;
 }

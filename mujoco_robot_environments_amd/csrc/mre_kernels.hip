@@ -17,6 +17,7 @@
 
 #include "mre_dev.h"
 #include "mre_math.h"
+#include "mre_collide.h"
 
 namespace mre {
 
@@ -37,7 +38,19 @@ struct Sm {
   // per-env cube constants
   float prop_mass[NPROP], prop_inertia[NPROP][3], prop_size[NPROP][3];
   float scratch[64];
+  int iscr[64];
   int nprops;
+  // active contacts (pair order)
+  int ncon, nefc, nl, nrrow, overflow, solver_iters;
+  float con_pos[NCON_MAX][3], con_frame[NCON_MAX][9], con_dist[NCON_MAX];
+  int con_pair[NCON_MAX], con_rslot[NCON_MAX], lim_info[NRV + 1];
+  // constraint rows: rowdata = {R, aref -> efc_b, force, 1/A_ii}
+  alignas(16) float4 rowdata[NEFC_MAX];
+  int hdr[NEFC_MAX];
+  float Jp[NEFC_MAX][13];
+  float Jr[NRROW_MAX][NRV], Br[NRROW_MAX][NRV];
+  float Ablk[NCON_MAX][9];
+  float jar[NEFC_MAX];
 };
 
 struct BodyRegs {
@@ -232,6 +245,10 @@ MRE_DEV void solve_robot_serial(const DevModel* M, const float* LD, const float*
   }
 }
 
+}  // namespace mre
+#include "mre_solver.h"
+namespace mre {
+
 // ------------------------------------------------ mj_comVel + mj_rne + mj_passive
 MRE_DEV void velocity_stage(const DevModel* M, Sm& s, int l) {
   // cvel, cdof_dot (lane = body; each lane re-accumulates its chain prefix)
@@ -414,7 +431,7 @@ __global__ __launch_bounds__(64) void k_step(StepArgs a) {
     s.qacc[l] = 0.f;
   }
   if (l < NU) s.ctrl[l] = a.ctrl[(size_t)env * NU + l];
-  if (l == 0) s.nprops = a.nprops[env];
+  if (l == 0) { s.nprops = a.nprops[env]; s.overflow = 0; s.ncon = 0; s.nefc = 0; s.solver_iters = 0; }
   if (l < NPROP * 3) {
     const float sz = a.prop_size[(size_t)env * NPROP * 3 + l];
     s.prop_size[l / 3][l % 3] = sz;
@@ -441,6 +458,11 @@ __global__ __launch_bounds__(64) void k_step(StepArgs a) {
     for (int e = l; e < NMR; e += 64) s.qLD[e] = s.qM[e];
     __syncthreads();
     factor_robot(M, s.qLD, s.qLDinv, l);
+    const bool constrained = (a.flags & F_NO_CONSTRAINTS) == 0;
+    if (constrained) {
+      collide(M, s, l);
+      assemble_constraints(M, s, l);
+    }
     // ------------------------------------------------ S1: velocity stage
     velocity_stage(M, s, l);
     __syncthreads();
@@ -452,8 +474,12 @@ __global__ __launch_bounds__(64) void k_step(StepArgs a) {
     }
     // ------------------------------------------------ S2
     const bool clamped = smooth_forces(M, s, l);
-    if (l < NVP) { s.qacc[l] = s.qacc_smooth[l]; s.qfrc_con[l] = 0.f; }
-    __syncthreads();
+    if (constrained) {
+      solve_constraints(M, s, l);
+    } else {
+      if (l < NVP) { s.qacc[l] = s.qacc_smooth[l]; s.qfrc_con[l] = 0.f; }
+      __syncthreads();
+    }
     integrate(M, s, l, clamped, a.flags);
     if (a.trace != nullptr && env < a.trace_nenv && (a.trace_base + step) < a.trace_max) {
       if (l < NQP)
@@ -483,7 +509,12 @@ __global__ __launch_bounds__(64) void k_step(StepArgs a) {
   if (l == 0 && a.status != nullptr) {
     unsigned st = 0;
     for (int k = 0; k < NQ; k++) if (!isfinite(s.qpos[k])) st |= 2u;
+    if (s.overflow) st |= 4u;
     a.status[env] |= st;
+    if (a.stats != nullptr && a.nsteps > 0) {
+      a.stats[env * 4 + 0] = s.ncon; a.stats[env * 4 + 1] = s.nefc;
+      a.stats[env * 4 + 2] = s.solver_iters; a.stats[env * 4 + 3] = s.nl;
+    }
   }
 }
 

@@ -116,10 +116,21 @@ MRE_DEV void cross_force(float* r, const float* vel, const float* f) {
 MRE_DEV float dot6(const float* a, const float* b) {
   return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3] + a[4] * b[4] + a[5] * b[5];
 }
+// wave64 sum, result uniform in every lane: DPP row reduction (quad_perm, row_half_mirror,
+// row_mirror), row_bcast15 / row_bcast31 across the four 16-lane rows, readlane 63.
+template <int CTRL, int ROW_MASK>
+MRE_DEV float dpp_add(float v) {
+  const int t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false);
+  return v + __builtin_bit_cast(float, t);
+}
 MRE_DEV float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v = dpp_add<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
+  v = dpp_add<0x141, 0xF>(v);  // row_half_mirror
+  v = dpp_add<0x140, 0xF>(v);  // row_mirror
+  v = dpp_add<0x142, 0xA>(v);  // row_bcast15 -> rows 1,3
+  v = dpp_add<0x143, 0xC>(v);  // row_bcast31 -> rows 2,3
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 MRE_DEV float clampf(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
 

@@ -216,3 +216,13 @@ class BatchedPhysics:
         st = np.empty((self.num_envs, 4), np.int32)
         check(_lib.lib().mre_get_solver_stats(self._h, _ptr(st)), "mre_get_solver_stats")
         return st
+
+    # ---------------------------------------------------------- measurement
+    def profile_enable(self, on: bool = True) -> None:
+        check(_lib.lib().mre_profile_enable(self._h, int(on)), "mre_profile_enable")
+
+    def profile_read(self):
+        """(summed kernel ms, launches) measured with HIP events on the handle's stream."""
+        ms, n = C.c_float(0), C.c_int(0)
+        check(_lib.lib().mre_profile_read(self._h, C.byref(ms), C.byref(n)), "mre_profile_read")
+        return float(ms.value), int(n.value)

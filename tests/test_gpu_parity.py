@@ -27,7 +27,7 @@ def _oracle_envs(oracle_model, nprops, sizes):
 
 
 def _rollout_both(compiled_model, oracle_model, N, T, flags, scale, seed=0, no_constraints=False,
-                  control_steps=5, z_extra=0.0):
+                  control_steps=5, z_extra=0.0, gravity_comp=False, yaw=False):
     import torch
     from mujoco_robot_environments_amd import rng
     A, _ = compiled_model
@@ -37,8 +37,10 @@ def _rollout_both(compiled_model, oracle_model, N, T, flags, scale, seed=0, no_c
     # gravity compensation offset keeps the arm in its workspace for the gentle variant
     envs = _oracle_envs(oracle_model, nprops, sizes)
     q0 = np.zeros((N, 43))
+    yaws = rng.uniform(seed + 7, ids, [0], 4)[0] * np.pi if yaw else None
     for i, e in enumerate(envs):
-        q0[i] = init_oracle_env(e, int(nprops[i]), sizes[i], z_extra=z_extra)
+        q0[i] = init_oracle_env(e, int(nprops[i]), sizes[i], z_extra=z_extra,
+                                yaw=None if yaws is None else yaws[i])
         # inactive cube slots keep the parked pose of mro_reset
         e.no_constraints(no_constraints)
         e.forward()
@@ -52,6 +54,8 @@ def _rollout_both(compiled_model, oracle_model, N, T, flags, scale, seed=0, no_c
         q0[i] = qp[i]
         envs[i].arr("qpos")[:43] = qp[i]
         envs[i].forward()
+    if gravity_comp:
+        acts[:, :, :7] += envs[0].arr("qfrc_bias")[:7]
     phys.set_state(qp, np.zeros((N, 39), np.float32))
     trace = phys.set_trace(N, T * control_steps)
     seq = torch.tensor(acts, dtype=torch.float32, device=phys.device).contiguous()
@@ -82,3 +86,43 @@ def test_smooth_dynamics_parity(compiled_model, oracle_model):
           "cubes", err[:, :, 15:].max())
     assert err.max() < QPOS_TOL
     assert (phys.status() == 0).all()
+
+
+def _report(name, gq, oq, nprops):
+    err = np.abs(gq - oq)
+    for i in range(gq.shape[1]):
+        err[:, i, 15 + 7 * int(nprops[i]):] = 0
+    print(f"{name}: max err {err.max():.3e} arm {err[:, :, :7].max():.3e} grip {err[:, :, 7:15].max():.3e} "
+          f"cubes {err[:, :, 15:].max():.3e}")
+    return err
+
+
+def test_resting_contact_parity(compiled_model, oracle_model):
+    """Full pipeline (collision, equality, limits, elliptic contacts, PGS, implicitfast):
+    cubes dropped 2 mm onto the table, arm holds home under gravity compensation +
+    10 % torque noise, gripper command random.  32 envs x 200 steps."""
+    gq, oq, nprops, phys = _rollout_both(compiled_model, oracle_model, N=32, T=40, flags=0, scale=0.1,
+                                         z_extra=0.002, gravity_comp=True, yaw=True)
+    err = _report("resting contact", gq, oq, nprops)
+    st = phys.solver_stats()
+    print("stats ncon/nefc/iters/nl (env 0..3):", st[:4].tolist())
+    assert (phys.status() == 0).all()
+    _assert_regimes(err)
+
+
+def _assert_regimes(err, grip_frac=0.9, grip_max=5e-3):
+    """Tolerances per regime (fp32 device vs fp64 oracle):
+      * arm joints and cube poses: max|dq| < 1e-4 for every env;
+      * the 8 passive/driven finger-linkage joints: < 1e-4 for >= 90 % of the envs and
+        < 5e-3 always.  The linkage couplers rest exactly AT their joint limit
+        (range [-1.57, 0], q ~ 0), so a limit row can switch on one step earlier or
+        later in fp32 than in fp64 when a crossing lands within the accumulated
+        rounding error (~2e-6) of zero; MuJoCo's limit model is discontinuous there
+        (aref jumps by B*vel), which perturbs the few-gram links by up to ~1e-3 rad."""
+    arm = err[:, :, :7].max()
+    cubes = err[:, :, 15:].max()
+    grip_env = err[:, :, 7:15].max(axis=(0, 2))
+    frac = float((grip_env < QPOS_TOL).mean())
+    print(f"regimes: arm {arm:.2e} cubes {cubes:.2e} grip<{QPOS_TOL} for {frac:.0%} of envs, grip max {grip_env.max():.2e}")
+    assert arm < QPOS_TOL and cubes < QPOS_TOL
+    assert frac >= grip_frac and grip_env.max() < grip_max
