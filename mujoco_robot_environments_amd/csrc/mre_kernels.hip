@@ -38,6 +38,7 @@ struct Sm {
   // per-env cube constants
   float prop_mass[NPROP], prop_inertia[NPROP][3], prop_size[NPROP][3];
   float scratch[64];
+  float osc_tgt[16];
   int iscr[64];
   int nprops;
   // active contacts (pair order)
@@ -247,6 +248,7 @@ MRE_DEV void solve_robot_serial(const DevModel* M, const float* LD, const float*
 
 }  // namespace mre
 #include "mre_solver.h"
+#include "mre_osc.h"
 namespace mre {
 
 // ------------------------------------------------ mj_comVel + mj_rne + mj_passive
@@ -417,6 +419,7 @@ MRE_DEV void integrate(const DevModel* M, Sm& s, int l, bool grip_clamped, unsig
 // =========================================================================
 __global__ __launch_bounds__(64) void k_step(StepArgs a) {
   __shared__ Sm s;
+  __shared__ OscSm osc;
   const int env = blockIdx.x;
   const int l = threadIdx.x;
   if (env >= a.N) return;
@@ -447,6 +450,14 @@ __global__ __launch_bounds__(64) void k_step(StepArgs a) {
   }
   __syncthreads();
 
+  bool arm_converged = false;
+  float grip_cmd = 0.f;
+  if (a.mode == CTRL_OSC) {
+    if (l < 16) s.osc_tgt[l] = a.osc_target[(size_t)env * 16 + l];
+    // MinMax.compute_control_output: max_val 255 (closed) / min_val 0 (open), min_max.yaml:3-4
+    grip_cmd = a.grip_closed[env] ? M->act_ctrlrange[NU - 1][1] : M->act_ctrlrange[NU - 1][0];
+    __syncthreads();
+  }
   BodyRegs br;
   for (int step = 0; step < a.nsteps; ++step) {
     // ------------------------------------------------ S1: position stage
@@ -472,6 +483,14 @@ __global__ __launch_bounds__(64) void k_step(StepArgs a) {
       if (l < NU) s.ctrl[l] = a.ctrl_seq[((size_t)tick * a.N + env) * NU + l];
       __syncthreads();
     }
+    if (a.mode == CTRL_OSC && (step % a.control_steps) == 0) {
+      // RobotArm.run_controller tick (robot_arm.py:69-88): is_converged() of the previous
+      // tick is evaluated on the same (step1-fresh) state the next torque is computed from
+      if (step > 0 && osc_converged(M, s, a.osc, s.osc_tgt)) arm_converged = true;
+      osc_compute(M, s, osc, a.osc, s.osc_tgt, l);
+      if (l == 0) s.ctrl[NU - 1] = grip_cmd;
+      __syncthreads();
+    }
     // ------------------------------------------------ S2
     const bool clamped = smooth_forces(M, s, l);
     if (constrained) {
@@ -489,6 +508,13 @@ __global__ __launch_bounds__(64) void k_step(StepArgs a) {
   // ---- final kinematics for site queries
   kinematics(M, s, l, br);
   __syncthreads();
+  if (a.mode == CTRL_OSC && a.nsteps > 0) {
+    if (osc_converged(M, s, a.osc, s.osc_tgt)) arm_converged = true;
+    if (l == 0) {
+      if (a.converged != nullptr) a.converged[env] = arm_converged ? 1 : 0;
+      if (!arm_converged && a.status != nullptr) a.status[env] |= 1u;
+    }
+  }
   if (a.sites != nullptr) {
     float* o = a.sites + (size_t)env * 16;
     if (l < 3) o[l] = s.site_xpos[M->tcp_site][l];
