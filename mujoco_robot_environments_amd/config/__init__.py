@@ -1,0 +1,188 @@
+"""Hydra-shaped configuration tree of the reference, without Hydra.
+
+The reference composes ``config/rearrangement.yaml`` with nested defaults lists and
+``group=option`` overrides at import time (tasks/rearrangement.py:31-49,
+transporter_network_data_generation.py:22-33).  hydra / omegaconf are not available on
+the target image, so the same tree (same key names and values, cited per group) is held
+here as plain data and ``compose()`` implements the subset of the compose API the
+reference's callers use: defaults, ``group=option`` / ``group/sub=option`` selection,
+``key=value`` and ``+key=value`` assignment, ``${a.b}`` interpolation.  It is re-entrant
+(no global state).
+"""
+from __future__ import annotations
+
+import copy
+from typing import Any, Dict, List, Optional
+
+
+class Cfg(dict):
+    """dict with attribute access (the part of DictConfig the env uses)."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+    def __deepcopy__(self, memo):
+        return Cfg({k: copy.deepcopy(v, memo) for k, v in self.items()})
+
+
+def _wrap(x):
+    if isinstance(x, dict):
+        return Cfg({k: _wrap(v) for k, v in x.items()})
+    if isinstance(x, list):
+        return [_wrap(v) for v in x]
+    return x
+
+
+# ------------------------------------------------------------------ option groups
+# config/arena/props/*.yaml
+_PROPS = {
+    "colour_splitter": dict(min_objects=2, max_objects=5, min_object_size=0.015, max_object_size=0.016,
+                            sample_size=True, sample_colour=True, color_noise=0.1, shapes=["cube"],
+                            colours=["green", "blue", "red", "yellow", "cyan", "magenta"],
+                            textures=["plain", "stary", "dotted"]),
+    "single_block": dict(min_objects=1, max_objects=1, min_object_size=0.015, max_object_size=0.016,
+                         sample_size=True, sample_colour=True, color_noise=0.1, shapes=["cube"],
+                         colours=["red"], textures=["plain"]),
+}
+# config/arena/cameras/transporter_data_collection.yaml
+_CAMERAS = {
+    "transporter_data_collection": [dict(name="overhead_camera", pos=[0.7, 0.0, 1.3],
+                                         quat=[0.707, 0.0, 0.0, -0.707], height=480, width=640, fovy=61)],
+}
+_WORKSPACE = dict(seed=1, workspace=dict(min_pose=[0.35, -0.4, 0.43], max_pose=[0.55, 0.4, 0.435]),
+                  gripper=dict(min_pose=[0.4, -0.0, 0.7, 3.14, 0.0, 0.0], max_pose=[0.5, 0.0, 0.7, 3.14, 0.0, 0.0]))
+
+
+def _target(name, loc, rgba):
+    return dict(name=name, location=loc, size=[0.075, 0.15, 0.01], rgba=rgba)
+
+
+# config/task/*.yaml
+_TASK = {
+    "rearrangement": dict(initializers=_WORKSPACE),
+    "rearrangement_w_targets": dict(
+        initializers=_WORKSPACE,
+        target_locations=dict(
+            top_left=_target("top_left", [0.55, 0.4, 0.4], [1.0, 0.0, 0.0, 0.1]),
+            bottom_left=_target("bottom_left", [0.35, 0.4, 0.4], [0.0, 1.0, 0.0, 0.1]),
+            top_right=_target("top_right", [0.55, -0.4, 0.4], [0.0, 0.0, 1.0, 0.1]),
+            bottom_right=_target("bottom_right", [0.35, -0.4, 0.4], [1.0, 1.0, 0.0, 0.1]),
+            top_middle=_target("top_middle", [0.55, 0.0, 0.4], [1.0, 0.0, 1.0, 0.1]),
+            bottom_middle=_target("bottom_middle", [0.35, 0.0, 0.4], [0.0, 1.0, 1.0, 0.1])),
+        colour_target_map=dict(red="top_left", green="bottom_left", blue="top_right",
+                               yellow="bottom_right", magenta="top_middle", cyan="bottom_middle")),
+}
+# config/robots/arm/*.yaml
+_ARM = dict(
+    actuator_config=dict(type="motor", high_torque_motor=dict(ctrlrange="-87 87"),
+                         low_torque_motor=dict(ctrlrange="-12 12"),
+                         joint_actuator_mapping=dict(joint1="high_torque_motor", joint2="high_torque_motor",
+                                                     joint3="high_torque_motor", joint4="high_torque_motor",
+                                                     joint5="low_torque_motor", joint6="low_torque_motor",
+                                                     joint7="low_torque_motor")),
+    controller_config=dict(
+        controller_params=dict(
+            name="osc", physics_dt="${physics_dt}", control_dt="${control_dt}",
+            gains=dict(position=dict(kp=350.0, kd=20.0), orientation=dict(kp=500.0, kd=100.0),
+                       nullspace=dict(kp=200.0, kd=30.0)),
+            nullspace=dict(joint_config=[0, -0.785, 0, -2.356, 0, 1.571, 0.785]),
+            convergence=dict(position_threshold=5e-3, orientation_threshold=68e-3)),
+        controller=dict(_target_="mujoco_controllers.osc.OSC", _partial_=True,
+                        controller_config="${robots.arm.controller_config.controller_params}")),
+    default_configurations=dict(home=[0, -0.785, 0, -2.356, 0, 1.571, 0.785]),
+    arm=dict(_target_="mujoco_robot_environments.models.arms.franka_emika.FER"),
+)
+# config/robots/end_effector/*.yaml
+_EEF = dict(controller_config=dict(controller=dict(_target_="mujoco_controllers.min_max.MinMax",
+                                                   min_val=0.0, max_val=255.0)),
+            end_effector=dict(_target_="mujoco_robot_environments.models.end_effectors.robotiq_2f85.Robotiq2F85"))
+
+# config/rearrangement.yaml (wandb block is unused by the env and omitted)
+_ROOT = dict(physics_dt=0.001, control_dt=0.005, gravity=[0.0, 0.0, -9.8], nconmax=1000, njmax=2000,
+             offheight=640, offwidth=640, znear=0.0005, viewer=False, simulation_tuning_mode=False,
+             dataset=dict(num_episodes=1000, max_steps=10, max_episodes_per_file=10))
+_DEFAULTS = {"arena/cameras": "transporter_data_collection", "arena/props": None, "task": "rearrangement"}
+
+
+def _set_path(tree: dict, path: str, value: Any, must_exist: bool):
+    keys = path.split(".")
+    node = tree
+    for k in keys[:-1]:
+        node = node.setdefault(k, {})
+    if must_exist and keys[-1] not in node:
+        raise KeyError(f"could not override '{path}': key not in config (use +{path}= to add)")
+    node[keys[-1]] = value
+
+
+def _parse_value(v: str):
+    lv = v.strip()
+    if lv.lower() in ("true", "false"):
+        return lv.lower() == "true"
+    if lv.lower() in ("null", "none"):
+        return None
+    try:
+        return int(lv)
+    except ValueError:
+        pass
+    try:
+        return float(lv)
+    except ValueError:
+        return lv
+
+
+def _interpolate(node, root):
+    if isinstance(node, dict):
+        for k, v in list(node.items()):
+            node[k] = _interpolate(v, root)
+        return node
+    if isinstance(node, list):
+        return [_interpolate(v, root) for v in node]
+    if isinstance(node, str) and node.startswith("${") and node.endswith("}"):
+        cur = root
+        for k in node[2:-1].split("."):
+            cur = cur[k]
+        return _interpolate(copy.deepcopy(cur), root)
+    return node
+
+
+def compose(config_name: str = "rearrangement", overrides: Optional[List[str]] = None) -> Cfg:
+    if config_name != "rearrangement":
+        raise ValueError(f"unknown config '{config_name}' (only the RearrangementEnv tree is mirrored)")
+    groups = dict(_DEFAULTS)
+    assigns = []
+    for ov in overrides or []:
+        key, _, val = ov.partition("=")
+        add = key.startswith("+")
+        key = key.lstrip("+")
+        if key in groups and not add:
+            groups[key] = val
+        else:
+            assigns.append((key, _parse_value(val), add))
+    if groups["arena/props"] is None:
+        # config/arena/rearrangement_table.yaml:3 points at a non-existent `props: default`
+        raise ValueError("arena/props has no default in the reference tree: pass 'arena/props=<option>'")
+    tree: Dict[str, Any] = copy.deepcopy(_ROOT)
+    tree["arena"] = dict(cameras=copy.deepcopy(_CAMERAS[groups["arena/cameras"]]),
+                         props=copy.deepcopy(_PROPS[groups["arena/props"]]))
+    tree["robots"] = dict(arm=copy.deepcopy(_ARM), end_effector=copy.deepcopy(_EEF))
+    tree["task"] = copy.deepcopy(_TASK[groups["task"]])
+    for key, val, add in assigns:
+        _set_path(tree, key, val, must_exist=not add)
+    return _wrap(_interpolate(tree, tree))
+
+
+def default_config() -> Cfg:
+    """tasks/rearrangement.py:34-40 DEFAULT_CONFIG."""
+    return compose("rearrangement", ["arena/props=colour_splitter", "simulation_tuning_mode=False"])
+
+
+def colour_separator_task_config() -> Cfg:
+    """transporter_network_data_generation.py:26-33 COLOR_SEPERATOR_TASK_CONFIG."""
+    return compose("rearrangement", ["+name=colour_splitter", "task=rearrangement_w_targets",
+                                     "arena/props=colour_splitter"])

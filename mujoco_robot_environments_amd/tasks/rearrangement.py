@@ -1,0 +1,452 @@
+"""RearrangementEnv on the MI355X batched physics step.
+
+Drop-in shell of the reference's ``tasks/rearrangement.py`` (class RearrangementEnv,
+:51-779): same constructor arguments, ``reset()`` / ``step(action_dict)`` 4-tuples and
+observation shapes, ``pick`` / ``place`` scripted macros, ``sort_colours`` / ``prop_pick`` /
+``prop_place`` demo helpers and camera maths -- with the inner loop
+(``RobotArm.run_controller`` -> OSC + ``physics.step()``) executed by the HIP kernels for
+``num_envs`` environments in lockstep.  ``BatchedRearrangementEnv`` carries a leading env
+axis on every array; ``RearrangementEnv`` is the batch of one with reference shapes and
+reference error behaviour (RuntimeError when a phase does not converge).
+
+Rendering is out of scope: observations are zero images of
+the reference shapes; pixel/world conversions use the analytic pinhole model and the table
+plane for depth.
+"""
+from __future__ import annotations
+
+import collections
+import enum
+from typing import Dict, Optional
+
+import numpy as np
+from scipy.spatial.transform import Rotation as R
+
+from .. import placement, rng
+from ..config import Cfg, colour_separator_task_config, default_config  # noqa: F401
+from ..model import compile as _compile
+from ..model import spec as _spec
+from ..models.robot_arm import RobotArm
+from ..physics import BatchedPhysics
+
+try:  # dm_env is what the reference returns; fall back to an equivalent tuple
+    import dm_env
+    from dm_env import specs as _specs
+    TimeStep, StepType = dm_env.TimeStep, dm_env.StepType
+    _Array = _specs.Array
+except Exception:  # pragma: no cover - dm_env absent on the target image
+    class StepType(enum.IntEnum):
+        FIRST = 0
+        MID = 1
+        LAST = 2
+
+    TimeStep = collections.namedtuple("TimeStep", ["step_type", "reward", "discount", "observation"])
+
+    class _Array:
+        def __init__(self, shape, dtype, name=None):
+            self.shape, self.dtype, self.name = tuple(shape), np.dtype(dtype), name
+
+        def __repr__(self):
+            return f"Array(shape={self.shape}, dtype={self.dtype}, name={self.name})"
+
+DEFAULT_CONFIG = default_config()
+TABLE_TOP_Z = 0.4
+PICK_HEIGHT = 0.575     # tasks/rearrangement.py:362,405  ("hardcode for now :(")
+PRE_PICK_HEIGHT = 0.9   # :364,408
+PROP_GEOM_ID0 = 12      # geom ids of prop_0..3 in the compiled scene
+
+PropsLabels = collections.namedtuple("PropsLabels", ["shape", "colour", "texture"])
+
+
+def mat2quat(mat3x3) -> np.ndarray:
+    """mujoco.mju_mat2Quat: (w, x, y, z)."""
+    return _compile.m2q(np.asarray(mat3x3, np.float64).reshape(3, 3))
+
+
+def home_quat() -> np.ndarray:
+    """mju_mat2Quat(R.from_euler('xyz',[0,180,0])) (tasks/rearrangement.py:391-393)."""
+    return mat2quat(R.from_euler("xyz", [0, 180, 0], degrees=True).as_matrix())
+
+
+class BatchedRearrangementEnv:
+    """num_envs independent RearrangementEnv instances stepped in lockstep on one GPU."""
+
+    def __init__(self, cfg: Optional[Cfg] = None, num_envs: int = 1, viewer=None, device: int = 0,
+                 seed: Optional[int] = None, env_id_offset: int = 0):
+        self._cfg = cfg if cfg is not None else DEFAULT_CONFIG
+        cfg = self._cfg
+        self.num_envs = int(num_envs)
+        self.has_viewer = False  # no viewer on a headless GPU batch (tasks/rearrangement.py:64-70)
+        self.env_ids = np.arange(env_id_offset, env_id_offset + self.num_envs)
+        self.seed = int(cfg.task.initializers.seed if seed is None else seed)
+        ac = cfg.robots.arm.actuator_config
+        lim = [float(ac[ac.joint_actuator_mapping[f"joint{i + 1}"]].ctrlrange.split()[1]) for i in range(7)]
+        scene = _spec.default_scene(dict(physics_dt=cfg.physics_dt, gravity=cfg.gravity, motor_ctrlrange=lim,
+                                         home=cfg.robots.arm.default_configurations.home))
+        self._model = _compile.compile_scene(scene)
+        self._physics = BatchedPhysics(self.num_envs, model=self._model, device=device)
+        # ---- props: count / size / colour per env (environment/props.py:583-639)
+        pc = cfg.arena.props
+        u = rng.uniform(self.seed ^ 0xC0105, self.env_ids, [0], 12)[0]
+        if pc.min_objects == pc.max_objects:
+            self.nprops = np.full(self.num_envs, pc.min_objects, np.int32)
+        else:  # np.random.randint(min, max): max exclusive
+            self.nprops = (pc.min_objects + np.floor(u[:, 0] * (pc.max_objects - pc.min_objects))).astype(np.int32)
+        assert self.nprops.max() <= 4, "the compiled scene has 4 cube slots"
+        size = pc.min_object_size + (pc.max_object_size - pc.min_object_size) * u[:, 1:5]
+        self.prop_half_size = np.repeat(size[:, :, None], 3, axis=2)
+        self.prop_colours = []
+        for i in range(self.num_envs):
+            cols = []
+            for p in range(int(self.nprops[i])):
+                cols.append(pc.colours[p] if p <= 1 else pc.colours[int(u[i, 5 + p] * len(pc.colours)) % len(pc.colours)])
+            self.prop_colours.append(cols)
+        self._physics.set_props(self.nprops, self.prop_half_size)
+        # ---- cameras (config/arena/cameras/*.yaml); only the pose / fovy constants are needed
+        self._cameras = {}
+        for cam in cfg.arena.cameras:
+            q = np.asarray(cam.quat, np.float64)
+            q = q / np.linalg.norm(q)
+            self._cameras[f"{cam.name}/{cam.name}"] = dict(pos=np.asarray(cam.pos, np.float64),
+                                                           mat=_compile.q2m(q), fovy=float(cam.fovy))
+            if cam.name == "overhead_camera":
+                self.overhead_camera_height, self.overhead_camera_width = int(cam.height), int(cam.width)
+        self._reset_count = 0
+        self._place_count = 0
+        self._robot: Optional[RobotArm] = None
+        self.mode = None
+        self.eef_home_pose = None
+        self.last_converged = np.ones(self.num_envs, bool)
+        self.failed_phase = np.full(self.num_envs, "", dtype=object)
+
+    # ------------------------------------------------------------------ misc
+    def close(self) -> None:
+        self._physics.close()
+
+    @property
+    def physics(self) -> BatchedPhysics:
+        return self._physics
+
+    def _zeros_obs(self):
+        h, w = self.overhead_camera_height, self.overhead_camera_width
+        n = self.num_envs
+        rgb = np.broadcast_to(np.zeros((1, 1, 1, 1), np.uint8), (n, h, w, 3))
+        depth = np.broadcast_to(np.zeros((1, 1, 1), np.float32), (n, h, w))
+        return {"overhead_camera/rgb": rgb, "overhead_camera/depth": depth}
+
+    def _compute_observation(self):
+        return self._zeros_obs()
+
+    def observation_spec(self):
+        h, w = self.overhead_camera_height, self.overhead_camera_width
+        return {"overhead_camera/depth": _Array(shape=(h, w), dtype=np.float32),
+                "overhead_camera/rgb": _Array(shape=(h, w, 3), dtype=np.float32)}
+
+    def action_spec(self) -> Dict[str, _Array]:
+        return {"pose": _Array(shape=(7,), dtype=np.float64),
+                "pixel_coords": _Array(shape=(2,), dtype=np.int64),
+                "gripper_rot": _Array(shape=(1,), dtype=np.float64)}
+
+    # ----------------------------------------------------------------- reset
+    def reset(self) -> TimeStep:
+        """Physics.reset, arm to home, PropPlacer (sample + settle), new RobotArm
+        (tasks/rearrangement.py:297-337)."""
+        ws = self._cfg.task.initializers.workspace
+        self._physics.reset()
+        pose, ok = placement.sample_poses(self.seed + 104729 * self._reset_count, self.env_ids, self.nprops,
+                                          self.prop_half_size, ws.min_pose, ws.max_pose)
+        if not ok.all():
+            raise RuntimeError("Failed to find a non-colliding pose for some props")
+        self._reset_count += 1
+        qp = placement.write_poses(self._physics.qpos(), pose, self.nprops)
+        self._physics.set_state(qp, np.zeros((self.num_envs, 39), np.float32))
+        # settle with the robot frozen: >= 0.3 s, <= 2 s, until max|qvel| of the cubes < 1e-3
+        steps, done = 300, False
+        self._physics.step(steps, flags=2)
+        while not done and steps < 2000:
+            qv = self._physics.qvel()[:, 15:]
+            done = bool(np.abs(qv).max() < 1e-3)
+            if not done:
+                self._physics.step(100, flags=2)
+                steps += 100
+        cp = self._cfg.robots.arm.controller_config.controller_params
+        mm = self._cfg.robots.end_effector.controller_config.controller
+        self._robot = RobotArm(self._physics, controller_params=cp, gripper_cfg=mm)
+        self._robot.time = steps * self._physics.timestep
+        pose0 = np.atleast_2d(self._robot.eef_pose).copy()
+        pose0[:, 0] -= 0.1  # reference shifts x although the comment says "up" (App. D.5)
+        self.eef_home_pose = pose0
+        self.mode = "pick"
+        self.last_converged[:] = True
+        self.failed_phase[:] = ""
+        return TimeStep(step_type=StepType.FIRST, reward=0.0, discount=0.0,
+                        observation=self._compute_observation())
+
+    # ------------------------------------------------------------------ step
+    def step(self, action_dict) -> TimeStep:
+        observation = self._compute_observation()  # rendered BEFORE acting (App. D.1)
+        if self.mode == "pick":
+            self.pick(action_dict["pose"])
+            self.mode = "place"
+        else:
+            self.place(action_dict["pose"])
+            self.mode = "pick"
+        return TimeStep(step_type=StepType.MID, reward=0.0, discount=0.0, observation=observation)
+
+    def _phase(self, name: str, duration: float):
+        conv = np.atleast_1d(self._robot.run_controller(duration))
+        newly = (~conv) & (self.failed_phase == "")
+        self.failed_phase[newly] = name
+        self.last_converged &= conv
+        return conv
+
+    def _pose2d(self, pose):
+        pose = np.asarray(pose)
+        return pose.reshape(self.num_envs, 7) if pose.ndim == 1 else pose
+
+    def pick(self, pose):
+        """Scripted pick (tasks/rearrangement.py:358-399): pre-pick 2 s, descend 2 s,
+        close 1 s, lift 2 s, home 2 s."""
+        pose[..., 2] = PICK_HEIGHT  # in-place, like the reference
+        p = self._pose2d(pose).astype(np.float64)
+        pre = p.copy()
+        pre[:, 2] = PRE_PICK_HEIGHT
+        c = self._robot.arm_controller
+        c.set_target(position=pre[:, :3], velocity=np.zeros(3), quat=pre[:, 3:], angular_velocity=np.zeros(3))
+        self._phase("Failed to move arm to pre pick position", 2.0)
+        c.set_target(position=p[:, :3])
+        self._phase("Failed to move arm to pick position", 2.0)
+        self._robot.end_effector_controller.status = "max"
+        self._phase("Failed to close gripper", 1.0)
+        c.set_target(position=pre[:, :3])
+        self._phase("Failed to move arm to pre grasp position", 2.0)
+        c.set_target(position=self.eef_home_pose, quat=home_quat())
+        self._phase("Failed to move arm to home position", 2.0)
+
+    def place(self, pose):
+        """Scripted place (tasks/rearrangement.py:401-440)."""
+        pose[..., 2] = PICK_HEIGHT
+        p = self._pose2d(pose).astype(np.float64)
+        pre = p.copy()
+        pre[:, 2] = PRE_PICK_HEIGHT
+        c = self._robot.arm_controller
+        c.set_target(position=pre[:, :3], quat=pre[:, 3:])
+        self._phase("Failed to move arm to pre place position", 2.0)
+        c.set_target(position=p[:, :3])
+        self._phase("Failed to move arm to place position", 2.0)
+        self._robot.end_effector_controller.status = "min"
+        self._phase("Failed to open gripper", 1.0)
+        c.set_target(position=pre[:, :3])
+        self._phase("Failed to move arm to pre place position", 2.0)
+        c.set_target(position=self.eef_home_pose, quat=home_quat())
+        self._phase("Failed to move arm to home position", 2.0)
+
+    # ---------------------------------------------------------------- camera
+    def _get_camera_intrinsics(self, camera_name, h, w, inverse=False):
+        fov = self._cameras[camera_name]["fovy"]
+        f = (1.0 / np.tan(np.deg2rad(fov) / 2)) * self.overhead_camera_height / 2.0
+        return np.array([[-f, 0, (w - 1) / 2], [0, f, (h - 1) / 2], [0, 0, 1]])
+
+    def _get_camera_extrinsics(self, camera_name):
+        cam = self._cameras[camera_name]
+        ext = np.eye(4)
+        ext[:3, :3] = cam["mat"].T
+        ext[:3, 3] = -cam["mat"].T @ cam["pos"]
+        return ext
+
+    def world_2_pixel(self, camera_name, coords):
+        """tasks/rearrangement.py:533-548 (coords [3] or [N,3])."""
+        K = self._get_camera_intrinsics(camera_name, self.overhead_camera_height, self.overhead_camera_width)
+        E = self._get_camera_extrinsics(camera_name)
+        c = np.atleast_2d(np.asarray(coords, np.float64))
+        cam = (E @ np.concatenate([c, np.ones((len(c), 1))], axis=1).T).T
+        cam = cam[:, :3] / cam[:, 3:4]
+        img = (K @ cam.T).T
+        img = img[:, :2] / img[:, 2:3]
+        out = np.round(img).astype(np.int32)
+        return out[0] if np.asarray(coords).ndim == 1 else out
+
+    def pixel_2_world(self, camera_name, coords):
+        """tasks/rearrangement.py:505-531 with the depth taken from the table plane
+        (rendering is stubbed): intersect the pixel ray with z = table top."""
+        K = self._get_camera_intrinsics(camera_name, self.overhead_camera_height, self.overhead_camera_width)
+        E = self._get_camera_extrinsics(camera_name)
+        ray_c = np.linalg.inv(K) @ np.concatenate([np.asarray(coords, np.float64), np.ones(1)])
+        cam = self._cameras[camera_name]
+        d_w = cam["mat"] @ (-ray_c)  # camera looks along -z; scale by depth below
+        depth = (TABLE_TOP_Z - cam["pos"][2]) / d_w[2]
+        camc = np.concatenate([ray_c * (-depth), np.ones(1)])
+        w = np.linalg.inv(E) @ camc
+        return w[:3] / w[3]
+
+    def get_camera_params(self, camera_name):
+        return {"intrinsics": self._get_camera_intrinsics(camera_name, self.overhead_camera_height, self.overhead_camera_width),
+                "extrinsics": self._get_camera_extrinsics(camera_name)}
+
+    def get_camera_metadata(self):
+        K = self._get_camera_intrinsics("overhead_camera/overhead_camera", self.overhead_camera_height, self.overhead_camera_width)
+        E = self._get_camera_extrinsics("overhead_camera/overhead_camera")
+        quat = R.from_matrix(E[:3, :3]).as_quat()
+        # NB the reference reads the translation from row 3 of the 4x4 (always 0,0,0): kept (:563-565)
+        return {"intrinsics": {"fx": K[0, 0], "fy": K[1, 1], "cx": K[0, 2], "cy": K[1, 2]},
+                "extrinsics": {"x": E[3, 0], "y": E[3, 1], "z": E[3, 2],
+                               "qx": quat[0], "qy": quat[1], "qz": quat[2], "qw": quat[3]}}
+
+    # ------------------------------------------------------------ demo logic
+    def props_info_env(self, i: int, prop_pose: Optional[np.ndarray] = None) -> dict:
+        """props_info of env i (tasks/rearrangement.py:227-295); keys are geom ids."""
+        if prop_pose is None:
+            prop_pose = self._physics.sites()[2]
+        info = {}
+        for p in range(int(self.nprops[i])):
+            pos = prop_pose[i, p, :3].astype(np.float64)
+            qw = prop_pose[i, p, 3:7].astype(np.float64)
+            mat = _compile.q2m(qw / np.linalg.norm(qw))
+            half = self.prop_half_size[i, p]
+            corners = np.array([[sx, sy, sz] for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)]) * half
+            px = self.world_2_pixel("overhead_camera/overhead_camera", pos + corners @ mat.T)
+            bbox = np.array([px[:, 0].min(), px[:, 1].min(), px[:, 0].max(), px[:, 1].max()])
+            info[PROP_GEOM_ID0 + p] = {
+                "prop_name": f"prop_{p}", "position": pos,
+                "orientation": R.from_matrix(mat).as_quat(),  # scipy (x,y,z,w) like the reference
+                "rgba": None, "bbox": bbox,
+                "labels": PropsLabels("cube", self.prop_colours[i][p], "plain")}
+        return info
+
+    def prop_pick_env(self, i: int, prop_id: int, info: Optional[dict] = None) -> np.ndarray:
+        """tasks/rearrangement.py:579-595."""
+        info = info or self.props_info_env(i)
+        obj_pose, obj_quat = info[prop_id]["position"], info[prop_id]["orientation"]
+        m = R.from_quat(obj_quat).as_matrix()
+        rz = abs(np.rad2deg(np.arctan2(m[1, 0], m[0, 0])))
+        rz = min([rz, rz - 90])
+        grasp = mat2quat(R.from_euler("xyz", [0, 180, rz], degrees=True).as_matrix())
+        return np.concatenate([obj_pose, grasp])
+
+    def prop_place_env(self, i: int, prop_id: int, min_pose=None, max_pose=None, info: Optional[dict] = None):
+        """Collision-free place pose (tasks/rearrangement.py:597-665): uniform samples in the
+        bounds, rejected while any other cube is closer than 0.05 m (contact.dist <= 0.05)."""
+        info = info or self.props_info_env(i)
+        ws = self._cfg.task.initializers.workspace
+        lo = np.asarray(ws.min_pose if min_pose is None else min_pose, np.float64)
+        hi = np.asarray(ws.max_pose if max_pose is None else max_pose, np.float64)
+        p = prop_id - PROP_GEOM_ID0
+        rb = np.linalg.norm(self.prop_half_size[i], axis=1)
+        quat = home_quat()
+        for att in range(10000):
+            u = rng.uniform(self.seed + 1, [int(self.env_ids[i])], [self._place_count * 10000 + att], 3)[0, 0]
+            pos = lo + (hi - lo) * u
+            ok = True
+            for other, a in info.items():
+                if other == prop_id:
+                    continue
+                o = other - PROP_GEOM_ID0
+                if np.linalg.norm(pos - a["position"]) <= rb[p] + rb[o] + 0.05:
+                    ok = False
+                    break
+            if ok:
+                self._place_count += 1
+                return np.concatenate([pos, quat])
+        raise Exception("Failed to find collision free place pose.")
+
+    def sort_colours_env(self, i: int, info: Optional[dict] = None):
+        """tasks/rearrangement.py:700-751 for env i."""
+        info = info or self.props_info_env(i)
+        task = self._cfg.task
+        for prop_id, a in info.items():
+            tl = task.target_locations[task.colour_target_map[a["labels"].colour]]
+            lo = np.array([tl["location"][0] - tl["size"][0] / 2, tl["location"][1] - tl["size"][1] / 2, 0.4])
+            hi = np.array([tl["location"][0] + tl["size"][0] / 2, tl["location"][1] + tl["size"][1] / 2, 0.4])
+            x, y, _ = a["position"]
+            if not (lo[0] <= x <= hi[0] and lo[1] <= y <= hi[1]):
+                return True, self.prop_pick_env(i, prop_id, info), self.prop_place_env(i, prop_id, lo, hi, info)
+        return False, None, None
+
+    def sort_colours(self):
+        """Batched: (in_progress[N], pick_pose[N,7], place_pose[N,7]); finished envs get
+        their home pose as a no-op target."""
+        poses = self._physics.sites()[2]
+        prog = np.zeros(self.num_envs, bool)
+        pick = np.zeros((self.num_envs, 7))
+        place = np.zeros((self.num_envs, 7))
+        for i in range(self.num_envs):
+            ip, a, b = self.sort_colours_env(i, self.props_info_env(i, poses))
+            prog[i] = ip
+            if ip:
+                pick[i], place[i] = a, b
+            else:
+                pick[i, :3] = place[i, :3] = self.eef_home_pose[i]
+                pick[i, 3:] = place[i, 3:] = home_quat()
+        return prog, pick, place
+
+    def random_pick_and_place(self):
+        """tasks/rearrangement.py:667-698 (always the first prop), batched."""
+        poses = self._physics.sites()[2]
+        ws = self._cfg.task.initializers.workspace
+        pick = np.zeros((self.num_envs, 7))
+        place = np.zeros((self.num_envs, 7))
+        u = rng.uniform(self.seed + 2, self.env_ids, [self._place_count], 3)[0]
+        self._place_count += 1
+        for i in range(self.num_envs):
+            info = self.props_info_env(i, poses)
+            first = list(info.keys())[0]
+            m = R.from_quat(info[first]["orientation"]).as_matrix()
+            rz = np.rad2deg(np.arctan2(m[1, 0], m[0, 0]))
+            grasp = mat2quat(R.from_euler("xyz", [0, 180, rz], degrees=True).as_matrix())
+            pick[i] = np.concatenate([info[first]["position"], grasp])
+            place[i] = np.concatenate([np.asarray(ws.min_pose) + (np.asarray(ws.max_pose) - np.asarray(ws.min_pose)) * u[i], grasp])
+        return pick, place
+
+
+class RearrangementEnv(BatchedRearrangementEnv):
+    """Batch of one with the reference's shapes and error behaviour
+    (signature: tasks/rearrangement.py:54-58)."""
+
+    def __init__(self, viewer=None, cfg: Optional[Cfg] = None, device: int = 0):
+        super().__init__(cfg=cfg, num_envs=1, viewer=viewer, device=device)
+
+    def _compute_observation(self):
+        o = self._zeros_obs()
+        return {k: v[0] for k, v in o.items()}
+
+    def _phase(self, name, duration):
+        conv = super()._phase(name, duration)
+        if not conv[0]:  # tasks/rearrangement.py:371-399,413-440
+            raise RuntimeError(name)
+        return conv
+
+    @property
+    def props_info(self) -> dict:
+        return self.props_info_env(0)
+
+    def prop_pick(self, prop_id):
+        return self.prop_pick_env(0, prop_id)
+
+    def prop_place(self, prop_id, min_pose=None, max_pose=None):
+        return self.prop_place_env(0, prop_id, min_pose, max_pose)
+
+    def sort_colours(self):
+        return self.sort_colours_env(0)
+
+    def random_pick_and_place(self):
+        a, b = super().random_pick_and_place()
+        return a[0], b[0]
+
+    def reset(self):
+        ts = super().reset()
+        self.eef_home_pose = self.eef_home_pose[0]
+        return ts
+
+    def pick(self, pose):
+        self.eef_home_pose = np.atleast_2d(self.eef_home_pose)
+        try:
+            super().pick(pose)
+        finally:
+            self.eef_home_pose = self.eef_home_pose[0]
+
+    def place(self, pose):
+        self.eef_home_pose = np.atleast_2d(self.eef_home_pose)
+        try:
+            super().place(pose)
+        finally:
+            self.eef_home_pose = self.eef_home_pose[0]

@@ -1,0 +1,57 @@
+"""Generates tests/golden/oracle_rollout_v1.npz from THIS repo's fp64 CPU oracle.
+
+The reference cannot produce vectors here (MuJoCo / dm_control / mujoco_controllers are
+absent), so the fixture pins the oracle against regressions and gives
+the GPU tests a committed target.  Run from the repo root:  python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+from mujoco_robot_environments_amd import rng  # noqa: E402
+from mujoco_robot_environments_amd.model import compile as MC  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+from tests.common import init_oracle_env  # noqa: E402
+
+N, T, SEED, CS = 4, 20, 42, 5
+
+
+def scenario():
+    ids = np.arange(N)
+    nprops, sizes = rng.prop_params(SEED, ids)
+    yaws = rng.uniform(SEED + 7, ids, [0], 4)[0] * np.pi
+    acts = rng.random_actions(SEED, ids, np.arange(T), scale=0.1)
+    return ids, nprops, sizes, yaws, acts
+
+
+def run():
+    A = MC.compile_scene()
+    m = O.Model(MC.to_blob(A))
+    ids, nprops, sizes, yaws, acts = scenario()
+    q0 = np.zeros((N, 43))
+    qpos = np.zeros((T, N, 43))
+    qvel = np.zeros((T, N, 39))
+    for i in range(N):
+        e = O.Env(m, int(nprops[i]), sizes[i])
+        init_oracle_env(e, int(nprops[i]), sizes[i], yaw=yaws[i], z_extra=0.002)
+        e.forward()
+        q0[i] = e.arr("qpos")[:43]
+        bias = e.arr("qfrc_bias")[:7].copy()
+        for t in range(T):
+            c = acts[t, i].copy()
+            c[:7] += bias
+            e.arr("ctrl")[:] = c.astype(np.float32).astype(np.float64)
+            e.step(CS)
+            qpos[t, i] = e.arr("qpos")[:43]
+            qvel[t, i] = e.arr("qvel")[:39]
+    return dict(q0=q0, qpos=qpos, qvel=qvel, nprops=nprops, sizes=sizes, bias=bias, acts=acts)
+
+
+if __name__ == "__main__":
+    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle_rollout_v1.npz")
+    np.savez_compressed(out, **run())
+    print("wrote", out)

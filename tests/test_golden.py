@@ -1,0 +1,46 @@
+"""Golden fixture (tests/golden/oracle_rollout_v1.npz, produced by make_golden.py from
+this repo's own oracle -- the reference has no vectors, parity unpinned)."""
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, "golden", "oracle_rollout_v1.npz")
+
+
+def test_oracle_reproduces_golden():
+    from tests.golden import make_golden
+    g = np.load(GOLD)
+    r = make_golden.run()
+    assert np.array_equal(r["nprops"], g["nprops"])
+    assert np.abs(r["qpos"] - g["qpos"]).max() < 1e-9
+    assert np.abs(r["qvel"] - g["qvel"]).max() < 1e-7
+
+
+@pytest.mark.gpu
+def test_gpu_matches_golden(compiled_model):
+    import torch
+    from mujoco_robot_environments_amd.physics import BatchedPhysics
+    g = np.load(GOLD)
+    A, _ = compiled_model
+    N, T = g["q0"].shape[0], g["qpos"].shape[0]
+    phys = BatchedPhysics(N, model=A)
+    phys.set_props(g["nprops"], g["sizes"])
+    qp = phys.qpos().copy()
+    for i in range(N):
+        n = int(g["nprops"][i])
+        qp[i, :15 + 7 * n] = g["q0"][i, :15 + 7 * n]
+    phys.set_state(qp, np.zeros((N, 39), np.float32))
+    acts = g["acts"].copy()
+    acts[:, :, :7] += g["bias"]
+    seq = torch.tensor(acts, dtype=torch.float32, device=phys.device).contiguous()
+    tr = phys.set_trace(N, T * 5)
+    phys.rollout(seq, control_steps=5)
+    phys.sync()
+    gq = tr.cpu().numpy()[4::5, :, :43]
+    err = np.abs(gq - g["qpos"])
+    for i in range(N):
+        err[:, i, 15 + 7 * int(g["nprops"][i]):] = 0
+    print("gpu vs golden: arm %.2e grip %.2e cubes %.2e" % (err[..., :7].max(), err[..., 7:15].max(), err[..., 15:].max()))
+    assert err[..., :7].max() < 1e-4 and err[..., 15:].max() < 1e-4 and err[..., 7:15].max() < 5e-3

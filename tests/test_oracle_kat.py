@@ -1,0 +1,176 @@
+"""Known-answer tests pinning the CPU oracle (the reference ships no tests and MuJoCo is
+absent: SURVEY.md section 8c, 'parity unpinned').  Each test checks one stage of the
+restated mj_step pipeline against an analytic result or an independent computation."""
+import numpy as np
+import pytest
+
+from mujoco_robot_environments_amd.model import compile as MC
+from tests.common import HOME, init_oracle_env
+
+
+def _env(oracle_model, nprops=0, sizes=None):
+    from oracle import oracle as O
+    e = O.Env(oracle_model, nprops=nprops, prop_size=sizes)
+    e.arr("qpos")[:7] = HOME
+    return e
+
+
+def _dense_M(A, e):
+    nv = 39
+    M = np.zeros((nv, nv))
+    qM = e.arr("qM")
+    for i in range(nv):
+        a, j = int(A["dof_Madr"][i]), i
+        while j >= 0:
+            M[i, j] = M[j, i] = qM[a]
+            a += 1
+            j = int(A["dof_parentid"][j])
+    return M
+
+
+def test_free_fall_semi_implicit_euler(compiled_model, oracle_model):
+    """z_k = z0 - g h^2 k(k+1)/2 exactly (free joint, no contact, implicitfast == Euler here)."""
+    e = _env(oracle_model, 1)
+    q = e.arr("qpos")
+    q[15:22] = [0.45, 0.0, 1.5, 1, 0, 0, 0]
+    e.forward()
+    for k in range(1, 201):
+        e.step(1)
+        assert abs(q[17] - (1.5 - 9.8 * 1e-6 * k * (k + 1) / 2)) < 1e-12
+    assert abs(e.arr("qvel")[17] + 9.8 * 0.2) < 1e-12
+
+
+def test_free_rotation_conserves_angular_momentum(oracle_model):
+    sizes = np.tile([0.01, 0.015, 0.02], (4, 1))
+    e = _env(oracle_model, 1, sizes)
+    q, v = e.arr("qpos"), e.arr("qvel")
+    q[15:22] = [0.45, 0.0, 3.0, 1, 0, 0, 0]
+    v[18:21] = [3.0, -2.0, 5.0]
+    e.forward()
+    I = 0.1 / 3 * np.array([0.015**2 + 0.02**2, 0.01**2 + 0.02**2, 0.01**2 + 0.015**2])
+
+    def L():
+        return MC.q2m(q[18:22]) @ (I * v[18:21])
+    L0 = L()
+    for _ in range(300):
+        e.step(1)
+    assert abs(np.linalg.norm(q[18:22]) - 1) < 1e-12
+    assert np.linalg.norm(L() - L0) / np.linalg.norm(L0) < 2e-3  # first-order integrator drift
+
+
+def test_crb_mass_matrix_matches_jacobian_formula(compiled_model, oracle_model):
+    A, _ = compiled_model
+    rs = np.random.RandomState(0)
+    e = _env(oracle_model, 4)
+    for trial in range(3):
+        q = e.arr("qpos")
+        init_oracle_env(e, 4, yaw=rs.uniform(0, 3, 4))
+        q[:7] = HOME + rs.uniform(-0.3, 0.3, 7)
+        q[7:15] = rs.uniform(0, 0.3, 8) * [1, -1, 1, -1, 1, -1, 1, -1]
+        e.forward()
+        M = _dense_M(A, e)
+        Md = MC.dense_mass_matrix(A, q[:43].copy())
+        assert np.abs(M - Md).max() < 1e-12
+        assert np.linalg.eigvalsh(M).min() > 0
+        # sparse L'DL solve round trip
+        y = rs.randn(39)
+        x = np.linalg.solve(M, y)
+        e.arr("ctrl")[:] = 0
+        assert np.abs(M @ x - y).max() < 1e-9
+
+
+def test_bias_force_is_potential_gradient_at_rest(compiled_model, oracle_model):
+    """qvel = 0: qfrc_bias = dV/dq with V = sum m g z_com (finite differences)."""
+    A, _ = compiled_model
+    e = _env(oracle_model, 0)
+    q = e.arr("qpos")
+    q[:7] = HOME + 0.2
+    e.forward()
+    bias = e.arr("qfrc_bias")[:15].copy()
+
+    def V(qq):
+        xpos, xquat = MC.forward_kinematics(A, qq)
+        z = 0.0
+        for b in range(1, 16):
+            z += A["body_mass"][b] * 9.8 * (xpos[b] + MC.qrot(xquat[b], A["body_ipos"][b]))[2]
+        return z
+    q0 = q[:43].copy()
+    for d in range(15):
+        qp, qm = q0.copy(), q0.copy()
+        qp[d] += 1e-6
+        qm[d] -= 1e-6
+        assert abs((V(qp) - V(qm)) / 2e-6 - bias[d]) < 1e-6
+
+
+def test_cube_rests_on_table_with_weight_balanced(oracle_model):
+    e = _env(oracle_model, 1)
+    q = e.arr("qpos")
+    q[15:22] = [0.45, 0.1, 0.4 + 0.0155 + 0.001, 1, 0, 0, 0]
+    e.forward()
+    for _ in range(600):
+        e.step(1)
+    assert e.ncon >= 4
+    n = e.nefc
+    f = e.arr("efc_force")[:n]
+    normals = f[n - 12::3]
+    assert abs(normals.sum() - 0.1 * 9.8) < 2e-4  # PGS stops at 100 sweeps, not at the exact optimum
+    assert (normals > 0).all() and np.ptp(normals) < 0.02
+    assert np.abs(e.arr("qvel")[15:18]).max() < 1e-4
+    assert np.abs(e.arr("qvel")[18:21]).max() < 5e-3  # slow PGS friction creep (unconverged sweeps)
+    assert -5e-4 < q[17] - 0.4155 < 0  # small steady penetration of the soft contact
+
+
+def test_boxbox_face_edge_and_margin():
+    from oracle import oracle as O
+    I = np.eye(3)
+    # face-face: unit cube resting 1 mm into a slab -> 4 points at the cube's bottom corners
+    n, nrm, pos, dist = O.boxbox([0, 0, 0], I, [1, 1, 0.5], [0, 0, 0.999], I, [0.5, 0.5, 0.5], 0.0)
+    assert n == 4 and np.allclose(nrm, [0, 0, 1]) and np.allclose(dist, -0.001)
+    assert np.allclose(sorted(map(tuple, np.round(np.abs(pos[:, :2]), 9))), [(0.5, 0.5)] * 4)
+    assert np.allclose(pos[:, 2], 0.4995)
+    # separated but within margin: reported with positive distance
+    n, nrm, pos, dist = O.boxbox([0, 0, 0], I, [1, 1, 0.5], [0, 0, 1.05], I, [0.5, 0.5, 0.5], 0.15)
+    assert n == 4 and np.allclose(dist, 0.05)
+    n, *_ = O.boxbox([0, 0, 0], I, [1, 1, 0.5], [0, 0, 1.2], I, [0.5, 0.5, 0.5], 0.15)
+    assert n == 0
+    # edge-edge: two cubes rotated 45 deg about perpendicular axes touching along crossed edges
+    c, s = np.cos(np.pi / 4), np.sin(np.pi / 4)
+    Rx = np.array([[1, 0, 0], [0, c, -s], [0, s, c]])
+    Ry = np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]])
+    h = 0.5 * np.sqrt(2)
+    n, nrm, pos, dist = O.boxbox([0, 0, 0], Rx, [0.5] * 3, [0, 0, 2 * h - 0.01], Ry, [0.5] * 3, 0.0)
+    assert n == 1 and np.allclose(np.abs(nrm), [0, 0, 1], atol=1e-9) and abs(dist[0] + 0.01) < 1e-9
+    assert np.allclose(pos[0], [0, 0, h - 0.005], atol=1e-9)
+
+
+def test_gripper_linkage_closes_symmetrically_with_clamped_force(oracle_model):
+    e = _env(oracle_model, 0)
+    e.forward()
+    e.arr("ctrl")[:7] = e.arr("qfrc_bias")[:7]
+    e.arr("ctrl")[7] = 255.0
+    for _ in range(400):
+        e.arr("ctrl")[:7] = e.arr("qfrc_bias")[:7]
+        e.step(1)
+        assert abs(e.arr("actuator_force")[7]) <= 1.5 + 1e-12  # forcerange override (robotiq_2f85.py:41-48)
+    q = e.arr("qpos")
+    assert abs(q[7] - q[11]) < 1e-4, "driver joints are tied by the joint equality"
+    assert 0.7 < q[7] <= 0.8 + 2e-3
+    n = e.nefc
+    assert np.abs(e.arr("efc_pos")[:6]).max() < 5e-4, "connect residuals stay small"
+
+
+def test_osc_holds_current_pose_and_tracks_a_step(oracle_model):
+    from oracle import oracle as O
+    e = _env(oracle_model, 0)
+    e.forward()
+    p = O.make_osc()
+    sx = e.arr("site_xpos")[:3].copy()
+    p.target_pos[:] = sx
+    p.target_quat[:] = MC.m2q(e.arr("site_xmat")[:9].reshape(3, 3))
+    tau = e.osc(p)
+    assert np.abs(tau - e.arr("qfrc_bias")[:7]).max() < 1e-9  # zero error, q = nullspace config
+    assert e.osc_converged(p)
+    p.target_pos[:] = sx + [0.05, 0.08, -0.12]
+    assert not e.osc_converged(p)
+    assert e.run_controller(p, 0.0, 400, 5)  # converges within the 2 s window (rearrangement.py:371)
+    assert np.linalg.norm(e.arr("site_xpos")[:3] - np.array(p.target_pos)) < 5e-3
