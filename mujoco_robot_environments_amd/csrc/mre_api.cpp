@@ -6,6 +6,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -240,6 +241,7 @@ extern "C" int mre_create(const void* blob, size_t nbytes, int num_envs, int dev
   mre_env* e = new mre_env();
   int rc = build_model(blob, nbytes, e->hM);
   if (rc != MRE_OK) { delete e; return rc; }
+  if (const char* it = getenv("MRE_DEBUG_ITERS")) e->hM.iterations = atoi(it);  // profiling knob only
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
     delete e;

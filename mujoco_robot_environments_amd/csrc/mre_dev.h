@@ -27,6 +27,7 @@ constexpr int MAXFAC = 45;    // (i,j) ancestor pairs touched by one elimination
 constexpr int NCON_MAX = 36;  // active contacts kept per env
 constexpr int NEFC_MAX = 128; // constraint rows per env
 constexpr int NRROW_MAX = 64; // rows with a robot part
+constexpr int MAXBLK = 64;    // 7 equality + <=15 limit rows + NCON_MAX contacts
 
 struct DevModel {
   // ---- bodies (index = body id)

@@ -50,8 +50,15 @@ struct Sm {
   int hdr[NEFC_MAX];
   float Jp[NEFC_MAX][13];
   float Jr[NRROW_MAX][NRV], Br[NRROW_MAX][NRV];
-  float Ablk[NCON_MAX][9];
+  float Ablk[NCON_MAX + 8][9];  // contact blocks, then scalar-row triples
+  float con_fric[NCON_MAX];
   float jar[NEFC_MAX];
+  float frc[NEFC_MAX];
+  float zpad[4];  // zeros: operand source for lanes / rows outside a block
+  // constraint blocks (scalar row or 3-row contact) and their island schedule
+  int blk_info[MAXBLK];
+  int sched[MAXBLK][5];
+  int nblk, nsched;
 };
 
 struct BodyRegs {
@@ -434,6 +441,7 @@ __global__ __launch_bounds__(64) void k_step(StepArgs a) {
     s.qacc[l] = 0.f;
   }
   if (l < NU) s.ctrl[l] = a.ctrl[(size_t)env * NU + l];
+  if (l < 4) s.zpad[l] = 0.f;
   if (l == 0) { s.nprops = a.nprops[env]; s.overflow = 0; s.ncon = 0; s.nefc = 0; s.solver_iters = 0; }
   if (l < NPROP * 3) {
     const float sz = a.prop_size[(size_t)env * NPROP * 3 + l];

@@ -18,6 +18,9 @@
 namespace mre {
 
 constexpr int HDR_NONE = 0xFF;
+constexpr int BLK_NONE = 0x7F;
+
+MRE_DEV void build_schedule(const DevModel* M, Sm& s);
 
 MRE_DEV float prop_invM(const Sm& s, int p, int k) {
   return 1.0f / ((k < 3) ? s.prop_mass[p] : s.prop_inertia[p][k - 3]);
@@ -94,6 +97,7 @@ MRE_DEV void collide(const DevModel* M, Sm& s, int l) {
     for (int k = 0; k < 9; k++) s.con_frame[id][k] = f[k];
     s.con_dist[id] = pc.dist[c];
     s.con_pair[id] = l;
+    s.con_fric[id] = M->pair_friction[l][0];
   }
   __syncthreads();
 }
@@ -189,6 +193,7 @@ MRE_DEV void assemble_constraints(const DevModel* M, Sm& s, int l) {
     s.ncon = kept;
     s.nefc = base + 3 * kept;
     s.nrrow = rnext;
+    build_schedule(M, s);
   }
   __syncthreads();
   const int nefc = s.nefc, nl = s.nl;
@@ -302,13 +307,17 @@ MRE_DEV void assemble_constraints(const DevModel* M, Sm& s, int l) {
     solve_robot_serial(M, s.qLD, s.qLDinv, s.Br[rs]);
   }
   __syncthreads();
-  // ---- diagonal blocks of A = J M^-1 J' + R
+  // ---- diagonal blocks of A = J M^-1 J' + R.  Contacts: 3x3 block of the contact's rows.
+  // Scalar rows (equality / limit, robot-only) are grouped in consecutive triples whose
+  // 3x3 block lets one solver step apply the three sequential scalar updates exactly.
   for (int i = l; i < nefc; i += 64) {
     const int h = s.hdr[i];
     const int rs = h & 0xFF, pa = (h >> 8) & 0xF, pb = (h >> 12) & 0xF;
-    const int nb = (i < 7 + nl) ? 1 : 3;
-    const int r = (nb == 3) ? (i - 7 - nl) % 3 : 0;
+    const bool scalar = i < 7 + nl;
+    const int r = scalar ? i % 3 : (i - 7 - nl) % 3;
     const int i0 = i - r;
+    const int nb = scalar ? ((7 + nl - i0) < 3 ? (7 + nl - i0) : 3) : 3;
+    const int slot = scalar ? NCON_MAX + i / 3 : (i - 7 - nl) / 3;
     float acc[3] = {0.f, 0.f, 0.f};
     for (int cc = 0; cc < nb; cc++) {
       float a = 0.f;
@@ -323,18 +332,18 @@ MRE_DEV void assemble_constraints(const DevModel* M, Sm& s, int l) {
       acc[cc] = a;
     }
     float4 rd = s.rowdata[i];
-    if (nb == 1) {
-      rd.w = 1.0f / (acc[0] + rd.x);
-    } else {
-      const int c = (i - 7 - nl) / 3;
-      acc[r] += rd.x;
-      for (int cc = 0; cc < 3; cc++) s.Ablk[c][3 * r + cc] = acc[cc];
-      rd.w = 1.0f / acc[r];
-    }
+    const float diag = (r == 0 ? acc[0] : (r == 1 ? acc[1] : acc[2])) + rd.x;
+    if (r == 0) acc[0] = scalar ? acc[0] : diag;
+    if (r == 1) acc[1] = scalar ? acc[1] : diag;
+    if (r == 2) acc[2] = scalar ? acc[2] : diag;
+    for (int cc = 0; cc < 3; cc++) s.Ablk[slot][3 * r + cc] = acc[cc];
+    rd.w = 1.0f / diag;
     s.rowdata[i] = rd;
   }
   __syncthreads();
 }
+
+MRE_DEV float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
 // mju_QCQP2
 MRE_DEV bool qcqp2(float* res, const float* A, const float* b, float d0, float d1, float r) {
@@ -344,14 +353,14 @@ MRE_DEV bool qcqp2(float* res, const float* A, const float* b, float d0, float d
   for (int iter = 0; iter < 20; iter++) {
     const float det = (A11 + la) * (A22 + la) - A12 * A12;
     if (det < 1e-10f) { res[0] = res[1] = 0.f; return false; }
-    const float di = 1.0f / det;
+    const float di = fast_rcp(det);
     const float P11 = (A22 + la) * di, P22 = (A11 + la) * di, P12 = -A12 * di;
     v1 = -P11 * b1 - P12 * b2;
     v2 = -P12 * b1 - P22 * b2;
     const float val = v1 * v1 + v2 * v2 - r * r;
     if (val < 1e-10f) break;
     const float deriv = -2.0f * (P11 * v1 * v1 + 2.0f * P12 * v1 * v2 + P22 * v2 * v2);
-    const float delta = -val / deriv;
+    const float delta = -val * fast_rcp(deriv);
     if (delta < 1e-10f) break;
     la += delta;
   }
@@ -360,27 +369,96 @@ MRE_DEV bool qcqp2(float* res, const float* A, const float* b, float d0, float d
   return la != 0.f;
 }
 
-// per-lane J / B entry of row i for the dof this lane owns
-MRE_DEV void lane_JB(const Sm& s, int i, int l, int lp, int lk, float linvM, float& j, float& b) {
-  const int h = s.hdr[i];
-  const int rs = h & 0xFF, pa = (h >> 8) & 0xF, pb = (h >> 12) & 0xF;
+// ---------------------------------------------------------------------------
+// Solver lane layout: lanes 0..14 = robot dofs (DPP row 0), lanes 16+8p+k (k<6) =
+// dof k of cube p (one 8-lane half-row per cube).  Islands: 0 = robot, 1+p = cube p.
+MRE_DEV int lane_island(int l) { return l < 16 ? 0 : (l < 48 ? 1 + ((l - 16) >> 3) : -1); }
+MRE_DEV int lane_dof(int l) {
+  if (l < NRV) return l;
+  if (l >= 16 && l < 48 && ((l - 16) & 7) < 6) return NRV + 6 * ((l - 16) >> 3) + ((l - 16) & 7);
+  return -1;
+}
+// sum over the lanes of one island: 8-lane halves everywhere, full 16 lanes on DPP row 0
+MRE_DEV float island_sum(float v) {
+  v = dpp_add<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
+  v = dpp_add<0x141, 0xF>(v);  // row_half_mirror
+  v = dpp_add<0x140, 0x1>(v);  // row_mirror, row 0 only (robot island spans 16 lanes)
+  return v;
+}
+
+// J / B entry of row `row` for the dof this lane owns (rs = robot slot or NONE, slot = which
+// prop part of the row belongs to this lane's cube)
+MRE_DEV void lane_JB(const Sm& s, int row, int rs, int l, int lk, int slot, float linvM, float& j, float& b) {
   j = 0.f; b = 0.f;
   if (l < NRV) {
-    if (rs != HDR_NONE) { j = s.Jr[rs][l]; b = s.Br[rs][l]; }
-  } else if (l < NV) {
-    if (lp == pa) j = s.Jp[i][lk];
-    else if (lp == pb) j = s.Jp[i][6 + lk];
+    if (rs != BLK_NONE) { j = s.Jr[rs][l]; b = s.Br[rs][l]; }
+  } else if (slot >= 0) {
+    j = s.Jp[row][slot * 6 + lk];
     b = j * linvM;
   }
+}
+
+// block descriptor helpers
+MRE_DEV int blk_type(int info) { return info & 3; }
+MRE_DEV int blk_row0(int info) { return (info >> 2) & 0x7F; }
+MRE_DEV int blk_rslot(int info) { return (info >> 9) & 0x7F; }
+MRE_DEV int blk_pa(int info) { return (info >> 16) & 0xF; }
+MRE_DEV int blk_pb(int info) { return (info >> 20) & 0xF; }
+MRE_DEV int blk_primary(int info) { return (info >> 24) & 0x7; }
+MRE_DEV int blk_nrows(int info) { return (info >> 27) & 0x3; }
+
+
+// Build the block list (global MuJoCo row order) and its ASAP schedule: block b runs at
+// step 1 + max(last step of every island it touches).  Blocks of one step touch disjoint
+// islands, and any two blocks sharing an island keep their sequential order, so a sweep over
+// the schedule produces exactly the iterates of the sequential Gauss-Seidel sweep.
+MRE_DEV void build_schedule(const DevModel* M, Sm& s) {
+  int last[5] = {0, 0, 0, 0, 0};
+  const int nscalar = 7 + s.nl;
+  int nb = 0, nst = 0;
+  for (int st = 0; st < MAXBLK; st++)
+    for (int k = 0; k < 5; k++) s.sched[st][k] = -1;
+  for (int i = 0; i < nscalar; i += 3) {
+    const int nr = (nscalar - i) < 3 ? (nscalar - i) : 3;
+    s.blk_info[nb] = 0 | (i << 2) | (i << 9) | (0xF << 16) | (0xF << 20) | (0 << 24) | (nr << 27);
+    const int st = last[0]++;
+    s.sched[st][0] = nb++;
+    if (last[0] > nst) nst = last[0];
+  }
+  for (int c = 0; c < s.ncon; c++) {
+    const int pr = s.con_pair[c];
+    const int b1 = M->geom_body[M->pair_g1[pr]], b2 = M->geom_body[M->pair_g2[pr]];
+    const int rs = s.con_rslot[c];
+    int pa = 0xF, pb = 0xF;
+    if (b1 >= NRB) pa = b1 - NRB;
+    if (b2 >= NRB) { if (pa == 0xF) pa = b2 - NRB; else pb = b2 - NRB; }
+    int isl[3], ni = 0;
+    if (rs != HDR_NONE) isl[ni++] = 0;
+    if (pa != 0xF) isl[ni++] = 1 + pa;
+    if (pb != 0xF) isl[ni++] = 1 + pb;
+    int st = 0;
+    for (int k = 0; k < ni; k++) if (last[isl[k]] > st) st = last[isl[k]];
+    for (int k = 0; k < ni; k++) { last[isl[k]] = st + 1; s.sched[st][isl[k]] = nb; }
+    if (st + 1 > nst) nst = st + 1;
+    const int rsl = (rs != HDR_NONE) ? rs : BLK_NONE;
+    s.blk_info[nb++] = 2 | ((nscalar + 3 * c) << 2) | (rsl << 9) | (pa << 16) | (pb << 20) | (isl[0] << 24) | (3 << 27);
+  }
+  s.nblk = nb;
+  s.nsched = nst;
 }
 
 // ------------------------------------------------------------- mj_fwdConstraint
 // On exit: s.qacc = qacc_smooth + M^-1 J' f, s.qfrc_con = J' f.
 MRE_DEV void solve_constraints(const DevModel* M, Sm& s, int l) {
   const int nefc = s.nefc, nl = s.nl;
-  const int lp = (l >= NRV && l < NV) ? (l - NRV) / 6 : -1;
-  const int lk = (l >= NRV && l < NV) ? (l - NRV) % 6 : 0;
-  const float linvM = (lp >= 0) ? prop_invM(s, lp, lk) : 0.f;
+  const int isl = lane_island(l);
+  const int ldof = lane_dof(l);
+  const int lp = (isl > 0) ? isl - 1 : -1;
+  const int lk = (isl > 0) ? ((l - 16) & 7) : 0;
+  const bool lvalid = ldof >= 0;
+  const float linvM = (lp >= 0 && lvalid) ? prop_invM(s, lp, lk) : 0.f;
+  const bool leader = (l == 0) || (l >= 16 && l < 48 && lk == 0);
   // ---- efc_b and warm-start forces (mj_constraintUpdate on J*qacc_warmstart - aref)
   for (int i = l; i < nefc; i += 64) {
     float4 rd = s.rowdata[i];
@@ -392,8 +470,8 @@ MRE_DEV void solve_constraints(const DevModel* M, Sm& s, int l) {
   __syncthreads();
   for (int i = l; i < nefc; i += 64) {
     const float D = 1.0f / s.rowdata[i].x;
-    if (i < 7) s.rowdata[i].z = -D * s.jar[i];
-    else if (i < 7 + nl) s.rowdata[i].z = s.jar[i] < 0.f ? -D * s.jar[i] : 0.f;
+    if (i < 7) s.frc[i] = -D * s.jar[i];
+    else if (i < 7 + nl) s.frc[i] = s.jar[i] < 0.f ? -D * s.jar[i] : 0.f;
     else if ((i - 7 - nl) % 3 == 0) {
       const int c = (i - 7 - nl) / 3, pr = s.con_pair[c];
       const float fr0 = M->pair_friction[pr][0];
@@ -412,127 +490,180 @@ MRE_DEV void solve_constraints(const DevModel* M, Sm& s, int l) {
         f1 = -f0 / T * U1 * fr0;
         f2 = -f0 / T * U2 * fr0;
       }
-      s.rowdata[i].z = f0; s.rowdata[i + 1].z = f1; s.rowdata[i + 2].z = f2;
+      s.frc[i] = f0; s.frc[i + 1] = f1; s.frc[i + 2] = f2;
     }
   }
   __syncthreads();
-  // ---- a = M^-1 J' f, w = J' f for the warm start (lane = dof)
+  // ---- a = M^-1 J' f, w = J' f for the warm start (lane = dof in the solver layout)
   float a = 0.f, w = 0.f;
-  for (int i = 0; i < nefc; i++) {
-    const float fi = s.rowdata[i].z;
-    if (fi != 0.f) {
+  for (int bi = 0; bi < s.nblk; bi++) {
+    const int info = s.blk_info[bi];
+    const int row0 = blk_row0(info), rs = blk_rslot(info), nr = blk_nrows(info);
+    const int slot = (lp >= 0 && lvalid) ? (lp == blk_pa(info) ? 0 : (lp == blk_pb(info) ? 1 : -1)) : -1;
+    for (int r = 0; r < nr; r++) {
+      const float fi = s.frc[row0 + r];
       float j, b;
-      lane_JB(s, i, l, lp, lk, linvM, j, b);
+      lane_JB(s, row0 + r, rs == BLK_NONE ? BLK_NONE : rs + r, l, lk, slot, linvM, j, b);
       a += b * fi;
       w += j * fi;
     }
   }
-  if (l < NVP) s.scratch[l] = (l < NV) ? a : 0.f;
+  if (l < NVP) s.scratch[l] = 0.f;
+  __syncthreads();
+  if (lvalid) s.scratch[ldof] = a;
   __syncthreads();
   // dual cost 0.5 f'ARf + f'b ; cold start if positive
   float part = 0.f;
   for (int i = l; i < nefc; i += 64) {
     const float4 rd = s.rowdata[i];
-    const float Af = row_dot(s, i, s.scratch) + rd.x * rd.z;
-    part += rd.z * (0.5f * Af + rd.y);
+    const float fi = s.frc[i];
+    const float Af = row_dot(s, i, s.scratch) + rd.x * fi;
+    part += fi * (0.5f * Af + rd.y);
   }
   const float cost = wave_sum(part);
   __syncthreads();
   if (cost > 0.f) {
     a = 0.f; w = 0.f;
-    for (int i = l; i < nefc; i += 64) s.rowdata[i].z = 0.f;
+    for (int i = l; i < nefc; i += 64) s.frc[i] = 0.f;
   }
   __syncthreads();
-  // ---- PGS sweeps
+  // ---- PGS sweeps over the island schedule
   const int nva = NRV + 6 * s.nprops;
   float msum = M->M0_diag_robot_sum;
   for (int p = 0; p < s.nprops; p++)
     msum += 3.f * s.prop_mass[p] + s.prop_inertia[p][0] + s.prop_inertia[p][1] + s.prop_inertia[p][2];
   const float scale = 1.0f / ((msum / nva) * nva);
+  const int nsched = s.nsched, max_iter = M->iterations, nscalar = 7 + nl;
+  const float tol = M->tolerance;
   int iters = 0;
-  for (int iter = 0; iter < M->iterations; iter++) {
-    float improvement = 0.f;
-    int i = 0;
-    for (; i < 7 + nl; i++) {
-      float j, b;
-      lane_JB(s, i, l, lp, lk, linvM, j, b);
-      const float4 rd = s.rowdata[i];
-      const float res = wave_sum(j * a) + rd.x * rd.z + rd.y;
-      float fn = rd.z - res * rd.w;
-      if (i >= 7 && fn < 0.f) fn = 0.f;
-      float delta = fn - rd.z;
-      float change = delta * (0.5f * delta / rd.w + res);
-      if (change > 1e-10f) { delta = 0.f; change = 0.f; }
-      improvement -= change;
-      a += b * delta;
-      w += j * delta;
-      if (l == 0) s.rowdata[i].z = rd.z + delta;
-    }
-    for (; i < nefc; i += 3) {
-      const int c = (i - 7 - nl) / 3;
-      float j0, b0, j1, b1, j2, b2;
-      lane_JB(s, i, l, lp, lk, linvM, j0, b0);
-      lane_JB(s, i + 1, l, lp, lk, linvM, j1, b1);
-      lane_JB(s, i + 2, l, lp, lk, linvM, j2, b2);
-      const float4 r0 = s.rowdata[i], r1 = s.rowdata[i + 1], r2 = s.rowdata[i + 2];
-      float res[3];
-      res[0] = wave_sum(j0 * a) + r0.x * r0.z + r0.y;
-      res[1] = wave_sum(j1 * a) + r1.x * r1.z + r1.y;
-      res[2] = wave_sum(j2 * a) + r2.x * r2.z + r2.y;
-      float At[9];
-      for (int k = 0; k < 9; k++) At[k] = s.Ablk[c][k];
-      const float fr = M->pair_friction[s.con_pair[c]][0];
-      const float old[3] = {r0.z, r1.z, r2.z};
-      float f[3] = {old[0], old[1], old[2]};
-      if (f[0] < kMinVal) {
-        f[0] -= res[0] / At[0];
-        if (f[0] < 0.f) f[0] = 0.f;
-        f[1] = f[2] = 0.f;
-      } else {
-        float v1[3];
-        m3mulv(v1, At, f);
-        const float denom = v3dot(f, v1);
-        if (denom >= kMinVal) {
-          float x = -v3dot(f, res) / denom;
-          if (f[0] + x * f[0] < 0.f) x = -1.0f;
-          const float v[3] = {f[0], f[1], f[2]};
-          for (int k = 0; k < 3; k++) f[k] += x * v[k];
+  for (int iter = 0; iter < max_iter; iter++) {
+    float impr = 0.f;
+    for (int st = 0; st < nsched; st++) {
+      const int bid = (isl >= 0) ? s.sched[st][isl] : -1;
+      const bool on = bid >= 0;
+      const int info = on ? s.blk_info[bid] : 0;
+      const int type = blk_type(info), row0 = blk_row0(info), rs = blk_rslot(info), nr = blk_nrows(info);
+      const int pa = blk_pa(info), pb = blk_pb(info);
+      const int slot = (lp >= 0) ? (lp == pa ? 0 : 1) : -1;
+      const bool is3 = on && type == 2;
+      // partner island of a coupled contact block: a lane holding the other island's partial sums
+      int partner = l;
+      if (is3) {
+        if (isl == 0) { if (pa != 0xF) partner = 16 + 8 * pa; }
+        else if (rs != BLK_NONE) partner = 0;
+        else if (pb != 0xF) partner = 16 + 8 * (lp == pa ? pb : pa);
+      }
+      // branch-free operand fetch: every lane loads three rows through a per-lane base
+      // pointer / stride (a zero pad for lanes or rows that do not take part), then masks
+      const bool rob_lane = l < NRV, rob_row = rs != BLK_NONE;
+      const bool take = on && lvalid && (rob_lane ? rob_row : (slot >= 0));
+      const float* jptr = take ? (rob_lane ? &s.Jr[rs][l] : &s.Jp[row0][slot * 6 + lk]) : s.zpad;
+      const float* bptr = (take && rob_lane) ? &s.Br[rs][l] : s.zpad;
+      const int jstr = take ? (rob_lane ? NRV : 13) : 0;
+      const int bstr = (take && rob_lane) ? NRV : 0;
+      // (select, not multiply: rows past the block may hold stale non-finite LDS contents)
+      const bool h1 = nr > 1, h2 = nr > 2;
+      const float j0 = jptr[0], j1 = h1 ? jptr[jstr] : 0.f, j2 = h2 ? jptr[2 * jstr] : 0.f;
+      float b0 = bptr[0], b1 = h1 ? bptr[bstr] : 0.f, b2 = h2 ? bptr[2 * bstr] : 0.f;
+      if (!rob_lane) { b0 = j0 * linvM; b1 = j1 * linvM; b2 = j2 * linvM; }
+      const int ra = row0, rb = (nr > 1) ? row0 + 1 : row0, rc = (nr > 2) ? row0 + 2 : row0;
+      const float4 r0 = s.rowdata[ra], r1 = s.rowdata[rb], r2 = s.rowdata[rc];
+      const float f0 = s.frc[ra], f1 = h1 ? s.frc[rb] : 0.f, f2 = h2 ? s.frc[rc] : 0.f;
+      float p0 = island_sum(j0 * a), p1 = island_sum(j1 * a), p2 = island_sum(j2 * a);
+      if (__any(partner != l)) {
+        const float q0 = __shfl(p0, partner, 64), q1 = __shfl(p1, partner, 64), q2 = __shfl(p2, partner, 64);
+        if (partner != l) { p0 += q0; p1 += q1; p2 += q2; }
+      }
+      float d0 = 0.f, d1 = 0.f, d2 = 0.f, change = 0.f;
+      if (on) {
+        const int aslot = is3 ? (row0 - nscalar) / 3 : NCON_MAX + row0 / 3;
+        const float* At = s.Ablk[aslot];
+        const float A00 = At[0], A01 = At[1], A02 = At[2], A10 = At[3], A11 = At[4], A12 = At[5],
+                    A20 = At[6], A21 = At[7], A22 = At[8];
+        const float res0 = p0 + r0.x * f0 + r0.y, res1 = p1 + r1.x * f1 + r1.y, res2 = p2 + r2.x * f2 + r2.y;
+        if (!is3) {
+          // up to three sequential scalar updates; cross terms through the block's A entries
+          float fn = f0 - res0 * r0.w;
+          if (row0 >= 7 && fn < 0.f) fn = 0.f;
+          d0 = fn - f0;
+          float ch = d0 * (0.5f * d0 * (A00 + r0.x) + res0);
+          if (ch > 1e-10f) { d0 = 0.f; ch = 0.f; }
+          change = ch;
+          if (nr > 1) {
+            const float rs1 = res1 + A10 * d0;
+            fn = f1 - rs1 * r1.w;
+            if (row0 + 1 >= 7 && fn < 0.f) fn = 0.f;
+            d1 = fn - f1;
+            ch = d1 * (0.5f * d1 * (A11 + r1.x) + rs1);
+            if (ch > 1e-10f) { d1 = 0.f; ch = 0.f; }
+            change += ch;
+          }
+          if (nr > 2) {
+            const float rs2 = res2 + A20 * d0 + A21 * d1;
+            fn = f2 - rs2 * r2.w;
+            if (row0 + 2 >= 7 && fn < 0.f) fn = 0.f;
+            d2 = fn - f2;
+            ch = d2 * (0.5f * d2 * (A22 + r2.x) + rs2);
+            if (ch > 1e-10f) { d2 = 0.f; ch = 0.f; }
+            change += ch;
+          }
+        } else {
+          const float fr = s.con_fric[aslot];
+          float n0 = f0, n1 = f1, n2 = f2;
+          if (n0 < kMinVal) {
+            n0 -= res0 * fast_rcp(A00);
+            if (n0 < 0.f) n0 = 0.f;
+            n1 = n2 = 0.f;
+          } else {
+            const float v0 = A00 * n0 + A01 * n1 + A02 * n2, v1 = A10 * n0 + A11 * n1 + A12 * n2,
+                        v2 = A20 * n0 + A21 * n1 + A22 * n2;
+            const float denom = n0 * v0 + n1 * v1 + n2 * v2;
+            if (denom >= kMinVal) {
+              float x = -(n0 * res0 + n1 * res1 + n2 * res2) * fast_rcp(denom);
+              if (n0 + x * n0 < 0.f) x = -1.0f;
+              n0 += x * f0; n1 += x * f1; n2 += x * f2;
+            }
+          }
+          const float Ac[4] = {A11, A12, A21, A22};
+          float bc[2];
+          bc[0] = res1 - A11 * f1 - A12 * f2 + A10 * (n0 - f0);
+          bc[1] = res2 - A21 * f1 - A22 * f2 + A20 * (n0 - f0);
+          if (n0 < kMinVal) {
+            n1 = n2 = 0.f;
+          } else {
+            float v[2];
+            const bool active = qcqp2(v, Ac, bc, fr, fr, n0);
+            if (active) {
+              float sq = (v[0] * v[0] + v[1] * v[1]) * fast_rcp(fr * fr);
+              sq = sqrtf(n0 * n0 * fast_rcp(fmaxf(sq, kMinVal)));
+              v[0] *= sq; v[1] *= sq;
+            }
+            n1 = v[0]; n2 = v[1];
+          }
+          d0 = n0 - f0; d1 = n1 - f1; d2 = n2 - f2;
+          const float Ad0 = A00 * d0 + A01 * d1 + A02 * d2, Ad1 = A10 * d0 + A11 * d1 + A12 * d2,
+                      Ad2 = A20 * d0 + A21 * d1 + A22 * d2;
+          change = 0.5f * (d0 * Ad0 + d1 * Ad1 + d2 * Ad2) + d0 * res0 + d1 * res1 + d2 * res2;
+          if (change > 1e-10f) { d0 = d1 = d2 = 0.f; change = 0.f; }
+        }
+        if (isl == blk_primary(info)) impr -= change;
+        if (leader) {
+          s.frc[row0] = f0 + d0;
+          if (nr > 1) s.frc[row0 + 1] = f1 + d1;
+          if (nr > 2) s.frc[row0 + 2] = f2 + d2;
         }
       }
-      const float Ac[4] = {At[4], At[5], At[7], At[8]};
-      float bc[2];
-      for (int k = 0; k < 2; k++) {
-        bc[k] = res[1 + k] - Ac[2 * k] * old[1] - Ac[2 * k + 1] * old[2] + At[3 * (k + 1)] * (f[0] - old[0]);
-      }
-      if (f[0] < kMinVal) {
-        f[1] = f[2] = 0.f;
-      } else {
-        float v[2];
-        const bool active = qcqp2(v, Ac, bc, fr, fr, f[0]);
-        if (active) {
-          float sq = (v[0] / fr) * (v[0] / fr) + (v[1] / fr) * (v[1] / fr);
-          sq = sqrtf(f[0] * f[0] / fmaxf(sq, kMinVal));
-          v[0] *= sq; v[1] *= sq;
-        }
-        f[1] = v[0]; f[2] = v[1];
-      }
-      float d[3] = {f[0] - old[0], f[1] - old[1], f[2] - old[2]}, Ad[3];
-      m3mulv(Ad, At, d);
-      float change = 0.5f * v3dot(d, Ad) + v3dot(d, res);
-      if (change > 1e-10f) { d[0] = d[1] = d[2] = 0.f; change = 0.f; }
-      improvement -= change;
-      a += b0 * d[0] + b1 * d[1] + b2 * d[2];
-      w += j0 * d[0] + j1 * d[1] + j2 * d[2];
-      if (l < 3) s.rowdata[i + l].z = old[l] + d[l];
+      a += b0 * d0 + b1 * d1 + b2 * d2;
+      w += j0 * d0 + j1 * d1 + j2 * d2;
+      __syncthreads();
     }
     iters = iter + 1;
-    __syncthreads();
-    if (improvement * scale < M->tolerance) break;
+    const float improvement = wave_sum(leader ? impr : 0.f);
+    if (improvement * scale < tol) break;
   }
-  if (l < NVP) {
-    s.qacc[l] = (l < NV) ? s.qacc_smooth[l] + a : 0.f;
-    s.qfrc_con[l] = (l < NV) ? w : 0.f;
-  }
+  if (l < NVP) { s.qacc[l] = (l < NV) ? s.qacc_smooth[l] : 0.f; s.qfrc_con[l] = 0.f; }
+  __syncthreads();
+  if (lvalid) { s.qacc[ldof] += a; s.qfrc_con[ldof] = w; }
   if (l == 0) s.solver_iters = iters;
   __syncthreads();
 }
