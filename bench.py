@@ -42,14 +42,11 @@ def algorithmic_bytes_per_env_step(nprops: np.ndarray) -> float:
 def setup_envs(phys, seed, env_ids, settle_steps=300):
     from mujoco_robot_environments_amd import placement, rng
     nprops, sizes = rng.prop_params(seed, env_ids)
+    phys.set_env_id_offset(int(env_ids[0]))
     phys.set_props(nprops, sizes)
     phys.reset()
-    pose, ok = placement.sample_poses(seed, env_ids, nprops, sizes, WS_MIN, WS_MAX)
-    assert ok.all(), "cube placement failed"
-    qp = placement.write_poses(phys.qpos(), pose, nprops)
-    phys.set_state(qp, np.zeros((len(env_ids), 39), np.float32))
-    phys.step(settle_steps, flags=2)  # settle with the robot frozen (prop_initializer.py:240-258)
-    phys.sync()
+    # PropPlacer: rejection sampling + settle with the robot frozen (prop_initializer.py:164-283)
+    phys.place_props(seed, WS_MIN, WS_MAX, settle_steps=settle_steps)
     return nprops, sizes
 
 

@@ -77,6 +77,9 @@ int mre_reset(mre_env*, const uint8_t* mask);
  * sampling of cube poses in the workspace + settle with the robot frozen. */
 int mre_place_props(mre_env*, const uint8_t* mask, uint64_t seed, const float* ws_min,
                     const float* ws_max, int max_attempts, int settle_steps);
+/* global id of env 0 of this handle (rank r of a sharded batch: r * num_envs); random
+ * draws are keyed by global id so results do not depend on the sharding */
+int mre_set_env_id_offset(mre_env*, long long offset);
 
 /* physics.bind(joints).qpos / .qvel access: rows [N][MRE_NQ_PAD] / [N][MRE_NV_PAD] */
 int mre_set_state(mre_env*, const float* qpos, const float* qvel);

@@ -20,8 +20,6 @@ extern "C" void mre_launch_step(const StepArgs* args, hipStream_t stream);
 extern "C" void mre_launch_reset(const DevModel* M, int N, float* qpos, float* qvel, float* qacc_ws,
                                  float* ctrl, uint32_t* status, const uint8_t* mask,
                                  hipStream_t stream);
-extern "C" void mre_launch_place(const StepArgs* args, const uint8_t* mask, uint64_t seed,
-                                 const float* ws, int max_attempts, hipStream_t stream);
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) {
@@ -53,6 +51,7 @@ struct mre_env {
   OscConfig osc;
   float* trace = nullptr;
   int trace_nenv = 0, trace_max = 0, trace_pos = 0;
+  long long env_id_offset = 0;
   bool profiling = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
   size_t events_used = 0;
@@ -518,24 +517,100 @@ extern "C" int mre_run_controller(mre_env* e, int nticks, int control_steps, uin
   return MRE_OK;
 }
 
+// ---- PropPlacer.__call__ (environment/prop_initializer.py:164-283), batched.
+// Same counter-based stream and rejection rule as mujoco_robot_environments_amd/placement.py
+// (splitmix64 keyed by (seed, GLOBAL env id, attempt, channel)): sample position ~ U(workspace),
+// yaw = pi*U(0,1); reject while another placed cube is closer than the 0.15 m contact margin
+// (bounding-sphere form of "any non-table contact detected"); envs whose scene cannot be
+// completed re-draw it in a further round.  Then settle on the GPU with the robot frozen.
+namespace {
+inline uint64_t mix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+inline double uniform01(uint64_t seed, uint64_t env, uint64_t tick, uint64_t ch) {
+  uint64_t k = mix64(seed + 0x9E3779B97F4A7C15ull * env);
+  k = mix64(k ^ (tick * 0xBF58476D1CE4E5B9ull));
+  k = mix64(k ^ (ch * 0x94D049BB133111EBull));
+  return (double)(k >> 11) * (1.0 / 9007199254740992.0);
+}
+}  // namespace
+
 extern "C" int mre_place_props(mre_env* e, const uint8_t* mask, uint64_t seed, const float* ws_min,
                                const float* ws_max, int max_attempts, int settle_steps) {
-  if (!e || !ws_min || !ws_max) return fail(MRE_ERR_ARG, "mre_place_props: null");
-  const uint8_t* dmask;
-  int rc = stage_mask(e, mask, &dmask);
+  if (!e || !ws_min || !ws_max || max_attempts < 1) return fail(MRE_ERR_ARG, "mre_place_props: bad argument");
+  const size_t N = (size_t)e->N;
+  std::vector<uint8_t> hm(N, 1);
+  int rc;
+  if (mask) { rc = copy_out(e, hm.data(), mask, N); if (rc) return rc; }
+  std::vector<int> np(N);
+  std::vector<float> ps(N * NPROP * 3), qp(N * NQP);
+  if ((rc = copy_out(e, np.data(), e->nprops, N * 4)) || (rc = copy_out(e, ps.data(), e->prop_size, ps.size() * 4)) ||
+      (rc = copy_out(e, qp.data(), e->qpos, qp.size() * 4)))
+    return rc;
+  const double kPi = 3.14159265358979323846, margin = 0.15;
+  double lo[3], hi[3];
+  for (int k = 0; k < 3; k++) { lo[k] = ws_min[k]; hi[k] = ws_max[k]; }
+  for (size_t i = 0; i < N; i++) {
+    if (!hm[i]) continue;
+    const uint64_t gid = (uint64_t)(e->env_id_offset + (long long)i);
+    double rb[NPROP], pose[NPROP][7];
+    for (int p = 0; p < NPROP; p++) {
+      const float* z = &ps[(i * NPROP + p) * 3];
+      rb[p] = std::sqrt((double)z[0] * z[0] + (double)z[1] * z[1] + (double)z[2] * z[2]);
+    }
+    bool ok = false;
+    for (int rnd = 0; rnd < 50 && !ok; rnd++) {
+      const uint64_t sr = seed + 7919ull * (uint64_t)rnd;
+      ok = true;
+      for (int p = 0; p < np[i] && ok; p++) {
+        bool placed = false;
+        for (int att = 0; att < max_attempts && !placed; att++) {
+          const uint64_t tick = (uint64_t)p * (uint64_t)max_attempts + (uint64_t)att;
+          double u[4];
+          for (int c = 0; c < 4; c++) u[c] = uniform01(sr, gid, tick, (uint64_t)c);
+          double pos[3];
+          for (int k = 0; k < 3; k++) pos[k] = lo[k] + (hi[k] - lo[k]) * u[k];
+          bool good = true;
+          for (int o = 0; o < p && good; o++) {
+            const double dx = pos[0] - pose[o][0], dy = pos[1] - pose[o][1], dz = pos[2] - pose[o][2];
+            if (std::sqrt(dx * dx + dy * dy + dz * dz) <= rb[p] + rb[o] + margin) good = false;
+          }
+          if (!good) continue;
+          const double yaw = kPi * u[3];
+          pose[p][0] = pos[0]; pose[p][1] = pos[1]; pose[p][2] = pos[2];
+          pose[p][3] = std::cos(yaw / 2); pose[p][4] = 0; pose[p][5] = 0; pose[p][6] = std::sin(yaw / 2);
+          placed = true;
+        }
+        if (!placed) ok = false;
+      }
+    }
+    if (!ok) return fail(MRE_ERR_ARG, "mre_place_props: failed to find a non-colliding pose (workspace too small)");
+    for (int p = 0; p < np[i]; p++)
+      for (int k = 0; k < 7; k++) qp[i * NQP + NRV + 7 * p + k] = (float)pose[p][k];
+  }
+  rc = copy_in(e, e->qpos, qp.data(), qp.size() * 4);
   if (rc) return rc;
-  float ws[6] = {ws_min[0], ws_min[1], ws_min[2], ws_max[0], ws_max[1], ws_max[2]};
-  StepArgs a;
-  fill_args(e, a);
-  a.trace = nullptr;
-  mre_launch_place(&a, dmask, seed, ws, max_attempts, e->stream);
-  HIPCHK(hipGetLastError());
-  // settle with the robot frozen (JointStaticIsolator); fixed count keeps envs in lockstep
+  HIPCHK(hipStreamSynchronize(e->stream));
   if (settle_steps > 0) {
-    a.nsteps = settle_steps; a.flags = F_FREEZE_ROBOT;
+    const uint8_t* dmask = nullptr;
+    if (mask) { rc = copy_in(e, e->mask, hm.data(), N); if (rc) return rc; dmask = e->mask; }
+    StepArgs a;
+    fill_args(e, a);
+    a.trace = nullptr;
+    a.nsteps = settle_steps; a.flags = F_FREEZE_ROBOT; a.env_mask = dmask;
     mre_launch_step(&a, e->stream);
     HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(e->stream));
   }
+  return MRE_OK;
+}
+
+extern "C" int mre_set_env_id_offset(mre_env* e, long long offset) {
+  if (!e) return fail(MRE_ERR_ARG, "null handle");
+  e->env_id_offset = offset;
   return MRE_OK;
 }
 

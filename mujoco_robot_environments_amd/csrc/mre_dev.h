@@ -107,6 +107,7 @@ struct StepArgs {
   int* stats;                // [N][4]
   float* trace;              // [max_steps][trace_nenv][NQP] or null
   int trace_nenv, trace_max, trace_base;
+  const uint8_t* env_mask;   // [N] or null: envs with 0 are skipped by this launch
 };
 
 }  // namespace mre

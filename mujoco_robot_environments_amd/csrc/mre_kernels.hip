@@ -430,6 +430,7 @@ __global__ __launch_bounds__(64) void k_step(StepArgs a) {
   const int env = blockIdx.x;
   const int l = threadIdx.x;
   if (env >= a.N) return;
+  if (a.env_mask != nullptr && a.env_mask[env] == 0) return;
   const DevModel* M = a.M;
 
   // ---- load state (one coalesced row per array)
@@ -578,11 +579,6 @@ __global__ __launch_bounds__(64) void k_reset(const DevModel* M, int N, float* q
 extern "C" void mre_launch_reset(const mre::DevModel* M, int N, float* qpos, float* qvel, float* qacc_ws,
                                  float* ctrl, uint32_t* status, const uint8_t* mask, hipStream_t stream) {
   hipLaunchKernelGGL(mre::k_reset, dim3(N), dim3(64), 0, stream, M, N, qpos, qvel, qacc_ws, ctrl, status, mask);
-}
-
-extern "C" void mre_launch_place(const mre::StepArgs* args, const uint8_t* mask, uint64_t seed,
-                                 const float* ws, int max_attempts, hipStream_t stream) {
-  (void)args; (void)mask; (void)seed; (void)ws; (void)max_attempts; (void)stream;
 }
 
 extern "C" void mre_launch_step(const mre::StepArgs* args, hipStream_t stream) {

@@ -84,6 +84,9 @@ class BatchedPhysics:
         check(_lib.lib().mre_reset(self._h, _ptr(m)), "mre_reset")
         self.sync()
 
+    def set_env_id_offset(self, offset: int) -> None:
+        check(_lib.lib().mre_set_env_id_offset(self._h, int(offset)), "mre_set_env_id_offset")
+
     def place_props(self, seed: int, ws_min, ws_max, mask=None, max_attempts: int = 1000,
                     settle_steps: int = 300) -> None:
         m = None if mask is None else np.ascontiguousarray(mask, np.uint8)

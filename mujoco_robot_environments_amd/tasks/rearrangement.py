@@ -153,16 +153,15 @@ class BatchedRearrangementEnv:
         (tasks/rearrangement.py:297-337)."""
         ws = self._cfg.task.initializers.workspace
         self._physics.reset()
-        pose, ok = placement.sample_poses(self.seed + 104729 * self._reset_count, self.env_ids, self.nprops,
-                                          self.prop_half_size, ws.min_pose, ws.max_pose)
-        if not ok.all():
-            raise RuntimeError("Failed to find a non-colliding pose for some props")
-        self._reset_count += 1
-        qp = placement.write_poses(self._physics.qpos(), pose, self.nprops)
-        self._physics.set_state(qp, np.zeros((self.num_envs, 39), np.float32))
+        self._physics.set_env_id_offset(int(self.env_ids[0]))
         # settle with the robot frozen: >= 0.3 s, <= 2 s, until max|qvel| of the cubes < 1e-3
         steps, done = 300, False
-        self._physics.step(steps, flags=2)
+        try:
+            self._physics.place_props(self.seed + 104729 * self._reset_count, ws.min_pose, ws.max_pose,
+                                      settle_steps=steps)
+        except Exception as e:  # reference: RuntimeError(_REJECTION_SAMPLING_FAILED)
+            raise RuntimeError("Failed to find a non-colliding pose for some props") from e
+        self._reset_count += 1
         while not done and steps < 2000:
             qv = self._physics.qvel()[:, 15:]
             done = bool(np.abs(qv).max() < 1e-3)

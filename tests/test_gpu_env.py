@@ -46,7 +46,8 @@ def test_batched_scripted_pick_runs_all_phases():
                    "gripper_rot": 0.0})
     assert ts.step_type == StepType.MID and env.mode == "place"
     assert np.allclose(p[:, 2], 0.575), "pick() overwrites pose[2] in place (reference :362)"
-    assert abs(env._robot.time - (env._robot.time // 0.001) * 0.001) < 1e-6
+    nsteps = round(env._robot.time / 0.001)
+    assert 300 + 9000 <= nsteps <= 2000 + 9000 + 25, "settle (0.3..2 s) + five phases of 2+2+1+2+2 s"
     assert env.last_converged.all(), list(env.failed_phase)
     tcp, eef, props = env.physics.sites()
     # reference quirk: eef_home_pose is read from the PINCH site but used as target of the
@@ -56,3 +57,40 @@ def test_batched_scripted_pick_runs_all_phases():
     lifted = [(props[i, :int(env.nprops[i]), 2] > 0.5).any() for i in range(N)]
     print("cubes held after pick:", sum(lifted), "/", N)
     env.close()
+
+
+def test_place_props_matches_host_sampler_and_respects_mask(compiled_model):
+    """mre_place_props = PropPlacer: same counter-RNG rejection sampling as placement.py,
+    then settle with the robot frozen; a mask restricts it to the envs being reset."""
+    from mujoco_robot_environments_amd import placement, rng
+    from mujoco_robot_environments_amd.physics import BatchedPhysics
+    A, _ = compiled_model
+    N, off, seed = 64, 4096, 5
+    ids = np.arange(off, off + N)
+    nprops, sizes = rng.prop_params(seed, ids)
+    sizes = sizes.astype(np.float32).astype(np.float64)
+    lo = np.array([0.35, -0.4, 0.43], np.float32)
+    hi = np.array([0.55, 0.4, 0.435], np.float32)
+    phys = BatchedPhysics(N, model=A)
+    phys.set_env_id_offset(off)
+    phys.set_props(nprops, sizes)
+    phys.reset()
+    phys.place_props(seed, lo, hi, settle_steps=0)
+    pose, ok = placement.sample_poses(seed, ids, nprops, sizes, lo.astype(np.float64), hi.astype(np.float64))
+    assert ok.all()
+    q = phys.qpos()
+    for i in range(N):
+        n = int(nprops[i])
+        assert np.abs(q[i, 15:15 + 7 * n].reshape(n, 7) - pose[i, :n]).max() < 1e-6
+    # settle only the even envs
+    mask = (np.arange(N) % 2 == 0).astype(np.uint8)
+    before = phys.qpos().copy()
+    phys.place_props(seed + 1, lo, hi, mask=mask, settle_steps=400)
+    after = phys.qpos()
+    assert np.array_equal(after[mask == 0], before[mask == 0]), "unmasked envs must not move"
+    for i in np.nonzero(mask)[0]:
+        n = int(nprops[i])
+        z = after[i, 15:15 + 7 * n].reshape(n, 7)[:, 2]
+        assert np.abs(z - (0.4 + sizes[i, :n, 2])).max() < 1e-3, "cubes rest on the table top"
+    assert np.abs(phys.qvel()[mask == 1][:, 15:]).max() < 5e-2
+    assert (phys.status() == 0).all()
