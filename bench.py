@@ -39,6 +39,19 @@ def algorithmic_bytes_per_env_step(nprops: np.ndarray) -> float:
     return float(np.mean(4.0 * (2 * (15 + 7 * n) + 4 * (15 + 6 * n) + 8)))
 
 
+def pmc_traffic():
+    """HBM bytes per launch from the latest committed PMC pass (profiles/*_pmc_summary.json:
+    separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same bench command); the
+    counters cannot be read from inside the process, so the figure is carried over."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
+    if not files:
+        return None, None
+    with open(files[-1]) as f:
+        d = json.load(f)
+    return d.get("traffic_bytes_per_launch"), os.path.basename(files[-1])
+
+
 def setup_envs(phys, seed, env_ids, settle_steps=300):
     from mujoco_robot_environments_amd import placement, rng
     nprops, sizes = rng.prop_params(seed, env_ids)
@@ -179,7 +192,8 @@ def main():
         "control_ticks_per_s": value / CONTROL_STEPS,
         "pick_place_macro_steps_per_s": value / 18000.0,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic()[0] if F == 1 else None,
+                     "traffic_source": pmc_traffic()[1],
                      "kernel": "mre::k_step", "avg_launch_ms": avg_launch_s * 1e3, "launches": launches,
                      "algorithmic_bytes_per_launch": bytes_per_launch,
                      "note": "path is dependency/latency bound (tree depth, PGS sweeps), not HBM bound"},
