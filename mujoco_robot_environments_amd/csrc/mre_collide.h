@@ -1,178 +1,220 @@
 // mre_collide.h -- per-lane narrow phase (box-box, plane-box), fp32.
-// One lane owns one collision pair; all scratch is lane-private.
+// One lane owns one collision pair.  No private-memory arrays with runtime indices:
+// the clip polygons live in a per-lane LDS buffer (56 floats, aliased by the caller
+// on the Jacobian pools that are not in use yet) and small vectors are picked with
+// select chains, so the kernel needs no scratch memory.
 // Box-box: separating-axis test over 15 axes (faces preferred over edges by a
 // 5 % fudge), face contact = incident face clipped against the reference face
 // (Sutherland-Hodgman, <= 8 points), edge contact = closest points of the two
 // supporting edges.  Contact position is midway between the surfaces, normal
 // points from geom1 to geom2, dist < 0 is penetration (MuJoCo conventions).
+// Output: candidates cand[k] = {x, y, z, dist}, k < n, in the lane's LDS buffer.
 #pragma once
 #include "mre_math.h"
 
 namespace mre {
 
-struct PairContacts {
-  int n;
-  float normal[3];
-  float pos[8][3];
-  float dist[8];
-};
+constexpr int COLL_BUF = 56;   // floats per lane: poly[8][3] | q[8][3] -> cand[8][4]
 
-// clip polygon (x, y, depth) against |x| <= sx, |y| <= sy; in/out p, returns count
-MRE_DEV int clip_poly(float (*p)[3], int n, float sx, float sy) {
-  float q[16][3];
+// runtime pick of one of three values by arithmetic masks (a select chain over a local
+// array is turned back into an indexed stack access by the compiler -> scratch memory)
+MRE_DEV float sel3(const float* v, int i) {
+  const float w0 = i == 0 ? 1.f : 0.f, w1 = i == 1 ? 1.f : 0.f, w2 = i == 2 ? 1.f : 0.f;
+  return w0 * v[0] + w1 * v[1] + w2 * v[2];
+}
+MRE_DEV void row3(float* o, const float (*m)[3], int i) {
+  const float w0 = i == 0 ? 1.f : 0.f, w1 = i == 1 ? 1.f : 0.f, w2 = i == 2 ? 1.f : 0.f;
+  o[0] = w0 * m[0][0] + w1 * m[1][0] + w2 * m[2][0];
+  o[1] = w0 * m[0][1] + w1 * m[1][1] + w2 * m[2][1];
+  o[2] = w0 * m[0][2] + w1 * m[1][2] + w2 * m[2][2];
+}
+
+// clip polygon p (x, y, depth) against |x| <= sx, |y| <= sy using q as the second buffer;
+// result ends in p.  p, q are LDS pointers private to this lane.
+MRE_DEV int clip_poly(float* p, float* q, int n, float sx, float sy) {
   for (int e = 0; e < 4; e++) {
     const int ax = e >> 1;
     const float sg = (e & 1) ? -1.0f : 1.0f;
     const float lim = ax ? sy : sx;
     int nq = 0;
     for (int i = 0; i < n; i++) {
-      const float* a = p[i];
-      const float* b = p[(i + 1) % n];
-      const float da = sg * a[ax] - lim, db = sg * b[ax] - lim;
-      if (da <= 0) { q[nq][0] = a[0]; q[nq][1] = a[1]; q[nq][2] = a[2]; nq++; }
-      if ((da <= 0) != (db <= 0)) {
+      const int i2 = (i + 1 == n) ? 0 : i + 1;
+      const float a0 = p[3 * i], a1 = p[3 * i + 1], a2 = p[3 * i + 2];
+      const float b0 = p[3 * i2], b1 = p[3 * i2 + 1], b2 = p[3 * i2 + 2];
+      const float da = sg * (ax ? a1 : a0) - lim, db = sg * (ax ? b1 : b0) - lim;
+      if (da <= 0 && nq < 8) { q[3 * nq] = a0; q[3 * nq + 1] = a1; q[3 * nq + 2] = a2; nq++; }
+      if ((da <= 0) != (db <= 0) && nq < 8) {
         const float t = da / (da - db);
-        for (int k = 0; k < 3; k++) q[nq][k] = a[k] + t * (b[k] - a[k]);
+        q[3 * nq] = a0 + t * (b0 - a0); q[3 * nq + 1] = a1 + t * (b1 - a1); q[3 * nq + 2] = a2 + t * (b2 - a2);
         nq++;
       }
-      if (nq >= 15) break;
     }
     n = nq;
-    for (int i = 0; i < n; i++) { p[i][0] = q[i][0]; p[i][1] = q[i][1]; p[i][2] = q[i][2]; }
+    for (int i = 0; i < 3 * n; i++) p[i] = q[i];
     if (n == 0) return 0;
   }
   return n;
 }
 
-// R1/R2: 3x3 row-major geom frames (columns = box axes)
-MRE_DEV void box_box(const float* p1, const float* R1, const float* s1, const float* p2,
-                     const float* R2, const float* s2, float margin, PairContacts& out) {
-  out.n = 0;
+// R1/R2: 3x3 row-major geom frames (columns = box axes); buf: this lane's LDS buffer.
+// Returns the number of candidates written to cand = buf + 24 ({x,y,z,dist} each).
+MRE_DEV int box_box(const float* p1, const float* R1, const float* s1, const float* p2,
+                    const float* R2, const float* s2, float margin, float* normal, float* buf) {
+  float* poly = buf;
+  float* cand = buf + 24;
   float A[3][3], B[3][3], dv[3], Cm[3][3], aC[3][3];
+#pragma unroll
   for (int i = 0; i < 3; i++)
+#pragma unroll
     for (int k = 0; k < 3; k++) { A[i][k] = R1[3 * k + i]; B[i][k] = R2[3 * k + i]; }
   v3sub(dv, p2, p1);
+#pragma unroll
   for (int i = 0; i < 3; i++)
+#pragma unroll
     for (int j = 0; j < 3; j++) { Cm[i][j] = v3dot(A[i], B[j]); aC[i][j] = fabsf(Cm[i][j]); }
   float tA[3], tB[3];
+#pragma unroll
   for (int i = 0; i < 3; i++) { tA[i] = v3dot(dv, A[i]); tB[i] = v3dot(dv, B[i]); }
   float best_face = -1e30f;
   int face_code = -1;
+#pragma unroll
   for (int i = 0; i < 3; i++) {
     const float sep = fabsf(tA[i]) - (s1[i] + s2[0] * aC[i][0] + s2[1] * aC[i][1] + s2[2] * aC[i][2]);
     if (sep > best_face) { best_face = sep; face_code = i; }
   }
+#pragma unroll
   for (int j = 0; j < 3; j++) {
     const float sep = fabsf(tB[j]) - (s2[j] + s1[0] * aC[0][j] + s1[1] * aC[1][j] + s1[2] * aC[2][j]);
     if (sep > best_face) { best_face = sep; face_code = 3 + j; }
   }
-  if (best_face > margin) return;
+  if (best_face > margin) return 0;
   float best_edge = -1e30f;
   int ei = -1, ej = -1;
   float en[3] = {0.f, 0.f, 0.f};
+  bool separated = false;
+#pragma unroll
   for (int i = 0; i < 3; i++)
+#pragma unroll
     for (int j = 0; j < 3; j++) {
       float L[3];
       v3cross(L, A[i], B[j]);
       const float len = v3norm(L);
-      if (len < 1e-6f) continue;
-      const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
-      const float rA = s1[i1] * aC[i2][j] + s1[i2] * aC[i1][j];
-      const float rB = s2[j1] * aC[i][j2] + s2[j2] * aC[i][j1];
-      const float t = v3dot(dv, L);
-      const float sep = (fabsf(t) - rA - rB) / len;
-      if (sep > margin) return;
-      if (sep > best_edge) {
-        best_edge = sep; ei = i; ej = j;
-        const float sg = (t >= 0 ? 1.0f : -1.0f) / len;
-        en[0] = L[0] * sg; en[1] = L[1] * sg; en[2] = L[2] * sg;
+      if (len >= 1e-6f) {
+        const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+        const float rA = s1[i1] * aC[i2][j] + s1[i2] * aC[i1][j];
+        const float rB = s2[j1] * aC[i][j2] + s2[j2] * aC[i][j1];
+        const float t = v3dot(dv, L);
+        const float sep = (fabsf(t) - rA - rB) / len;
+        if (sep > margin) separated = true;
+        if (sep > best_edge) {
+          best_edge = sep; ei = i; ej = j;
+          const float sg = (t >= 0 ? 1.0f : -1.0f) / len;
+          en[0] = L[0] * sg; en[1] = L[1] * sg; en[2] = L[2] * sg;
+        }
       }
     }
+  if (separated) return 0;
   const bool use_edge = (ei >= 0) && (best_edge - best_face > 0.05f * fabsf(best_face) + 1e-7f);
   if (use_edge) {
     float c1[3], c2[3];
     v3copy(c1, p1);
     v3copy(c2, p2);
+#pragma unroll
     for (int k = 0; k < 3; k++) {
       if (k != ei) v3addscl(c1, A[k], (v3dot(en, A[k]) >= 0 ? 1.0f : -1.0f) * s1[k]);
       if (k != ej) v3addscl(c2, B[k], (v3dot(en, B[k]) >= 0 ? -1.0f : 1.0f) * s2[k]);
     }
-    float w[3];
+    float Ae[3], Be[3], w[3];
+    row3(Ae, A, ei);
+    row3(Be, B, ej);
     v3sub(w, c1, c2);
-    const float uv = Cm[ei][ej], uw = v3dot(A[ei], w), vw = v3dot(B[ej], w);
+    const float uv = v3dot(Ae, Be), uw = v3dot(Ae, w), vw = v3dot(Be, w);
     const float den = 1.0f - uv * uv;
     float a = 0.f, bb = 0.f;
     if (den > 1e-12f) { a = (uv * vw - uw) / den; bb = (vw - uv * uw) / den; }
     float q1[3], q2[3], df[3];
-    v3copy(q1, c1); v3addscl(q1, A[ei], a);
-    v3copy(q2, c2); v3addscl(q2, B[ej], bb);
-    v3copy(out.normal, en);
-    for (int k = 0; k < 3; k++) out.pos[0][k] = 0.5f * (q1[k] + q2[k]);
+    v3copy(q1, c1); v3addscl(q1, Ae, a);
+    v3copy(q2, c2); v3addscl(q2, Be, bb);
+    v3copy(normal, en);
     v3sub(df, q2, q1);
-    out.dist[0] = v3dot(df, en);
-    out.n = out.dist[0] <= margin ? 1 : 0;
-    return;
+    const float d = v3dot(df, en);
+    cand[0] = 0.5f * (q1[0] + q2[0]); cand[1] = 0.5f * (q1[1] + q2[1]); cand[2] = 0.5f * (q1[2] + q2[2]);
+    cand[3] = d;
+    return d <= margin ? 1 : 0;
   }
-  const float *pr, *pi, *sr, *si;
-  float (*Ar)[3];
-  float (*Ai)[3];
-  int a;
-  float nr[3];
-  if (face_code < 3) {
-    a = face_code; pr = p1; pi = p2; sr = s1; si = s2; Ar = A; Ai = B;
-    const float sg = tA[a] >= 0 ? 1.0f : -1.0f;
-    for (int k = 0; k < 3; k++) { nr[k] = A[a][k] * sg; out.normal[k] = nr[k]; }
-  } else {
-    a = face_code - 3; pr = p2; pi = p1; sr = s2; si = s1; Ar = B; Ai = A;
-    const float sg = tB[a] >= 0 ? -1.0f : 1.0f;
-    for (int k = 0; k < 3; k++) { nr[k] = B[a][k] * sg; out.normal[k] = -nr[k]; }
+  // face contact: the reference box owns the separating face
+  const bool ref1 = face_code < 3;
+  const int a = ref1 ? face_code : face_code - 3;
+  float pr[3], pi[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) { pr[k] = ref1 ? p1[k] : p2[k]; pi[k] = ref1 ? p2[k] : p1[k]; }
+  float Ar[3][3], Ai[3][3], srv3[3], siv3[3];  // element-wise selects keep everything in registers
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) { Ar[i][k] = ref1 ? A[i][k] : B[i][k]; Ai[i][k] = ref1 ? B[i][k] : A[i][k]; }
+    srv3[i] = ref1 ? s1[i] : s2[i];
+    siv3[i] = ref1 ? s2[i] : s1[i];
+  }
+  float nr[3], Ara[3];
+  row3(Ara, Ar, a);
+  {
+    const float ta = ref1 ? sel3(tA, a) : sel3(tB, a);
+    const float sg = ref1 ? (ta >= 0 ? 1.0f : -1.0f) : (ta >= 0 ? -1.0f : 1.0f);
+    for (int k = 0; k < 3; k++) { nr[k] = Ara[k] * sg; normal[k] = ref1 ? nr[k] : -nr[k]; }
   }
   int kk = 0;
   float bestd = -1.f;
+#pragma unroll
   for (int k = 0; k < 3; k++) {
     const float dd = fabsf(v3dot(nr, Ai[k]));
     if (dd > bestd) { bestd = dd; kk = k; }
   }
-  const float isg = v3dot(nr, Ai[kk]) >= 0 ? -1.0f : 1.0f;
-  const int ku = (kk + 1) % 3, kv = (kk + 2) % 3;
+  const int ku = (kk + 1) % 3, kv = (kk + 2) % 3, au = (a + 1) % 3, av = (a + 2) % 3;
+  float Aik[3], Aiu[3], Aiv[3], Aru[3], Arv[3];
+  row3(Aik, Ai, kk); row3(Aiu, Ai, ku); row3(Aiv, Ai, kv);
+  row3(Aru, Ar, au); row3(Arv, Ar, av);
+  const float sik = sel3(siv3, kk), siu = sel3(siv3, ku), siv = sel3(siv3, kv);
+  const float sra = sel3(srv3, a), sru = sel3(srv3, au), srv = sel3(srv3, av);
+  const float isg = v3dot(nr, Aik) >= 0 ? -1.0f : 1.0f;
   float ci[3], cr[3];
   v3copy(ci, pi);
-  v3addscl(ci, Ai[kk], isg * si[kk]);
-  const int au = (a + 1) % 3, av = (a + 2) % 3;
+  v3addscl(ci, Aik, isg * sik);
   v3copy(cr, pr);
-  v3addscl(cr, nr, sr[a]);
-  float poly[16][3];
+  v3addscl(cr, nr, sra);
+#pragma unroll
   for (int v = 0; v < 4; v++) {
     const float su = (v == 0 || v == 3) ? 1.0f : -1.0f;
     const float sv = (v < 2) ? 1.0f : -1.0f;
     float w[3];
     v3copy(w, ci);
-    v3addscl(w, Ai[ku], su * si[ku]);
-    v3addscl(w, Ai[kv], sv * si[kv]);
+    v3addscl(w, Aiu, su * siu);
+    v3addscl(w, Aiv, sv * siv);
     v3sub(w, w, cr);
-    poly[v][0] = v3dot(w, Ar[au]);
-    poly[v][1] = v3dot(w, Ar[av]);
-    poly[v][2] = v3dot(w, nr);
+    poly[3 * v] = v3dot(w, Aru);
+    poly[3 * v + 1] = v3dot(w, Arv);
+    poly[3 * v + 2] = v3dot(w, nr);
   }
-  const int n = clip_poly(poly, 4, sr[au], sr[av]);
+  const int n = clip_poly(poly, cand, 4, sru, srv);
   int nc = 0;
-  for (int v = 0; v < n && nc < 8; v++) {
-    const float dep = poly[v][2];
+  for (int v = 0; v < n; v++) {
+    const float x = poly[3 * v], y = poly[3 * v + 1], dep = poly[3 * v + 2];
     if (dep > margin) continue;
-    for (int k = 0; k < 3; k++)
-      out.pos[nc][k] = cr[k] + poly[v][0] * Ar[au][k] + poly[v][1] * Ar[av][k] + 0.5f * dep * nr[k];
-    out.dist[nc] = dep;
+    cand[4 * nc] = cr[0] + x * Aru[0] + y * Arv[0] + 0.5f * dep * nr[0];
+    cand[4 * nc + 1] = cr[1] + x * Aru[1] + y * Arv[1] + 0.5f * dep * nr[1];
+    cand[4 * nc + 2] = cr[2] + x * Aru[2] + y * Arv[2] + 0.5f * dep * nr[2];
+    cand[4 * nc + 3] = dep;
     nc++;
   }
-  out.n = nc;
+  return nc;
 }
 
 // plane (geom1, normal = +z of its frame) vs box: corners within margin, at most 4
-MRE_DEV void plane_box(const float* pp, const float* Rp, const float* pb, const float* Rb,
-                       const float* sb, float margin, PairContacts& out) {
-  out.n = 0;
+MRE_DEV int plane_box(const float* pp, const float* Rp, const float* pb, const float* Rb,
+                      const float* sb, float margin, float* normal, float* buf) {
+  float* cand = buf + 24;
   float n[3] = {Rp[2], Rp[5], Rp[8]};
-  v3copy(out.normal, n);
+  v3copy(normal, n);
   int cnt = 0;
   for (int c = 0; c < 8 && cnt < 4; c++) {
     float loc[3] = {(c & 1) ? sb[0] : -sb[0], (c & 2) ? sb[1] : -sb[1], (c & 4) ? sb[2] : -sb[2]};
@@ -183,11 +225,10 @@ MRE_DEV void plane_box(const float* pp, const float* Rp, const float* pb, const 
     const float ds = v3dot(wd, n);
     if (ds > margin) continue;
     v3addscl(w, n, -0.5f * ds);
-    v3copy(out.pos[cnt], w);
-    out.dist[cnt] = ds;
+    cand[4 * cnt] = w[0]; cand[4 * cnt + 1] = w[1]; cand[4 * cnt + 2] = w[2]; cand[4 * cnt + 3] = ds;
     cnt++;
   }
-  out.n = cnt;
+  return cnt;
 }
 
 // mju_makeFrame: f[0:3] unit normal given, builds the two tangents

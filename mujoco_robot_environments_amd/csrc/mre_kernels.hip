@@ -52,12 +52,11 @@ struct Sm {
   float Jr[NRROW_MAX][NRV], Br[NRROW_MAX][NRV];
   float Ablk[NCON_MAX + 8][9];  // contact blocks, then scalar-row triples
   float con_fric[NCON_MAX];
-  float jar[NEFC_MAX];
   float frc[NEFC_MAX];
   float zpad[4];  // zeros: operand source for lanes / rows outside a block
   // constraint blocks (scalar row or 3-row contact) and their island schedule
   int blk_info[MAXBLK];
-  int sched[MAXBLK][5];
+  int8_t sched[MAXBLK][5];
   int nblk, nsched;
 };
 

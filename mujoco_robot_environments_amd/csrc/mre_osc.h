@@ -18,6 +18,7 @@ namespace mre {
 struct OscSm {
   float J[6][7], M[7][7], MiJt[7][6], Li[6][6], Lam[6][6], V[6][6], Jbar[7][6];
   float ep[3], eo[3], F[6], LF[6], tn[7], Jbt[6], xd[6], w[6];
+  float Awork[36];  // Jacobi work matrix of the pinv fallback (single lane, LDS resident)
   float det;
 };
 
@@ -50,8 +51,7 @@ MRE_DEV float gauss_jordan_inplace(float* A, int l) {
 }
 
 // pinv of a symmetric 6x6 with relative cutoff rcond (cyclic Jacobi, single lane; rare path)
-MRE_DEV void sym_pinv6_serial(const float* A_in, float* out, float* V, float* w, float rcond) {
-  float A[36];
+MRE_DEV void sym_pinv6_serial(const float* A_in, float* out, float* V, float* w, float* A, float rcond) {
   for (int k = 0; k < 36; k++) { A[k] = A_in[k]; V[k] = (k % 7 == 0) ? 1.f : 0.f; }
   for (int sweep = 0; sweep < 30; sweep++) {
     float off = 0.f;
@@ -126,11 +126,7 @@ MRE_DEV void osc_compute(const DevModel* M, Sm& s, OscSm& o, const OscConfig& c,
     const int hi = i > j ? i : j, lo = i > j ? j : i;
     o.M[i][j] = s.qM[M->dof_Madr[hi] + (hi - lo)];
   }
-  if (l < 3) {
-    float ep[3], eo[3];
-    osc_errors(M, s, tgt, ep, eo);
-    o.ep[l] = ep[l]; o.eo[l] = eo[l];
-  }
+  if (l == 0) osc_errors(M, s, tgt, o.ep, o.eo);
   __syncthreads();
   gauss_jordan_inplace<7, 7>(&o.M[0][0], l);  // o.M <- M^-1
   if (l < 42) {
@@ -166,7 +162,7 @@ MRE_DEV void osc_compute(const DevModel* M, Sm& s, OscSm& o, const OscConfig& c,
   const float det = gauss_jordan_inplace<6, 6>(&o.Lam[0][0], l);  // o.Lam <- inv(L^-1)
   const bool use_pinv = c.pinv_always || !(fabsf(det) >= 1e-2f);
   if (use_pinv) {
-    if (l == 0) sym_pinv6_serial(&o.Li[0][0], &o.Lam[0][0], &o.V[0][0], o.w, 1e-2f);
+    if (l == 0) sym_pinv6_serial(&o.Li[0][0], &o.Lam[0][0], &o.V[0][0], o.w, o.Awork, 1e-2f);
     __syncthreads();
   }
   if (l < 6) {

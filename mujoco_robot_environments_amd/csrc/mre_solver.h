@@ -48,8 +48,14 @@ MRE_DEV void geom_pose(const DevModel* M, const Sm& s, int g, float* p, float* R
 // lane = entry of the static pair table; keeps ACTIVE contacts only
 // (dist < margin - gap), in pair order, capped at NCON_MAX.
 MRE_DEV void collide(const DevModel* M, Sm& s, int l) {
-  PairContacts pc;
-  pc.n = 0;
+  // per-lane clip buffers alias the Jacobian pools (contiguous Jp|Jr|Br, unused until assembly)
+  static_assert(offsetof(Sm, Jr) == offsetof(Sm, Jp) + sizeof(float) * NEFC_MAX * 13, "Jp|Jr must be contiguous");
+  static_assert(offsetof(Sm, Br) == offsetof(Sm, Jr) + sizeof(float) * NRROW_MAX * NRV, "Jr|Br must be contiguous");
+  static_assert(NEFC_MAX * 13 + 2 * NRROW_MAX * NRV >= 64 * COLL_BUF, "clip buffers do not fit");
+  float* buf = &s.Jp[0][0] + l * COLL_BUF;
+  float* cand = buf + 24;
+  float normal[3] = {0.f, 0.f, 1.f};
+  int n = 0;
   const int g1 = M->pair_g1[l], g2 = M->pair_g2[l];
   if (g1 >= 0) {
     const int b1 = M->geom_body[g1], b2 = M->geom_body[g2];
@@ -58,46 +64,48 @@ MRE_DEV void collide(const DevModel* M, Sm& s, int l) {
       geom_pose(M, s, g1, p1, R1, s1, &rb1);
       geom_pose(M, s, g2, p2, R2, s2, &rb2);
       const float inc = M->pair_margin[l] - M->pair_gap[l];
+      float df[3];
+      v3sub(df, p2, p1);
       if (M->geom_type[g1] == 0) {
-        float n[3] = {R1[2], R1[5], R1[8]}, df[3];
-        v3sub(df, p2, p1);
-        if (v3dot(df, n) - rb2 <= inc) plane_box(p1, R1, p2, R2, s2, inc, pc);
+        float nn[3] = {R1[2], R1[5], R1[8]};
+        if (v3dot(df, nn) - rb2 <= inc) n = plane_box(p1, R1, p2, R2, s2, inc, normal, buf);
       } else {
-        float df[3];
-        v3sub(df, p2, p1);
         const float r = rb1 + rb2 + inc;
-        if (v3dot(df, df) <= r * r) box_box(p1, R1, s1, p2, R2, s2, inc, pc);
+        if (v3dot(df, df) <= r * r) n = box_box(p1, R1, s1, p2, R2, s2, inc, normal, buf);
       }
       // instantiate only contacts with dist < includemargin
       int m = 0;
-      for (int c = 0; c < pc.n; c++)
-        if (pc.dist[c] < inc) {
-          if (m != c) { v3copy(pc.pos[m], pc.pos[c]); pc.dist[m] = pc.dist[c]; }
+      for (int c = 0; c < n; c++)
+        if (cand[4 * c + 3] < inc) {
+          if (m != c) for (int k = 0; k < 4; k++) cand[4 * m + k] = cand[4 * c + k];
           m++;
         }
-      pc.n = m;
+      n = m;
     }
   }
-  s.iscr[l] = pc.n;
+  s.iscr[l] = n;
   __syncthreads();
   int off = 0;
   for (int k = 0; k < l; k++) off += s.iscr[k];
   if (l == 63) {
-    const int tot = off + pc.n;
+    const int tot = off + n;
     s.ncon = tot < NCON_MAX ? tot : NCON_MAX;
     if (tot > NCON_MAX) s.overflow = 1;
   }
-  for (int c = 0; c < pc.n; c++) {
-    const int id = off + c;
-    if (id >= NCON_MAX) break;
-    v3copy(s.con_pos[id], pc.pos[c]);
+  if (n > 0) {
     float f[9];
-    v3copy(f, pc.normal);
+    v3copy(f, normal);
     make_frame(f);
-    for (int k = 0; k < 9; k++) s.con_frame[id][k] = f[k];
-    s.con_dist[id] = pc.dist[c];
-    s.con_pair[id] = l;
-    s.con_fric[id] = M->pair_friction[l][0];
+    const float fric = M->pair_friction[l][0];
+    for (int c = 0; c < n; c++) {
+      const int id = off + c;
+      if (id >= NCON_MAX) break;
+      s.con_pos[id][0] = cand[4 * c]; s.con_pos[id][1] = cand[4 * c + 1]; s.con_pos[id][2] = cand[4 * c + 2];
+      for (int k = 0; k < 9; k++) s.con_frame[id][k] = f[k];
+      s.con_dist[id] = cand[4 * c + 3];
+      s.con_pair[id] = l;
+      s.con_fric[id] = fric;
+    }
   }
   __syncthreads();
 }
@@ -214,14 +222,14 @@ MRE_DEV void assemble_constraints(const DevModel* M, Sm& s, int l) {
       solref = M->eq_solref[e]; solimp = M->eq_solimp[e];
       if (e < 2) {
         const int b1 = M->eq_obj[e][0], b2 = M->eq_obj[e][1], k = i % 3;
-        float p1[3], p2[3], cp[3], ax[3] = {0.f, 0.f, 0.f};
+        float p1[3], p2[3], cp[3];
+        const float ax[3] = {k == 0 ? 1.f : 0.f, k == 1 ? 1.f : 0.f, k == 2 ? 1.f : 0.f};
         m3mulv(p1, s.xmat[b1], M->eq_data[e]); v3add(p1, p1, s.xpos[b1]);
         m3mulv(p2, s.xmat[b2], M->eq_data[e] + 3); v3add(p2, p2, s.xpos[b2]);
         v3sub(cp, p1, p2);
-        ax[k] = 1.f;
         jac_robot(M, s, rs, b1, p1, ax, 1.f);
         jac_robot(M, s, rs, b2, p2, ax, -1.f);
-        pos = cp[k];
+        pos = sel3(cp, k);
         imp_pos = v3norm(cp);
         diag = M->body_invweight0[b1][0] + M->body_invweight0[b2][0];
       } else {
@@ -319,16 +327,19 @@ MRE_DEV void assemble_constraints(const DevModel* M, Sm& s, int l) {
     const int nb = scalar ? ((7 + nl - i0) < 3 ? (7 + nl - i0) : 3) : 3;
     const int slot = scalar ? NCON_MAX + i / 3 : (i - 7 - nl) / 3;
     float acc[3] = {0.f, 0.f, 0.f};
-    for (int cc = 0; cc < nb; cc++) {
+#pragma unroll
+    for (int cc = 0; cc < 3; cc++) {
       float a = 0.f;
-      if (rs != HDR_NONE) {
-        const int rs2 = rs - r + cc;
-        for (int j = 0; j < NRV; j++) a += s.Jr[rs][j] * s.Br[rs2][j];
+      if (cc < nb) {
+        if (rs != HDR_NONE) {
+          const int rs2 = rs - r + cc;
+          for (int j = 0; j < NRV; j++) a += s.Jr[rs][j] * s.Br[rs2][j];
+        }
+        if (pa < NPROP)
+          for (int k = 0; k < 6; k++) a += s.Jp[i][k] * s.Jp[i0 + cc][k] * prop_invM(s, pa, k);
+        if (pb < NPROP)
+          for (int k = 0; k < 6; k++) a += s.Jp[i][6 + k] * s.Jp[i0 + cc][6 + k] * prop_invM(s, pb, k);
       }
-      if (pa < NPROP)
-        for (int k = 0; k < 6; k++) a += s.Jp[i][k] * s.Jp[i0 + cc][k] * prop_invM(s, pa, k);
-      if (pb < NPROP)
-        for (int k = 0; k < 6; k++) a += s.Jp[i][6 + k] * s.Jp[i0 + cc][6 + k] * prop_invM(s, pb, k);
       acc[cc] = a;
     }
     float4 rd = s.rowdata[i];
@@ -336,7 +347,7 @@ MRE_DEV void assemble_constraints(const DevModel* M, Sm& s, int l) {
     if (r == 0) acc[0] = scalar ? acc[0] : diag;
     if (r == 1) acc[1] = scalar ? acc[1] : diag;
     if (r == 2) acc[2] = scalar ? acc[2] : diag;
-    for (int cc = 0; cc < 3; cc++) s.Ablk[slot][3 * r + cc] = acc[cc];
+    s.Ablk[slot][3 * r] = acc[0]; s.Ablk[slot][3 * r + 1] = acc[1]; s.Ablk[slot][3 * r + 2] = acc[2];
     rd.w = 1.0f / diag;
     s.rowdata[i] = rd;
   }
@@ -414,7 +425,8 @@ MRE_DEV int blk_nrows(int info) { return (info >> 27) & 0x3; }
 // islands, and any two blocks sharing an island keep their sequential order, so a sweep over
 // the schedule produces exactly the iterates of the sequential Gauss-Seidel sweep.
 MRE_DEV void build_schedule(const DevModel* M, Sm& s) {
-  int last[5] = {0, 0, 0, 0, 0};
+  int* last = s.iscr;  // per-island last step (LDS; lane 0 only)
+  for (int k = 0; k < 5; k++) last[k] = 0;
   const int nscalar = 7 + s.nl;
   int nb = 0, nst = 0;
   for (int st = 0; st < MAXBLK; st++)
@@ -433,16 +445,18 @@ MRE_DEV void build_schedule(const DevModel* M, Sm& s) {
     int pa = 0xF, pb = 0xF;
     if (b1 >= NRB) pa = b1 - NRB;
     if (b2 >= NRB) { if (pa == 0xF) pa = b2 - NRB; else pb = b2 - NRB; }
-    int isl[3], ni = 0;
-    if (rs != HDR_NONE) isl[ni++] = 0;
-    if (pa != 0xF) isl[ni++] = 1 + pa;
-    if (pb != 0xF) isl[ni++] = 1 + pb;
+    const bool hr = rs != HDR_NONE, ha = pa != 0xF, hb = pb != 0xF;
     int st = 0;
-    for (int k = 0; k < ni; k++) if (last[isl[k]] > st) st = last[isl[k]];
-    for (int k = 0; k < ni; k++) { last[isl[k]] = st + 1; s.sched[st][isl[k]] = nb; }
+    if (hr && last[0] > st) st = last[0];
+    if (ha && last[1 + pa] > st) st = last[1 + pa];
+    if (hb && last[1 + pb] > st) st = last[1 + pb];
+    if (hr) { last[0] = st + 1; s.sched[st][0] = nb; }
+    if (ha) { last[1 + pa] = st + 1; s.sched[st][1 + pa] = nb; }
+    if (hb) { last[1 + pb] = st + 1; s.sched[st][1 + pb] = nb; }
     if (st + 1 > nst) nst = st + 1;
-    const int rsl = (rs != HDR_NONE) ? rs : BLK_NONE;
-    s.blk_info[nb++] = 2 | ((nscalar + 3 * c) << 2) | (rsl << 9) | (pa << 16) | (pb << 20) | (isl[0] << 24) | (3 << 27);
+    const int rsl = hr ? rs : BLK_NONE;
+    const int prim = hr ? 0 : 1 + pa;
+    s.blk_info[nb++] = 2 | ((nscalar + 3 * c) << 2) | (rsl << 9) | (pa << 16) | (pb << 20) | (prim << 24) | (3 << 27);
   }
   s.nblk = nb;
   s.nsched = nst;
@@ -459,25 +473,27 @@ MRE_DEV void solve_constraints(const DevModel* M, Sm& s, int l) {
   const bool lvalid = ldof >= 0;
   const float linvM = (lp >= 0 && lvalid) ? prop_invM(s, lp, lk) : 0.f;
   const bool leader = (l == 0) || (l >= 16 && l < 48 && lk == 0);
+  static_assert(NV * 6 >= NEFC_MAX, "jar aliases cdof_dot");
+  float* jar = &s.cdof_dot[0][0];  // cdof_dot is dead once the velocity stage is done
   // ---- efc_b and warm-start forces (mj_constraintUpdate on J*qacc_warmstart - aref)
   for (int i = l; i < nefc; i += 64) {
     float4 rd = s.rowdata[i];
     const float aref = rd.y;
-    s.jar[i] = row_dot(s, i, s.qacc_ws) - aref;
+    jar[i] = row_dot(s, i, s.qacc_ws) - aref;
     rd.y = row_dot(s, i, s.qacc_smooth) - aref;
     s.rowdata[i] = rd;
   }
   __syncthreads();
   for (int i = l; i < nefc; i += 64) {
     const float D = 1.0f / s.rowdata[i].x;
-    if (i < 7) s.frc[i] = -D * s.jar[i];
-    else if (i < 7 + nl) s.frc[i] = s.jar[i] < 0.f ? -D * s.jar[i] : 0.f;
+    if (i < 7) s.frc[i] = -D * jar[i];
+    else if (i < 7 + nl) s.frc[i] = jar[i] < 0.f ? -D * jar[i] : 0.f;
     else if ((i - 7 - nl) % 3 == 0) {
       const int c = (i - 7 - nl) / 3, pr = s.con_pair[c];
       const float fr0 = M->pair_friction[pr][0];
       const float D1 = 1.0f / s.rowdata[i + 1].x, D2 = 1.0f / s.rowdata[i + 2].x;
       const float mu = fr0 * sqrtf(s.rowdata[i + 1].x / s.rowdata[i].x);
-      const float j0 = s.jar[i], j1 = s.jar[i + 1], j2 = s.jar[i + 2];
+      const float j0 = jar[i], j1 = jar[i + 1], j2 = jar[i + 2];
       const float U0 = j0 * mu, U1 = j1 * fr0, U2 = j2 * fr0;
       const float N = U0, T = sqrtf(U1 * U1 + U2 * U2);
       float f0, f1, f2;
