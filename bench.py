@@ -100,7 +100,8 @@ def cpu_baseline(seed, budget_s=12.0, nenv=64):
         if time.perf_counter() - t0 > budget_s:
             break
     dt = time.perf_counter() - t0
-    return {"value": nenv * ticks * CONTROL_STEPS / dt, "unit": "env-steps/s", "cores": threads,
+    finite = sum(bool(np.isfinite(e.arr("qpos")[:43]).all()) for e in envs)
+    return {"finite_envs": finite, "value": nenv * ticks * CONTROL_STEPS / dt, "unit": "env-steps/s", "cores": threads,
             "kind": "port", "sample": f"{nenv} envs x {ticks} ticks x {CONTROL_STEPS} steps, fp64 oracle "
             f"(PGS, same scene/actions), OpenMP {threads} threads, {dt:.1f} s"}
 
