@@ -124,9 +124,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    # rehearsal knobs (1-GPU box): MRE_BENCH_DEVICE pins every rank to one device and
+    # MRE_BENCH_BACKEND=gloo replaces RCCL (two ranks cannot share a device under RCCL)
+    backend = os.environ.get("MRE_BENCH_BACKEND", "nccl")
+    if "MRE_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["MRE_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from mujoco_robot_environments_amd import rng
@@ -160,9 +168,12 @@ def main():
         phys.sync()
         tg = time.perf_counter()
         qp, qv = phys.get_state()
-        fin = torch.from_numpy(np.concatenate([qp, qv, phys.status()[:, None].astype(np.float32)], axis=1)).to(phys.device)
-        out = torch.empty((world * n_local, fin.shape[1]), dtype=fin.dtype, device=phys.device)
-        dist.all_gather_into_tensor(out, fin.contiguous())
+        from mujoco_robot_environments_amd import distributed as D
+        fin = D.pack_final_state(qp, qv, phys.status())
+        if backend == "nccl":
+            fin = fin.to(phys.device)
+        out = D.gather_final_state(fin)
+        assert out.shape[0] == world * n_local
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - tg) * 1e3
     barrier()
@@ -170,7 +181,7 @@ def main():
     kern_ms, launches = phys.profile_read()
     phys.profile_enable(False)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=phys.device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=phys.device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -193,7 +204,7 @@ def main():
         "control_ticks_per_s": value / CONTROL_STEPS,
         "pick_place_macro_steps_per_s": value / 18000.0,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic()[0] if F == 1 else None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic()[0] if (F == 1 and n_local == ENVS_PER_GPU) else None,
                      "traffic_source": pmc_traffic()[1],
                      "kernel": "mre::k_step", "avg_launch_ms": avg_launch_s * 1e3, "launches": launches,
                      "algorithmic_bytes_per_launch": bytes_per_launch,
