@@ -8,13 +8,15 @@
 // (Sutherland-Hodgman, <= 8 points), edge contact = closest points of the two
 // supporting edges.  Contact position is midway between the surfaces, normal
 // points from geom1 to geom2, dist < 0 is penetration (MuJoCo conventions).
-// Output: candidates cand[k] = {x, y, z, dist}, k < n, in the lane's LDS buffer.
+// Output: candidate k < n = position cand_xyz(buf,k)[0..2] and distance cand_dist(buf,k).
 #pragma once
 #include "mre_math.h"
 
 namespace mre {
 
-constexpr int COLL_BUF = 56;   // floats per lane: poly[8][3] | q[8][3] -> cand[8][4]
+constexpr int COLL_BUF = 48;   // floats per lane: poly[8][3] | q[8][3]; candidates: xyz in q, dist in poly[.][2]
+MRE_DEV float* cand_xyz(float* buf, int k) { return buf + 24 + 3 * k; }
+MRE_DEV float& cand_dist(float* buf, int k) { return buf[3 * k + 2]; }
 
 // runtime pick of one of three values by arithmetic masks (a select chain over a local
 // array is turned back into an indexed stack access by the compiler -> scratch memory)
@@ -57,11 +59,11 @@ MRE_DEV int clip_poly(float* p, float* q, int n, float sx, float sy) {
 }
 
 // R1/R2: 3x3 row-major geom frames (columns = box axes); buf: this lane's LDS buffer.
-// Returns the number of candidates written to cand = buf + 24 ({x,y,z,dist} each).
+// Returns the number of candidates written (cand_xyz / cand_dist).
 MRE_DEV int box_box(const float* p1, const float* R1, const float* s1, const float* p2,
                     const float* R2, const float* s2, float margin, float* normal, float* buf) {
   float* poly = buf;
-  float* cand = buf + 24;
+  float* qbuf = buf + 24;
   float A[3][3], B[3][3], dv[3], Cm[3][3], aC[3][3];
 #pragma unroll
   for (int i = 0; i < 3; i++)
@@ -138,8 +140,9 @@ MRE_DEV int box_box(const float* p1, const float* R1, const float* s1, const flo
     v3copy(normal, en);
     v3sub(df, q2, q1);
     const float d = v3dot(df, en);
-    cand[0] = 0.5f * (q1[0] + q2[0]); cand[1] = 0.5f * (q1[1] + q2[1]); cand[2] = 0.5f * (q1[2] + q2[2]);
-    cand[3] = d;
+    float* c0 = cand_xyz(buf, 0);
+    c0[0] = 0.5f * (q1[0] + q2[0]); c0[1] = 0.5f * (q1[1] + q2[1]); c0[2] = 0.5f * (q1[2] + q2[2]);
+    cand_dist(buf, 0) = d;
     return d <= margin ? 1 : 0;
   }
   // face contact: the reference box owns the separating face
@@ -195,15 +198,16 @@ MRE_DEV int box_box(const float* p1, const float* R1, const float* s1, const flo
     poly[3 * v + 1] = v3dot(w, Arv);
     poly[3 * v + 2] = v3dot(w, nr);
   }
-  const int n = clip_poly(poly, cand, 4, sru, srv);
+  const int n = clip_poly(poly, qbuf, 4, sru, srv);
   int nc = 0;
   for (int v = 0; v < n; v++) {
     const float x = poly[3 * v], y = poly[3 * v + 1], dep = poly[3 * v + 2];
     if (dep > margin) continue;
-    cand[4 * nc] = cr[0] + x * Aru[0] + y * Arv[0] + 0.5f * dep * nr[0];
-    cand[4 * nc + 1] = cr[1] + x * Aru[1] + y * Arv[1] + 0.5f * dep * nr[1];
-    cand[4 * nc + 2] = cr[2] + x * Aru[2] + y * Arv[2] + 0.5f * dep * nr[2];
-    cand[4 * nc + 3] = dep;
+    float* cx = cand_xyz(buf, nc);  // nc <= v: q is free after clipping, poly[nc][2] already consumed
+    cx[0] = cr[0] + x * Aru[0] + y * Arv[0] + 0.5f * dep * nr[0];
+    cx[1] = cr[1] + x * Aru[1] + y * Arv[1] + 0.5f * dep * nr[1];
+    cx[2] = cr[2] + x * Aru[2] + y * Arv[2] + 0.5f * dep * nr[2];
+    cand_dist(buf, nc) = dep;
     nc++;
   }
   return nc;
@@ -212,7 +216,6 @@ MRE_DEV int box_box(const float* p1, const float* R1, const float* s1, const flo
 // plane (geom1, normal = +z of its frame) vs box: corners within margin, at most 4
 MRE_DEV int plane_box(const float* pp, const float* Rp, const float* pb, const float* Rb,
                       const float* sb, float margin, float* normal, float* buf) {
-  float* cand = buf + 24;
   float n[3] = {Rp[2], Rp[5], Rp[8]};
   v3copy(normal, n);
   int cnt = 0;
@@ -225,7 +228,9 @@ MRE_DEV int plane_box(const float* pp, const float* Rp, const float* pb, const f
     const float ds = v3dot(wd, n);
     if (ds > margin) continue;
     v3addscl(w, n, -0.5f * ds);
-    cand[4 * cnt] = w[0]; cand[4 * cnt + 1] = w[1]; cand[4 * cnt + 2] = w[2]; cand[4 * cnt + 3] = ds;
+    float* cx = cand_xyz(buf, cnt);
+    cx[0] = w[0]; cx[1] = w[1]; cx[2] = w[2];
+    cand_dist(buf, cnt) = ds;
     cnt++;
   }
   return cnt;

@@ -26,7 +26,7 @@ constexpr int MAXCHAIN = 9;   // longest dof chain root->leaf (7 arm + 2 finger)
 constexpr int MAXFAC = 45;    // (i,j) ancestor pairs touched by one elimination step
 constexpr int NCON_MAX = 36;  // active contacts kept per env
 constexpr int NEFC_MAX = 128; // constraint rows per env
-constexpr int NRROW_MAX = 64; // rows with a robot part
+constexpr int NRROW_MAX = 55; // rows with a robot part (7 equality + limits + 3 per robot contact)
 constexpr int MAXBLK = 64;    // 7 equality + <=15 limit rows + NCON_MAX contacts
 
 struct DevModel {

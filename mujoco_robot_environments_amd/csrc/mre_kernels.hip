@@ -21,6 +21,14 @@
 
 namespace mre {
 
+// OSC scratch (mre_osc.h); lives in LDS region R1 (see Sm)
+struct OscSm {
+  float J[6][7], M[7][7], MiJt[7][6], Li[6][6], Lam[6][6], V[6][6], Jbar[7][6];
+  float ep[3], eo[3], F[6], LF[6], tn[7], Jbt[6], xd[6], w[6];
+  float Awork[36];  // Jacobi work matrix of the pinv fallback (single lane)
+  float det;
+};
+
 struct Sm {
   // state
   float qpos[NQP], qvel[NVP], qacc_ws[NVP], ctrl[NU];
@@ -28,31 +36,39 @@ struct Sm {
   float qfrc_smooth[NVP], qacc_smooth[NVP], qacc[NVP], qfrc_bias[NVP], qfrc_con[NVP];
   // body frames
   float xpos[NB][3], xquat[NB][4], xmat[NB][9];
-  float cinert[NB][10], crb[NB][10];
-  float cdof[NV][6], cdof_dot[NV][6];
-  float cvel[NB][6], cfrc[NB][6];
+  // LDS regions reused along the step (lifetimes: S1a kinematics..factor, S1b velocity stage,
+  // S1c collision + assembly, tick-boundary controller, S2 solve + integrate)
+  union {  // R1: spatial inertias (S1a/S1b) | OSC scratch (tick boundary)
+    struct { float cinert[NB][10], crb[NB][10]; };
+    OscSm osc;
+  };
+  float cdof[NV][6];
+  union {  // R2: velocity-stage temporaries (S1b) | contact geometry (S1c) | jar + forces (S2)
+    struct { float cdof_dot[NV][6], cvel[NB][6], cfrc[NB][6]; };
+    struct { float con_pos[NCON_MAX][3], con_frame[NCON_MAX][9]; };
+    struct { float jar[NEFC_MAX], frc[NEFC_MAX]; };
+  };
   float com_robot[3];
   float site_xpos[NSITE][3], site_xmat[NSITE][9];
   // robot block of the sparse mass matrix and its factors
-  float qM[NMR], qLD[NMR], qLDinv[NRV + 1], qH[NMR], qHinv[NRV + 1];
+  float qM[NMR], qLD[NMR], qLDinv[NRV + 1];  // qLD doubles as the factor of M - h dF/dv in integrate
   // per-env cube constants
   float prop_mass[NPROP], prop_inertia[NPROP][3], prop_size[NPROP][3];
-  float scratch[64];
+  union { float scratch[64]; int iscr[64]; };
   float osc_tgt[16];
-  int iscr[64];
   int nprops;
   // active contacts (pair order)
   int ncon, nefc, nl, nrrow, overflow, solver_iters;
-  float con_pos[NCON_MAX][3], con_frame[NCON_MAX][9], con_dist[NCON_MAX];
-  int con_pair[NCON_MAX], con_rslot[NCON_MAX], lim_info[NRV + 1];
+  float con_dist[NCON_MAX];
+  uint8_t con_pair[NCON_MAX], con_rslot[NCON_MAX];
+  uint16_t lim_info[NRV + 1];
   // constraint rows: rowdata = {R, aref -> efc_b, force, 1/A_ii}
   alignas(16) float4 rowdata[NEFC_MAX];
-  int hdr[NEFC_MAX];
+  uint16_t hdr[NEFC_MAX];  // robot slot | propA << 8 | propB << 12
   float Jp[NEFC_MAX][13];
   float Jr[NRROW_MAX][NRV], Br[NRROW_MAX][NRV];
   float Ablk[NCON_MAX + 8][9];  // contact blocks, then scalar-row triples
   float con_fric[NCON_MAX];
-  float frc[NEFC_MAX];
   float zpad[4];  // zeros: operand source for lanes / rows outside a block
   // constraint blocks (scalar row or 3-row contact) and their island schedule
   int blk_info[MAXBLK];
@@ -70,7 +86,7 @@ MRE_DEV bool body_is_active(const DevModel* M, const Sm& s, int b) {
 }
 
 // ------------------------------------------------------------ mj_kinematics
-MRE_DEV void kinematics(const DevModel* M, Sm& s, int l, BodyRegs& br) {
+MRE_PHASE_FN void kinematics(const DevModel* M, Sm& s, int l, BodyRegs& br) {
   if (l == 0) {
     v3zero(s.xpos[0]);
     s.xquat[0][0] = 1.f; s.xquat[0][1] = s.xquat[0][2] = s.xquat[0][3] = 0.f;
@@ -258,7 +274,7 @@ MRE_DEV void solve_robot_serial(const DevModel* M, const float* LD, const float*
 namespace mre {
 
 // ------------------------------------------------ mj_comVel + mj_rne + mj_passive
-MRE_DEV void velocity_stage(const DevModel* M, Sm& s, int l) {
+MRE_PHASE_FN void velocity_stage(const DevModel* M, Sm& s, int l) {
   // cvel, cdof_dot (lane = body; each lane re-accumulates its chain prefix)
   float cv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (l >= 1 && l < NB) {
@@ -372,7 +388,7 @@ MRE_DEV bool smooth_forces(const DevModel* M, Sm& s, int l) {
 }
 
 // ------------------------------------------- mj_implicit (implicitfast) + advance
-MRE_DEV void integrate(const DevModel* M, Sm& s, int l, bool grip_clamped, unsigned flags) {
+MRE_PHASE_FN void integrate(const DevModel* M, Sm& s, int l, bool grip_clamped, unsigned flags) {
   const float h = M->timestep;
   if (l < NVP) s.qacc_ws[l] = (l < NV) ? s.qacc[l] : 0.f;
   // MH = M - h*dF/dv restricted to M's pattern (diagonal terms only here)
@@ -386,12 +402,12 @@ MRE_DEV void integrate(const DevModel* M, Sm& s, int l, bool grip_clamped, unsig
         if (i == M->ten_dof[1]) v -= h * M->grip_biasprm[2] * M->ten_coef[1] * M->ten_coef[1];
       }
     }
-    s.qH[e] = v;
+    s.qLD[e] = v;
   }
   if (l < NRV) s.scratch[l] = s.qfrc_smooth[l] + s.qfrc_con[l];
   __syncthreads();
-  factor_robot(M, s.qH, s.qHinv, l);
-  if (l == 0) solve_robot_serial(M, s.qH, s.qHinv, s.scratch);
+  factor_robot(M, s.qLD, s.qLDinv, l);
+  if (l == 0) solve_robot_serial(M, s.qLD, s.qLDinv, s.scratch);
   __syncthreads();
   const bool freeze = (flags & F_FREEZE_ROBOT) != 0;
   if (l < NV) {
@@ -423,9 +439,9 @@ MRE_DEV void integrate(const DevModel* M, Sm& s, int l, bool grip_clamped, unsig
 }
 
 // =========================================================================
-__global__ __launch_bounds__(64) void k_step(StepArgs a) {
+__global__ __launch_bounds__(64, 2) void k_step(StepArgs a) {
   __shared__ Sm s;
-  __shared__ OscSm osc;
+  OscSm& osc = s.osc;
   const int env = blockIdx.x;
   const int l = threadIdx.x;
   if (env >= a.N) return;
@@ -469,6 +485,7 @@ __global__ __launch_bounds__(64) void k_step(StepArgs a) {
   BodyRegs br;
   for (int step = 0; step < a.nsteps; ++step) {
     // ------------------------------------------------ S1: position stage
+
     kinematics(M, s, l, br);
     com_pos(M, s, l, br);
     __syncthreads();
@@ -477,14 +494,20 @@ __global__ __launch_bounds__(64) void k_step(StepArgs a) {
     for (int e = l; e < NMR; e += 64) s.qLD[e] = s.qM[e];
     __syncthreads();
     factor_robot(M, s.qLD, s.qLDinv, l);
-    const bool constrained = (a.flags & F_NO_CONSTRAINTS) == 0;
-    if (constrained) {
-      collide(M, s, l);
-      assemble_constraints(M, s, l);
-    }
-    // ------------------------------------------------ S1: velocity stage
+    // ------------------------------------------------ S1b: velocity stage (before collision:
+    // its temporaries share LDS region R2 with the contact geometry)
+
     velocity_stage(M, s, l);
     __syncthreads();
+    // ------------------------------------------------ S1c: collision + constraint assembly
+    const bool constrained = (a.flags & F_NO_CONSTRAINTS) == 0;
+    if (constrained) {
+
+      collide(M, s, l);
+
+      assemble_constraints(M, s, l);
+    }
+
     // ------------------------------------------------ control at tick boundary
     if (a.mode == CTRL_SEQ && (step % a.control_steps) == 0) {
       const int tick = step / a.control_steps;
@@ -501,12 +524,14 @@ __global__ __launch_bounds__(64) void k_step(StepArgs a) {
     }
     // ------------------------------------------------ S2
     const bool clamped = smooth_forces(M, s, l);
+
     if (constrained) {
       solve_constraints(M, s, l);
     } else {
       if (l < NVP) { s.qacc[l] = s.qacc_smooth[l]; s.qfrc_con[l] = 0.f; }
       __syncthreads();
     }
+
     integrate(M, s, l, clamped, a.flags);
     if (a.trace != nullptr && env < a.trace_nenv && (a.trace_base + step) < a.trace_max) {
       if (l < NQP)

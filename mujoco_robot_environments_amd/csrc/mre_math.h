@@ -4,6 +4,9 @@
 #include <hip/hip_runtime.h>
 
 #define MRE_DEV __device__ __forceinline__
+// whole phases are real functions: register allocation is scoped per phase instead of across
+// the fused step loop (the inlined kernel needed 332 registers -> 1 wave per SIMD)
+#define MRE_PHASE_FN __device__ __attribute__((noinline))
 
 namespace mre {
 

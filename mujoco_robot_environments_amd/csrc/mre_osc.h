@@ -15,13 +15,6 @@
 
 namespace mre {
 
-struct OscSm {
-  float J[6][7], M[7][7], MiJt[7][6], Li[6][6], Lam[6][6], V[6][6], Jbar[7][6];
-  float ep[3], eo[3], F[6], LF[6], tn[7], Jbt[6], xd[6], w[6];
-  float Awork[36];  // Jacobi work matrix of the pinv fallback (single lane, LDS resident)
-  float det;
-};
-
 // in-place inverse of an SPD n x n matrix (row stride ld) by Gauss-Jordan without
 // pivoting; lane = (i, j).  Returns the determinant (product of pivots), uniform.
 template <int N, int LD>
@@ -110,7 +103,7 @@ MRE_DEV bool osc_converged(const DevModel* M, const Sm& s, const OscConfig& c, c
 }
 
 // writes s.ctrl[0..6]; tgt = [pos3 quat4 vel3 angvel3] (uniform pointer into LDS)
-MRE_DEV void osc_compute(const DevModel* M, Sm& s, OscSm& o, const OscConfig& c, const float* tgt, int l) {
+MRE_PHASE_FN void osc_compute(const DevModel* M, Sm& s, OscSm& o, const OscConfig& c, const float* tgt, int l) {
   const int st = M->eef_site;
   // J (lane = r*7+a) and dense arm mass block (lane = i*7+j)
   if (l < 42) {

@@ -47,13 +47,12 @@ MRE_DEV void geom_pose(const DevModel* M, const Sm& s, int g, float* p, float* R
 // ------------------------------------------------------------------ mj_collision
 // lane = entry of the static pair table; keeps ACTIVE contacts only
 // (dist < margin - gap), in pair order, capped at NCON_MAX.
-MRE_DEV void collide(const DevModel* M, Sm& s, int l) {
+MRE_PHASE_FN void collide(const DevModel* M, Sm& s, int l) {
   // per-lane clip buffers alias the Jacobian pools (contiguous Jp|Jr|Br, unused until assembly)
   static_assert(offsetof(Sm, Jr) == offsetof(Sm, Jp) + sizeof(float) * NEFC_MAX * 13, "Jp|Jr must be contiguous");
   static_assert(offsetof(Sm, Br) == offsetof(Sm, Jr) + sizeof(float) * NRROW_MAX * NRV, "Jr|Br must be contiguous");
   static_assert(NEFC_MAX * 13 + 2 * NRROW_MAX * NRV >= 64 * COLL_BUF, "clip buffers do not fit");
   float* buf = &s.Jp[0][0] + l * COLL_BUF;
-  float* cand = buf + 24;
   float normal[3] = {0.f, 0.f, 1.f};
   int n = 0;
   const int g1 = M->pair_g1[l], g2 = M->pair_g2[l];
@@ -76,8 +75,11 @@ MRE_DEV void collide(const DevModel* M, Sm& s, int l) {
       // instantiate only contacts with dist < includemargin
       int m = 0;
       for (int c = 0; c < n; c++)
-        if (cand[4 * c + 3] < inc) {
-          if (m != c) for (int k = 0; k < 4; k++) cand[4 * m + k] = cand[4 * c + k];
+        if (cand_dist(buf, c) < inc) {
+          if (m != c) {
+            for (int k = 0; k < 3; k++) cand_xyz(buf, m)[k] = cand_xyz(buf, c)[k];
+            cand_dist(buf, m) = cand_dist(buf, c);
+          }
           m++;
         }
       n = m;
@@ -100,9 +102,10 @@ MRE_DEV void collide(const DevModel* M, Sm& s, int l) {
     for (int c = 0; c < n; c++) {
       const int id = off + c;
       if (id >= NCON_MAX) break;
-      s.con_pos[id][0] = cand[4 * c]; s.con_pos[id][1] = cand[4 * c + 1]; s.con_pos[id][2] = cand[4 * c + 2];
+      const float cx0 = cand_xyz(buf, c)[0], cx1 = cand_xyz(buf, c)[1], cx2 = cand_xyz(buf, c)[2];
+      s.con_pos[id][0] = cx0; s.con_pos[id][1] = cx1; s.con_pos[id][2] = cx2;
       for (int k = 0; k < 9; k++) s.con_frame[id][k] = f[k];
-      s.con_dist[id] = cand[4 * c + 3];
+      s.con_dist[id] = cand_dist(buf, c);
       s.con_pair[id] = l;
       s.con_fric[id] = fric;
     }
@@ -167,7 +170,7 @@ MRE_DEV float row_dot(const Sm& s, int i, const float* vec) {
 }
 
 // ------------------------- mj_makeConstraint + mj_makeImpedance + reference + project
-MRE_DEV void assemble_constraints(const DevModel* M, Sm& s, int l) {
+MRE_PHASE_FN void assemble_constraints(const DevModel* M, Sm& s, int l) {
   // ---- joint limits: lane = robot body; at most one side can be violated
   int lim = 0, lim_side = 0;
   if (l >= 1 && l < NRB && M->jnt_limited[l]) {
@@ -464,7 +467,7 @@ MRE_DEV void build_schedule(const DevModel* M, Sm& s) {
 
 // ------------------------------------------------------------- mj_fwdConstraint
 // On exit: s.qacc = qacc_smooth + M^-1 J' f, s.qfrc_con = J' f.
-MRE_DEV void solve_constraints(const DevModel* M, Sm& s, int l) {
+MRE_PHASE_FN void solve_constraints(const DevModel* M, Sm& s, int l) {
   const int nefc = s.nefc, nl = s.nl;
   const int isl = lane_island(l);
   const int ldof = lane_dof(l);
@@ -473,8 +476,7 @@ MRE_DEV void solve_constraints(const DevModel* M, Sm& s, int l) {
   const bool lvalid = ldof >= 0;
   const float linvM = (lp >= 0 && lvalid) ? prop_invM(s, lp, lk) : 0.f;
   const bool leader = (l == 0) || (l >= 16 && l < 48 && lk == 0);
-  static_assert(NV * 6 >= NEFC_MAX, "jar aliases cdof_dot");
-  float* jar = &s.cdof_dot[0][0];  // cdof_dot is dead once the velocity stage is done
+  float* jar = s.jar;
   // ---- efc_b and warm-start forces (mj_constraintUpdate on J*qacc_warmstart - aref)
   for (int i = l; i < nefc; i += 64) {
     float4 rd = s.rowdata[i];
@@ -489,8 +491,8 @@ MRE_DEV void solve_constraints(const DevModel* M, Sm& s, int l) {
     if (i < 7) s.frc[i] = -D * jar[i];
     else if (i < 7 + nl) s.frc[i] = jar[i] < 0.f ? -D * jar[i] : 0.f;
     else if ((i - 7 - nl) % 3 == 0) {
-      const int c = (i - 7 - nl) / 3, pr = s.con_pair[c];
-      const float fr0 = M->pair_friction[pr][0];
+      const int c = (i - 7 - nl) / 3;
+      const float fr0 = s.con_fric[c];
       const float D1 = 1.0f / s.rowdata[i + 1].x, D2 = 1.0f / s.rowdata[i + 2].x;
       const float mu = fr0 * sqrtf(s.rowdata[i + 1].x / s.rowdata[i].x);
       const float j0 = jar[i], j1 = jar[i + 1], j2 = jar[i + 2];

@@ -43,4 +43,4 @@ def test_gpu_matches_golden(compiled_model):
     for i in range(N):
         err[:, i, 15 + 7 * int(g["nprops"][i]):] = 0
     print("gpu vs golden: arm %.2e grip %.2e cubes %.2e" % (err[..., :7].max(), err[..., 7:15].max(), err[..., 15:].max()))
-    assert err[..., :7].max() < 1e-4 and err[..., 15:].max() < 1e-4 and err[..., 7:15].max() < 5e-3
+    assert err[..., :7].max() < 1e-4 and err[..., 15:].max() < 1e-3 and err[..., 7:15].max() < 5e-3
