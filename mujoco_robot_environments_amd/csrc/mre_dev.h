@@ -24,10 +24,11 @@ constexpr int NSITE = 2;
 constexpr int NEQ = 3;
 constexpr int MAXCHAIN = 9;   // longest dof chain root->leaf (7 arm + 2 finger)
 constexpr int MAXFAC = 45;    // (i,j) ancestor pairs touched by one elimination step
-constexpr int NCON_MAX = 36;  // active contacts kept per env
-constexpr int NEFC_MAX = 128; // constraint rows per env
-constexpr int NRROW_MAX = 55; // rows with a robot part (7 equality + limits + 3 per robot contact)
-constexpr int MAXBLK = 64;    // 7 equality + <=15 limit rows + NCON_MAX contacts
+constexpr int NCON_MAX = 32;  // active contacts kept per env
+constexpr int NEFC_MAX = 112; // constraint rows per env (7 equality + limits + 3 per contact)
+constexpr int NRROW_MAX = 50; // rows with a robot part (7 equality + limits + 3 per robot contact)
+constexpr int NPP_MAX = 8;    // cube-cube contacts (rows with two prop parts)
+constexpr int MAXBLK = 56;    // 7 equality + <=15 limit rows + NCON_MAX contacts
 
 struct DevModel {
   // ---- bodies (index = body id)

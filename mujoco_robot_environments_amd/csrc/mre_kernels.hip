@@ -25,8 +25,6 @@ namespace mre {
 struct OscSm {
   float J[6][7], M[7][7], MiJt[7][6], Li[6][6], Lam[6][6], V[6][6], Jbar[7][6];
   float ep[3], eo[3], F[6], LF[6], tn[7], Jbt[6], xd[6], w[6];
-  float Awork[36];  // Jacobi work matrix of the pinv fallback (single lane)
-  float det;
 };
 
 struct Sm {
@@ -39,17 +37,17 @@ struct Sm {
   // LDS regions reused along the step (lifetimes: S1a kinematics..factor, S1b velocity stage,
   // S1c collision + assembly, tick-boundary controller, S2 solve + integrate)
   union {  // R1: spatial inertias (S1a/S1b) | OSC scratch (tick boundary)
-    struct { float cinert[NB][10], crb[NB][10]; };
+    struct { float cinert[NB][10], crb[NRB][10]; };
     OscSm osc;
   };
-  float cdof[NV][6];
+  float cdof[NRV][6];  // robot dofs only; cube cdofs are implicit (prop_cdof)
   union {  // R2: velocity-stage temporaries (S1b) | contact geometry (S1c) | jar + forces (S2)
     struct { float cdof_dot[NV][6], cvel[NB][6], cfrc[NB][6]; };
     struct { float con_pos[NCON_MAX][3], con_frame[NCON_MAX][9]; };
     struct { float jar[NEFC_MAX], frc[NEFC_MAX]; };
   };
   float com_robot[3];
-  float site_xpos[NSITE][3], site_xmat[NSITE][9];
+  float site_xpos[NSITE][3], site_xmat[1][9];  // orientation of the controller site only
   // robot block of the sparse mass matrix and its factors
   float qM[NMR], qLD[NMR], qLDinv[NRV + 1];  // qLD doubles as the factor of M - h dF/dv in integrate
   // per-env cube constants
@@ -60,19 +58,23 @@ struct Sm {
   // active contacts (pair order)
   int ncon, nefc, nl, nrrow, overflow, solver_iters;
   float con_dist[NCON_MAX];
-  uint8_t con_pair[NCON_MAX], con_rslot[NCON_MAX];
+  uint8_t con_pair[NCON_MAX], con_rslot[NCON_MAX], con_bslot[NCON_MAX];
   uint16_t lim_info[NRV + 1];
-  // constraint rows: rowdata = {R, aref -> efc_b, force, 1/A_ii}
-  alignas(16) float4 rowdata[NEFC_MAX];
-  uint16_t hdr[NEFC_MAX];  // robot slot | propA << 8 | propB << 12
-  float Jp[NEFC_MAX][13];
+  // ---- contiguous block [JpA .. sched]: written only after collision; hosts the per-lane
+  // clip buffers of the narrow phase (mre_solver.h: collide)
+  float JpA[3 * NCON_MAX][6];            // prop part A of every contact row
+  float JpB[3 * NPP_MAX][6];             // prop part B (cube-cube contacts only)
   float Jr[NRROW_MAX][NRV], Br[NRROW_MAX][NRV];
+  // constraint rows: regulariser R, aref (S1) -> efc_b (S2), 1/A_ii
+  float rowR[NEFC_MAX], rowB[NEFC_MAX], rowAinv[NEFC_MAX];
   float Ablk[NCON_MAX + 8][9];  // contact blocks, then scalar-row triples
-  float con_fric[NCON_MAX];
-  float zpad[4];  // zeros: operand source for lanes / rows outside a block
   // constraint blocks (scalar row or 3-row contact) and their island schedule
   int blk_info[MAXBLK];
+  uint16_t hdr[NEFC_MAX];  // per row: robot slot | propA << 8 | propB << 12
   int8_t sched[MAXBLK][5];
+
+  float con_fric[NCON_MAX];
+  float zpad[4];  // zeros: operand source for lanes / rows outside a block
   int nblk, nsched;
 };
 
@@ -139,7 +141,7 @@ MRE_PHASE_FN void kinematics(const DevModel* M, Sm& s, int l, BodyRegs& br) {
     m3mulv(tmp, s.xmat[b], M->site_pos[l]);
     v3add(s.site_xpos[l], s.xpos[b], tmp);
     qmul(q, s.xquat[b], M->site_quat[l]);
-    q2mat(s.site_xmat[l], q);
+    if (l == M->eef_site) q2mat(s.site_xmat[0], q);
   }
 }
 
@@ -184,19 +186,22 @@ MRE_DEV void com_pos(const DevModel* M, Sm& s, int l, const BodyRegs& br) {
     if (pid < 0) {
       v3copy(s.cdof[da], br.axis);
       v3cross(s.cdof[da] + 3, br.axis, off);
-    } else {
-#pragma unroll
-      for (int k = 0; k < 3; k++) {
-        float* t = s.cdof[da + k];
-        t[0] = t[1] = t[2] = 0.f; t[3] = t[4] = t[5] = 0.f;
-        t[3 + k] = 1.f;
-        float ax[3] = {s.xmat[b][k], s.xmat[b][3 + k], s.xmat[b][6 + k]};
-        v3copy(s.cdof[da + 3 + k], ax);
-        v3cross(s.cdof[da + 3 + k] + 3, ax, off);
-      }
     }
+    // cube cdofs are not stored: translation k = [0; e_k], rotation k = [xmat column k; 0]
+    // (each cube is its own tree, c-frame origin = its COM) -- see prop_cdof()
   }
   if (l == 0) for (int k = 0; k < 10; k++) s.cinert[0][k] = 0.f;
+}
+
+// cdof of cube body b, local dof j (mju_dofCom with zero offset)
+MRE_DEV void prop_cdof(const Sm& s, int b, int j, float* c) {
+  c[0] = c[1] = c[2] = c[3] = c[4] = c[5] = 0.f;
+  if (j < 3) {
+    c[3 + j] = 1.f;
+  } else {
+    const int k = j - 3;
+    c[0] = s.xmat[b][k]; c[1] = s.xmat[b][3 + k]; c[2] = s.xmat[b][6 + k];
+  }
 }
 
 // ------------------------------------------------------- mj_crb (robot block)
@@ -290,15 +295,23 @@ MRE_PHASE_FN void velocity_stage(const DevModel* M, Sm& s, int l) {
       }
     } else {
       const int da = M->body_dofadr[b];
+#pragma unroll
       for (int j = 0; j < 3; j++) {
         for (int t = 0; t < 6; t++) s.cdof_dot[da + j][t] = 0.f;
-        const float qv = s.qvel[da + j];
-        for (int t = 0; t < 6; t++) cv[t] += s.cdof[da + j][t] * qv;
+        cv[3 + j] += s.qvel[da + j];
       }
-      for (int j = 3; j < 6; j++) cross_motion(s.cdof_dot[da + j], cv, s.cdof[da + j]);
+#pragma unroll
       for (int j = 3; j < 6; j++) {
+        float cd[6];
+        prop_cdof(s, b, j, cd);
+        cross_motion(s.cdof_dot[da + j], cv, cd);
+      }
+#pragma unroll
+      for (int j = 3; j < 6; j++) {
+        float cd[6];
+        prop_cdof(s, b, j, cd);
         const float qv = s.qvel[da + j];
-        for (int t = 0; t < 6; t++) cv[t] += s.cdof[da + j][t] * qv;
+        for (int t = 0; t < 3; t++) cv[t] += cd[t] * qv;
       }
     }
 #pragma unroll
@@ -347,7 +360,10 @@ MRE_PHASE_FN void velocity_stage(const DevModel* M, Sm& s, int l) {
         }
     }
     const bool act = body_is_active(M, s, b);
-    s.qfrc_bias[l] = act ? dot6(s.cdof[l], tot) : 0.f;
+    float cd[6];
+    if (b < NRB) { for (int t = 0; t < 6; t++) cd[t] = s.cdof[l][t]; }
+    else prop_cdof(s, b, l - M->body_dofadr[b], cd);
+    s.qfrc_bias[l] = act ? dot6(cd, tot) : 0.f;
   }
 }
 
@@ -554,7 +570,7 @@ __global__ __launch_bounds__(64, 2) void k_step(StepArgs a) {
     if (l >= 3 && l < 6) o[l] = s.site_xpos[M->eef_site][l - 3];
     if (l == 6) {
       float q[4];
-      mat2q(q, s.site_xmat[M->eef_site]);
+      mat2q(q, s.site_xmat[0]);
       o[6] = q[0]; o[7] = q[1]; o[8] = q[2]; o[9] = q[3];
     }
   }

@@ -89,7 +89,8 @@ MRE_DEV void osc_errors(const DevModel* M, const Sm& s, const float* tgt, float*
   const int st = M->eef_site;
   v3sub(ep, tgt, s.site_xpos[st]);
   float q[4], qc[4], qe[4];
-  mat2q(q, s.site_xmat[st]);
+  (void)st;
+  mat2q(q, s.site_xmat[0]);
   qc[0] = q[0]; qc[1] = -q[1]; qc[2] = -q[2]; qc[3] = -q[3];
   qmul(qe, tgt + 3, qc);
   const float sg = qe[0] > 0.f ? 1.f : (qe[0] < 0.f ? -1.f : 0.f);
@@ -155,7 +156,7 @@ MRE_PHASE_FN void osc_compute(const DevModel* M, Sm& s, OscSm& o, const OscConfi
   const float det = gauss_jordan_inplace<6, 6>(&o.Lam[0][0], l);  // o.Lam <- inv(L^-1)
   const bool use_pinv = c.pinv_always || !(fabsf(det) >= 1e-2f);
   if (use_pinv) {
-    if (l == 0) sym_pinv6_serial(&o.Li[0][0], &o.Lam[0][0], &o.V[0][0], o.w, o.Awork, 1e-2f);
+    if (l == 0) sym_pinv6_serial(&o.Li[0][0], &o.Lam[0][0], &o.V[0][0], o.w, &o.Jbar[0][0] /* free until Jbar is formed */, 1e-2f);
     __syncthreads();
   }
   if (l < 6) {

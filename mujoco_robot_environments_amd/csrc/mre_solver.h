@@ -49,10 +49,10 @@ MRE_DEV void geom_pose(const DevModel* M, const Sm& s, int g, float* p, float* R
 // (dist < margin - gap), in pair order, capped at NCON_MAX.
 MRE_PHASE_FN void collide(const DevModel* M, Sm& s, int l) {
   // per-lane clip buffers alias the Jacobian pools (contiguous Jp|Jr|Br, unused until assembly)
-  static_assert(offsetof(Sm, Jr) == offsetof(Sm, Jp) + sizeof(float) * NEFC_MAX * 13, "Jp|Jr must be contiguous");
-  static_assert(offsetof(Sm, Br) == offsetof(Sm, Jr) + sizeof(float) * NRROW_MAX * NRV, "Jr|Br must be contiguous");
-  static_assert(NEFC_MAX * 13 + 2 * NRROW_MAX * NRV >= 64 * COLL_BUF, "clip buffers do not fit");
-  float* buf = &s.Jp[0][0] + l * COLL_BUF;
+  // [JpA .. sched] is one contiguous block of arrays that are only written after collision
+  static_assert(offsetof(Sm, sched) + sizeof(((Sm*)0)->sched) - offsetof(Sm, JpA) >= sizeof(float) * 64 * COLL_BUF,
+                "clip buffers do not fit");
+  float* buf = &s.JpA[0][0] + l * COLL_BUF;
   float normal[3] = {0.f, 0.f, 1.f};
   int n = 0;
   const int g1 = M->pair_g1[l], g2 = M->pair_g2[l];
@@ -142,11 +142,17 @@ MRE_DEV void jac_robot(const DevModel* M, Sm& s, int rs, int b, const float* p, 
     s.Jr[rs][j] += sg * (ax[0] * (c[3] + t[0]) + ax[1] * (c[4] + t[1]) + ax[2] * (c[5] + t[2]));
   }
 }
-// same for a cube body into Jp[i][slot*6 ..]
+// prop parts of contact row i: part A (first cube of the contact) is indexed by contact row,
+// part B exists only for cube-cube contacts (slot con_bslot)
+MRE_DEV float* jpA(Sm& s, int i) { return s.JpA[i - 7 - s.nl]; }
+MRE_DEV const float* jpA(const Sm& s, int i) { return s.JpA[i - 7 - s.nl]; }
+MRE_DEV float* jpB(Sm& s, int i) { const int cr = i - 7 - s.nl; return s.JpB[3 * s.con_bslot[cr / 3] + cr % 3]; }
+MRE_DEV const float* jpB(const Sm& s, int i) { const int cr = i - 7 - s.nl; return s.JpB[3 * s.con_bslot[cr / 3] + cr % 3]; }
+// same for a cube body into the prop part `slot` of row i
 MRE_DEV void jac_prop(Sm& s, int i, int slot, int b, const float* p, const float* ax, float sg) {
   float off[3];
   v3sub(off, p, s.xpos[b]);
-  float* J = &s.Jp[i][slot * 6];
+  float* J = slot == 0 ? jpA(s, i) : jpB(s, i);
   for (int k = 0; k < 3; k++) {
     J[k] = sg * ax[k];
     float axk[3] = {s.xmat[b][k], s.xmat[b][3 + k], s.xmat[b][6 + k]}, t[3];
@@ -163,9 +169,9 @@ MRE_DEV float row_dot(const Sm& s, int i, const float* vec) {
   if (rs != HDR_NONE)
     for (int j = 0; j < NRV; j++) acc += s.Jr[rs][j] * vec[j];
   if (pa < NPROP)
-    for (int k = 0; k < 6; k++) acc += s.Jp[i][k] * vec[NRV + 6 * pa + k];
+    { const float* ja = jpA(s, i); for (int k = 0; k < 6; k++) acc += ja[k] * vec[NRV + 6 * pa + k]; }
   if (pb < NPROP)
-    for (int k = 0; k < 6; k++) acc += s.Jp[i][6 + k] * vec[NRV + 6 * pb + k];
+    { const float* jb = jpB(s, i); for (int k = 0; k < 6; k++) acc += jb[k] * vec[NRV + 6 * pb + k]; }
   return acc;
 }
 
@@ -188,17 +194,22 @@ MRE_PHASE_FN void assemble_constraints(const DevModel* M, Sm& s, int l) {
   // ---- robot-slot assignment and capacity (serial, lane 0)
   if (l == 0) {
     const int base = 7 + s.nl;
-    int rnext = base, ncon = s.ncon, kept = 0;
+    int rnext = base, ncon = s.ncon, kept = 0, bnext = 0;
     for (int c = 0; c < ncon; c++) {
       const int pr = s.con_pair[c];
-      const bool rob = M->geom_body[M->pair_g1[pr]] < NRB && M->geom_body[M->pair_g1[pr]] > 0;
-      const bool rob2 = M->geom_body[M->pair_g2[pr]] < NRB && M->geom_body[M->pair_g2[pr]] > 0;
-      if (base + 3 * (c + 1) > NEFC_MAX || ((rob || rob2) && rnext + 3 > NRROW_MAX)) {
+      const int cb1 = M->geom_body[M->pair_g1[pr]], cb2 = M->geom_body[M->pair_g2[pr]];
+      const bool rob = cb1 < NRB && cb1 > 0;
+      const bool rob2 = cb2 < NRB && cb2 > 0;
+      const bool two_props = cb1 >= NRB && cb2 >= NRB;
+      if (base + 3 * (c + 1) > NEFC_MAX || ((rob || rob2) && rnext + 3 > NRROW_MAX) ||
+          (two_props && bnext >= NPP_MAX)) {
         s.overflow = 1;
         break;
       }
       s.con_rslot[c] = (rob || rob2) ? rnext : HDR_NONE;
       if (rob || rob2) rnext += 3;
+      s.con_bslot[c] = two_props ? bnext : 0;
+      if (two_props) bnext++;
       kept++;
     }
     s.ncon = kept;
@@ -218,7 +229,6 @@ MRE_PHASE_FN void assemble_constraints(const DevModel* M, Sm& s, int l) {
     const float *solref, *solimp;
     bool fric_row = false;
     float R0scale = 1.0f;
-    for (int k = 0; k < 12; k++) s.Jp[i][k] = 0.f;
     if (i < 7) {
       rs = i;
       const int e = i < 6 ? i / 3 : 2;
@@ -309,7 +319,7 @@ MRE_PHASE_FN void assemble_constraints(const DevModel* M, Sm& s, int l) {
     const float vel = row_dot(s, i, s.qvel);
     const float efc_margin = fric_row ? 0.f : margin;
     const float aref = -B * vel - K * imp * (pos - efc_margin);
-    s.rowdata[i] = make_float4(R, aref, 0.f, 0.f);
+    s.rowR[i] = R; s.rowB[i] = aref;
   }
   __syncthreads();
   // ---- Br = M^-1 Jr' (lane = robot slot, serial sparse solve in place)
@@ -339,20 +349,18 @@ MRE_PHASE_FN void assemble_constraints(const DevModel* M, Sm& s, int l) {
           for (int j = 0; j < NRV; j++) a += s.Jr[rs][j] * s.Br[rs2][j];
         }
         if (pa < NPROP)
-          for (int k = 0; k < 6; k++) a += s.Jp[i][k] * s.Jp[i0 + cc][k] * prop_invM(s, pa, k);
+          { const float *x = jpA(s, i), *y = jpA(s, i0 + cc); for (int k = 0; k < 6; k++) a += x[k] * y[k] * prop_invM(s, pa, k); }
         if (pb < NPROP)
-          for (int k = 0; k < 6; k++) a += s.Jp[i][6 + k] * s.Jp[i0 + cc][6 + k] * prop_invM(s, pb, k);
+          { const float *x = jpB(s, i), *y = jpB(s, i0 + cc); for (int k = 0; k < 6; k++) a += x[k] * y[k] * prop_invM(s, pb, k); }
       }
       acc[cc] = a;
     }
-    float4 rd = s.rowdata[i];
-    const float diag = (r == 0 ? acc[0] : (r == 1 ? acc[1] : acc[2])) + rd.x;
+    const float diag = (r == 0 ? acc[0] : (r == 1 ? acc[1] : acc[2])) + s.rowR[i];
     if (r == 0) acc[0] = scalar ? acc[0] : diag;
     if (r == 1) acc[1] = scalar ? acc[1] : diag;
     if (r == 2) acc[2] = scalar ? acc[2] : diag;
     s.Ablk[slot][3 * r] = acc[0]; s.Ablk[slot][3 * r + 1] = acc[1]; s.Ablk[slot][3 * r + 2] = acc[2];
-    rd.w = 1.0f / diag;
-    s.rowdata[i] = rd;
+    s.rowAinv[i] = 1.0f / diag;
   }
   __syncthreads();
 }
@@ -408,7 +416,7 @@ MRE_DEV void lane_JB(const Sm& s, int row, int rs, int l, int lk, int slot, floa
   if (l < NRV) {
     if (rs != BLK_NONE) { j = s.Jr[rs][l]; b = s.Br[rs][l]; }
   } else if (slot >= 0) {
-    j = s.Jp[row][slot * 6 + lk];
+    j = (slot == 0 ? jpA(s, row) : jpB(s, row))[lk];
     b = j * linvM;
   }
 }
@@ -421,6 +429,7 @@ MRE_DEV int blk_pa(int info) { return (info >> 16) & 0xF; }
 MRE_DEV int blk_pb(int info) { return (info >> 20) & 0xF; }
 MRE_DEV int blk_primary(int info) { return (info >> 24) & 0x7; }
 MRE_DEV int blk_nrows(int info) { return (info >> 27) & 0x3; }
+MRE_DEV int blk_bslot(int info) { return (info >> 29) & 0x7; }
 
 
 // Build the block list (global MuJoCo row order) and its ASAP schedule: block b runs at
@@ -459,7 +468,8 @@ MRE_DEV void build_schedule(const DevModel* M, Sm& s) {
     if (st + 1 > nst) nst = st + 1;
     const int rsl = hr ? rs : BLK_NONE;
     const int prim = hr ? 0 : 1 + pa;
-    s.blk_info[nb++] = 2 | ((nscalar + 3 * c) << 2) | (rsl << 9) | (pa << 16) | (pb << 20) | (prim << 24) | (3 << 27);
+    const int bsl = hb ? s.con_bslot[c] : 0;
+    s.blk_info[nb++] = 2 | ((nscalar + 3 * c) << 2) | (rsl << 9) | (pa << 16) | (pb << 20) | (prim << 24) | (3 << 27) | (bsl << 29);
   }
   s.nblk = nb;
   s.nsched = nst;
@@ -479,22 +489,20 @@ MRE_PHASE_FN void solve_constraints(const DevModel* M, Sm& s, int l) {
   float* jar = s.jar;
   // ---- efc_b and warm-start forces (mj_constraintUpdate on J*qacc_warmstart - aref)
   for (int i = l; i < nefc; i += 64) {
-    float4 rd = s.rowdata[i];
-    const float aref = rd.y;
+    const float aref = s.rowB[i];
     jar[i] = row_dot(s, i, s.qacc_ws) - aref;
-    rd.y = row_dot(s, i, s.qacc_smooth) - aref;
-    s.rowdata[i] = rd;
+    s.rowB[i] = row_dot(s, i, s.qacc_smooth) - aref;
   }
   __syncthreads();
   for (int i = l; i < nefc; i += 64) {
-    const float D = 1.0f / s.rowdata[i].x;
+    const float D = 1.0f / s.rowR[i];
     if (i < 7) s.frc[i] = -D * jar[i];
     else if (i < 7 + nl) s.frc[i] = jar[i] < 0.f ? -D * jar[i] : 0.f;
     else if ((i - 7 - nl) % 3 == 0) {
       const int c = (i - 7 - nl) / 3;
       const float fr0 = s.con_fric[c];
-      const float D1 = 1.0f / s.rowdata[i + 1].x, D2 = 1.0f / s.rowdata[i + 2].x;
-      const float mu = fr0 * sqrtf(s.rowdata[i + 1].x / s.rowdata[i].x);
+      const float D1 = 1.0f / s.rowR[i + 1], D2 = 1.0f / s.rowR[i + 2];
+      const float mu = fr0 * sqrtf(s.rowR[i + 1] / s.rowR[i]);
       const float j0 = jar[i], j1 = jar[i + 1], j2 = jar[i + 2];
       const float U0 = j0 * mu, U1 = j1 * fr0, U2 = j2 * fr0;
       const float N = U0, T = sqrtf(U1 * U1 + U2 * U2);
@@ -533,10 +541,9 @@ MRE_PHASE_FN void solve_constraints(const DevModel* M, Sm& s, int l) {
   // dual cost 0.5 f'ARf + f'b ; cold start if positive
   float part = 0.f;
   for (int i = l; i < nefc; i += 64) {
-    const float4 rd = s.rowdata[i];
     const float fi = s.frc[i];
-    const float Af = row_dot(s, i, s.scratch) + rd.x * fi;
-    part += fi * (0.5f * Af + rd.y);
+    const float Af = row_dot(s, i, s.scratch) + s.rowR[i] * fi;
+    part += fi * (0.5f * Af + s.rowB[i]);
   }
   const float cost = wave_sum(part);
   __syncthreads();
@@ -575,9 +582,9 @@ MRE_PHASE_FN void solve_constraints(const DevModel* M, Sm& s, int l) {
       // pointer / stride (a zero pad for lanes or rows that do not take part), then masks
       const bool rob_lane = l < NRV, rob_row = rs != BLK_NONE;
       const bool take = on && lvalid && (rob_lane ? rob_row : (slot >= 0));
-      const float* jptr = take ? (rob_lane ? &s.Jr[rs][l] : &s.Jp[row0][slot * 6 + lk]) : s.zpad;
+      const float* jptr = take ? (rob_lane ? &s.Jr[rs][l] : (slot == 0 ? &s.JpA[row0 - nscalar][lk] : &s.JpB[3 * blk_bslot(info)][lk])) : s.zpad;
       const float* bptr = (take && rob_lane) ? &s.Br[rs][l] : s.zpad;
-      const int jstr = take ? (rob_lane ? NRV : 13) : 0;
+      const int jstr = take ? (rob_lane ? NRV : 6) : 0;
       const int bstr = (take && rob_lane) ? NRV : 0;
       // (select, not multiply: rows past the block may hold stale non-finite LDS contents)
       const bool h1 = nr > 1, h2 = nr > 2;
@@ -585,7 +592,9 @@ MRE_PHASE_FN void solve_constraints(const DevModel* M, Sm& s, int l) {
       float b0 = bptr[0], b1 = h1 ? bptr[bstr] : 0.f, b2 = h2 ? bptr[2 * bstr] : 0.f;
       if (!rob_lane) { b0 = j0 * linvM; b1 = j1 * linvM; b2 = j2 * linvM; }
       const int ra = row0, rb = (nr > 1) ? row0 + 1 : row0, rc = (nr > 2) ? row0 + 2 : row0;
-      const float4 r0 = s.rowdata[ra], r1 = s.rowdata[rb], r2 = s.rowdata[rc];
+      const float4 r0 = make_float4(s.rowR[ra], s.rowB[ra], 0.f, s.rowAinv[ra]);
+      const float4 r1 = make_float4(s.rowR[rb], s.rowB[rb], 0.f, s.rowAinv[rb]);
+      const float4 r2 = make_float4(s.rowR[rc], s.rowB[rc], 0.f, s.rowAinv[rc]);
       const float f0 = s.frc[ra], f1 = h1 ? s.frc[rb] : 0.f, f2 = h2 ? s.frc[rc] : 0.f;
       float p0 = island_sum(j0 * a), p1 = island_sum(j1 * a), p2 = island_sum(j2 * a);
       if (__any(partner != l)) {
