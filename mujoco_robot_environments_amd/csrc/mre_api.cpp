@@ -152,6 +152,7 @@ static int build_model(const void* blob, size_t nbytes, DevModel& m) {
     for (int k = 0; k < NPAIR; k++) { m.pair_g1[k] = -1; m.pair_g2[k] = -1; }
     for (int k = 0; k < npair; k++) { m.pair_g1[k] = pg[2 * k]; m.pair_g2[k] = pg[2 * k + 1]; }
   }
+  RI("pair_single", m.pair_single, npair);
   RF("pair_friction", m.pair_friction, npair * 3); RF("pair_solref", m.pair_solref, npair * 2);
   RF("pair_solimp", m.pair_solimp, npair * 5); RF("pair_margin", m.pair_margin, npair);
   RF("pair_gap", m.pair_gap, npair);

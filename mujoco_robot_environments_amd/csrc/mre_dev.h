@@ -54,7 +54,7 @@ struct DevModel {
   // ---- geoms / pairs / sites
   int geom_type[NG], geom_body[NG], geom_propid[NG];
   float geom_size[NG][3], geom_pos[NG][3], geom_quat[NG][4], geom_rbound[NG];
-  int pair_g1[NPAIR], pair_g2[NPAIR];
+  int pair_g1[NPAIR], pair_g2[NPAIR], pair_single[NPAIR];
   float pair_friction[NPAIR][3], pair_solref[NPAIR][2], pair_solimp[NPAIR][5];
   float pair_margin[NPAIR], pair_gap[NPAIR];
   int site_body[NSITE];

@@ -72,6 +72,16 @@ MRE_PHASE_FN void collide(const DevModel* M, Sm& s, int l) {
         const float r = rb1 + rb2 + inc;
         if (v3dot(df, df) <= r * r) n = box_box(p1, R1, s1, p2, R2, s2, inc, normal, buf);
       }
+      // mesh stand-in pairs keep one contact (deepest point), like MuJoCo's convex-mesh test
+      if (M->pair_single[l] && n > 1) {
+        int best = 0;
+        for (int c = 1; c < n; c++) if (cand_dist(buf, c) < cand_dist(buf, best)) best = c;
+        if (best != 0) {
+          for (int k = 0; k < 3; k++) cand_xyz(buf, 0)[k] = cand_xyz(buf, best)[k];
+          cand_dist(buf, 0) = cand_dist(buf, best);
+        }
+        n = 1;
+      }
       // instantiate only contacts with dist < includemargin
       int m = 0;
       for (int c = 0; c < n; c++)

@@ -31,7 +31,7 @@ import numpy as np
 from . import spec as _spec
 
 BLOB_MAGIC = 0x4D524542  # 'MREB'
-BLOB_VERSION = 3
+BLOB_VERSION = 4
 
 JNT_NONE, JNT_HINGE, JNT_FREE = 0, 1, 2
 GEOM_PLANE, GEOM_BOX = 0, 1
@@ -449,10 +449,14 @@ def compile_scene(scene: dict = None) -> Dict[str, np.ndarray]:
     pair_solimp = np.zeros((npair, 5))
     pair_margin = np.zeros(npair)
     pair_gap = np.zeros(npair)
+    pair_single = np.zeros(npair, np.int32)
     for k, (g1, g2) in enumerate(pairs):
         c, fr, sr, si, mg, gp = _mix_pair(geoms[g1], geoms[g2])
         pair_condim[k], pair_friction[k], pair_solref[k] = c, fr, sr
         pair_solimp[k], pair_margin[k], pair_gap[k] = si, mg, gp
+        # hull geoms stand in for convex collision MESHES: MuJoCo's mesh narrow phase (mjc_Convex,
+        # multiccd off) returns ONE contact per pair -> keep only the deepest point of the box test
+        pair_single[k] = int(bool(geoms[g1]["hull"] or geoms[g2]["hull"]))
         assert c == 3, "kernels implement condim 3 (all geoms of this scene)"
 
     A.update(
@@ -474,7 +478,7 @@ def compile_scene(scene: dict = None) -> Dict[str, np.ndarray]:
         geom_propid=geom_propid,
         pair_geom=pair_geom, pair_condim=pair_condim, pair_friction=pair_friction,
         pair_solref=pair_solref, pair_solimp=pair_solimp, pair_margin=pair_margin,
-        pair_gap=pair_gap,
+        pair_gap=pair_gap, pair_single=pair_single,
         site_bodyid=np.array(site_body, np.int32),
         site_pos=np.array([s["pos"] for s in sites], dtype=np.float64).reshape(-1, 3),
         site_quat=np.array([s["quat"] for s in sites], dtype=np.float64).reshape(-1, 4),

@@ -46,7 +46,7 @@ struct mro_model {
   int geom_type[MRO_MAXG], geom_bodyid[MRO_MAXG], geom_propid[MRO_MAXG];
   double geom_size[MRO_MAXG][3], geom_pos[MRO_MAXG][3], geom_quat[MRO_MAXG][4],
       geom_rbound[MRO_MAXG];
-  int pair_geom[MRO_MAXPAIR][2];
+  int pair_geom[MRO_MAXPAIR][2], pair_single[MRO_MAXPAIR];
   double pair_friction[MRO_MAXPAIR][3], pair_solref[MRO_MAXPAIR][2], pair_solimp[MRO_MAXPAIR][5],
       pair_margin[MRO_MAXPAIR], pair_gap[MRO_MAXPAIR];
   int site_bodyid[MRO_MAXS];
@@ -284,7 +284,7 @@ mro_model* mro_model_load(const void* blob, size_t nbytes) {
   LI(geom_type, MRO_MAXG); LI(geom_bodyid, MRO_MAXG); LI(geom_propid, MRO_MAXG);
   LD(geom_size, MRO_MAXG * 3); LD(geom_pos, MRO_MAXG * 3); LD(geom_quat, MRO_MAXG * 4);
   LD(geom_rbound, MRO_MAXG);
-  LI(pair_geom, MRO_MAXPAIR * 2); LD(pair_friction, MRO_MAXPAIR * 3);
+  LI(pair_geom, MRO_MAXPAIR * 2); LI(pair_single, MRO_MAXPAIR); LD(pair_friction, MRO_MAXPAIR * 3);
   LD(pair_solref, MRO_MAXPAIR * 2); LD(pair_solimp, MRO_MAXPAIR * 5);
   LD(pair_margin, MRO_MAXPAIR); LD(pair_gap, MRO_MAXPAIR);
   LI(site_bodyid, MRO_MAXS); LD(site_pos, MRO_MAXS * 3); LD(site_quat, MRO_MAXS * 4);
@@ -783,7 +783,14 @@ static void collision(const mro_model* m, mro_data* d) {
       double normal[3], pos[24], dist[8];
       int n = mro_boxbox(d->geom_xpos[g1], d->geom_xmat[g1], d->geom_size[g1], d->geom_xpos[g2],
                          d->geom_xmat[g2], d->geom_size[g2], margin, normal, pos, dist);
-      for (int c = 0; c < n; c++) add_contact(m, d, k, pos + 3 * c, normal, dist[c]);
+      if (m->pair_single[k] && n > 1) {
+        /* mesh stand-in: one contact per pair (deepest point), like mjc_Convex */
+        int best = 0;
+        for (int c = 1; c < n; c++) if (dist[c] < dist[best]) best = c;
+        add_contact(m, d, k, pos + 3 * best, normal, dist[best]);
+      } else {
+        for (int c = 0; c < n; c++) add_contact(m, d, k, pos + 3 * c, normal, dist[c]);
+      }
     }
   }
 }
