@@ -49,6 +49,7 @@ struct mre_env {
   uint32_t* status = nullptr;
   int* stats = nullptr;
   OscConfig osc;
+  OscConfig* d_osc = nullptr;
   float* trace = nullptr;
   int trace_nenv = 0, trace_max = 0, trace_pos = 0;
   long long env_id_offset = 0;
@@ -272,6 +273,8 @@ extern "C" int mre_create(const void* blob, size_t nbytes, int num_envs, int dev
   // OSC defaults (osc.yaml:5-22)
   e->osc = OscConfig{350.f, 20.f, 500.f, 100.f, 200.f, 30.f, {0.f, -0.785f, 0.f, -2.356f, 0.f, 1.571f, 0.785f},
                      5e-3f, 68e-3f, 0};
+  HIPCHK(hipMalloc(&e->d_osc, sizeof(OscConfig)));
+  HIPCHK(hipMemcpy(e->d_osc, &e->osc, sizeof(OscConfig), hipMemcpyHostToDevice));
   *out = e;
   rc = mre_reset(e, nullptr);
   if (rc != MRE_OK) return rc;
@@ -283,7 +286,7 @@ extern "C" int mre_destroy(mre_env* e) {
   (void)hipSetDevice(e->device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   void* ptrs[] = {e->dM, e->qpos, e->qvel, e->qacc_ws, e->ctrl, e->nprops, e->prop_size, e->osc_target,
-                  e->grip_closed, e->converged, e->mask, e->sites, e->status, e->stats};
+                  e->grip_closed, e->converged, e->mask, e->sites, e->status, e->stats, e->d_osc};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
@@ -366,7 +369,7 @@ static void fill_args(mre_env* e, StepArgs& a) {
   a.qpos = e->qpos; a.qvel = e->qvel; a.qacc_ws = e->qacc_ws; a.ctrl = e->ctrl;
   a.nprops = e->nprops; a.prop_size = e->prop_size;
   a.control_steps = 1; a.mode = CTRL_HELD;
-  a.osc = e->osc; a.osc_target = e->osc_target; a.grip_closed = e->grip_closed;
+  a.osc = e->d_osc; a.osc_target = e->osc_target; a.grip_closed = e->grip_closed;
   a.sites = e->sites; a.status = e->status; a.stats = e->stats;
   a.trace = e->trace; a.trace_nenv = e->trace_nenv; a.trace_max = e->trace_max; a.trace_base = e->trace_pos;
 }
@@ -423,6 +426,8 @@ extern "C" int mre_osc_configure(mre_env* e, const float* gains, const float* nu
   if (null_q) for (int k = 0; k < 7; k++) e->osc.null_q[k] = null_q[k];
   if (thr) { e->osc.pos_thresh = thr[0]; e->osc.ori_thresh = thr[1]; }
   e->osc.pinv_always = pinv_always;
+  HIPCHK(hipStreamSynchronize(e->stream));
+  HIPCHK(hipMemcpy(e->d_osc, &e->osc, sizeof(OscConfig), hipMemcpyHostToDevice));
   return MRE_OK;
 }
 

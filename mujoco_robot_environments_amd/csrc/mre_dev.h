@@ -98,7 +98,7 @@ struct StepArgs {
   int nsteps, control_steps, mode;
   unsigned flags;
   // OSC
-  OscConfig osc;
+  const OscConfig* osc;      // device copy of the controller parameters
   const float* osc_target;   // [N][16]: pos3 quat4 vel3 angvel3 pad3
   const uint8_t* grip_closed;  // [N]
   uint8_t* converged;        // [N] or null

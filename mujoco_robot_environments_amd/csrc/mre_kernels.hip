@@ -88,7 +88,7 @@ MRE_DEV bool body_is_active(const DevModel* M, const Sm& s, int b) {
 }
 
 // ------------------------------------------------------------ mj_kinematics
-MRE_PHASE_FN void kinematics(const DevModel* M, Sm& s, int l, BodyRegs& br) {
+MRE_DEV void kinematics(const DevModel* M, Sm& s, int l, BodyRegs& br) {
   if (l == 0) {
     v3zero(s.xpos[0]);
     s.xquat[0][0] = 1.f; s.xquat[0][1] = s.xquat[0][2] = s.xquat[0][3] = 0.f;
@@ -191,6 +191,21 @@ MRE_DEV void com_pos(const DevModel* M, Sm& s, int l, const BodyRegs& br) {
     // (each cube is its own tree, c-frame origin = its COM) -- see prop_cdof()
   }
   if (l == 0) for (int k = 0; k < 10; k++) s.cinert[0][k] = 0.f;
+}
+
+// S1a: kinematics + comPos as one real function so that the per-lane body frame registers
+// (anchor, axis, inertial frame) never leave the register file
+MRE_PHASE_FN void position_stage(const DevModel* M, Sm& s, int l) {
+  BodyRegs br;
+  kinematics(M, s, l, br);
+  com_pos(M, s, l, br);
+  __syncthreads();
+}
+// kinematics only (site queries at the end of a launch)
+MRE_PHASE_FN void kinematics_only(const DevModel* M, Sm& s, int l) {
+  BodyRegs br;
+  kinematics(M, s, l, br);
+  __syncthreads();
 }
 
 // cdof of cube body b, local dof j (mju_dofCom with zero offset)
@@ -498,13 +513,10 @@ __global__ __launch_bounds__(64, 2) void k_step(StepArgs a) {
     grip_cmd = a.grip_closed[env] ? M->act_ctrlrange[NU - 1][1] : M->act_ctrlrange[NU - 1][0];
     __syncthreads();
   }
-  BodyRegs br;
   for (int step = 0; step < a.nsteps; ++step) {
     // ------------------------------------------------ S1: position stage
 
-    kinematics(M, s, l, br);
-    com_pos(M, s, l, br);
-    __syncthreads();
+    position_stage(M, s, l);
     crb_mass_matrix(M, s, l);
     __syncthreads();
     for (int e = l; e < NMR; e += 64) s.qLD[e] = s.qM[e];
@@ -555,8 +567,7 @@ __global__ __launch_bounds__(64, 2) void k_step(StepArgs a) {
     }
   }
   // ---- final kinematics for site queries
-  kinematics(M, s, l, br);
-  __syncthreads();
+  kinematics_only(M, s, l);
   if (a.mode == CTRL_OSC && a.nsteps > 0) {
     if (osc_converged(M, s, a.osc, s.osc_tgt)) arm_converged = true;
     if (l == 0) {

@@ -97,14 +97,16 @@ MRE_DEV void osc_errors(const DevModel* M, const Sm& s, const float* tgt, float*
   eo[0] = sg * qe[1]; eo[1] = sg * qe[2]; eo[2] = sg * qe[3];
 }
 
-MRE_DEV bool osc_converged(const DevModel* M, const Sm& s, const OscConfig& c, const float* tgt) {
+MRE_DEV bool osc_converged(const DevModel* M, const Sm& s, const OscConfig* cp, const float* tgt) {
+  const OscConfig& c = *cp;
   float ep[3], eo[3];
   osc_errors(M, s, tgt, ep, eo);
   return v3norm(ep) < c.pos_thresh && v3norm(eo) < c.ori_thresh;
 }
 
 // writes s.ctrl[0..6]; tgt = [pos3 quat4 vel3 angvel3] (uniform pointer into LDS)
-MRE_PHASE_FN void osc_compute(const DevModel* M, Sm& s, OscSm& o, const OscConfig& c, const float* tgt, int l) {
+MRE_PHASE_FN void osc_compute(const DevModel* M, Sm& s, OscSm& o, const OscConfig* cp, const float* tgt, int l) {
+  const OscConfig& c = *cp;
   const int st = M->eef_site;
   // J (lane = r*7+a) and dense arm mass block (lane = i*7+j)
   if (l < 42) {
