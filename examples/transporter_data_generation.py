@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""BASELINE.json configs[4]: the reference's data-generation loop
+(mujoco_robot_environments/transporter_network_data_generation.py:97-143) driving thousands of
+RearrangementEnv instances on one MI355X.  Rendering and envlogger/TFDS writing are stubbed
+(out of scope): observations are zero images of the reference shapes and
+the "dataset" is the list of (pick, place) actions with their pixel coordinates.
+
+    python examples/transporter_data_generation.py --num-envs 8192 --max-steps 2
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from mujoco_robot_environments_amd.tasks.rearrangement import (  # noqa: E402
+    BatchedRearrangementEnv, colour_separator_task_config)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--num-envs", type=int, default=8192)
+    ap.add_argument("--max-steps", type=int, default=None, help="pick/place pairs per episode (config: dataset.max_steps)")
+    args = ap.parse_args()
+    cfg = colour_separator_task_config()
+    max_steps = args.max_steps or cfg.dataset.max_steps
+    env = BatchedRearrangementEnv(cfg=cfg, num_envs=args.num_envs)
+    cam = "overhead_camera/overhead_camera"
+    t0 = time.time()
+    _, _, _, obs = env.reset()
+    metadata = env.get_camera_metadata()  # episode metadata of the reference (calibration_metadata)
+    episodes = []
+    for step in range(max_steps):
+        in_progress, pick_pose, place_pose = env.sort_colours()
+        if not in_progress.any():
+            print("Task demonstration is complete")
+            break
+        pick_action = {"pose": pick_pose, "pixel_coords": env.world_2_pixel(cam, pick_pose[:, :3]), "gripper_rot": 0.0}
+        place_action = {"pose": place_pose, "pixel_coords": env.world_2_pixel(cam, place_pose[:, :3]), "gripper_rot": 0.0}
+        _, _, _, obs = env.step(pick_action)
+        _, _, _, obs = env.step(place_action)
+        episodes.append((pick_action, place_action))
+        nsim = 2 * 9000
+        print(f"pair {step}: {in_progress.sum()} envs in progress, all phases converged in "
+              f"{int(env.last_converged.sum())}/{args.num_envs} envs, "
+              f"{args.num_envs * nsim / (time.time() - t0):.3g} env-steps/s so far")
+    done = ~env.sort_colours()[0]
+    print(f"{int(done.sum())}/{args.num_envs} envs have every cube in its colour's target after {len(episodes)} pairs; "
+          f"intrinsics fx={metadata['intrinsics']['fx']:.1f}; wall {time.time() - t0:.1f} s")
+    env.close()
+
+
+if __name__ == "__main__":
+    main()

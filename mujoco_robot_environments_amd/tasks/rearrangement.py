@@ -330,7 +330,8 @@ class BatchedRearrangementEnv:
         lo = np.asarray(ws.min_pose if min_pose is None else min_pose, np.float64)
         hi = np.asarray(ws.max_pose if max_pose is None else max_pose, np.float64)
         p = prop_id - PROP_GEOM_ID0
-        rb = np.linalg.norm(self.prop_half_size[i], axis=1)
+        # cubes lie flat on the table: footprint circum-radius sqrt(2)*s bounds the box distance
+        rb = np.sqrt(2.0) * self.prop_half_size[i].max(axis=1)
         quat = home_quat()
         for att in range(10000):
             u = rng.uniform(self.seed + 1, [int(self.env_ids[i])], [self._place_count * 10000 + att], 3)[0, 0]
@@ -369,7 +370,11 @@ class BatchedRearrangementEnv:
         pick = np.zeros((self.num_envs, 7))
         place = np.zeros((self.num_envs, 7))
         for i in range(self.num_envs):
-            ip, a, b = self.sort_colours_env(i, self.props_info_env(i, poses))
+            try:
+                ip, a, b = self.sort_colours_env(i, self.props_info_env(i, poses))
+            except Exception as e:  # reference: the caller abandons the episode (data generation :137-139)
+                ip, a, b = False, None, None
+                self.failed_phase[i] = str(e)
             prog[i] = ip
             if ip:
                 pick[i], place[i] = a, b

@@ -70,7 +70,7 @@ typedef struct {
 
 struct mro_data {
   /* per-env model parameters */
-  int nprops, freeze_robot, no_constraints, ncon_cap, nefc_cap;
+  int nprops, freeze_robot, no_constraints, ncon_cap, nefc_cap, nrrow_cap, npp_cap, overflow;
   int body_active[MRO_MAXB], dof_active[MRO_MAXV];
   double body_mass[MRO_MAXB], body_inertia[MRO_MAXB][3], body_invweight0[MRO_MAXB][2],
       dof_invweight0[MRO_MAXV], geom_size[MRO_MAXG][3], geom_rbound[MRO_MAXG];
@@ -363,7 +363,10 @@ void mro_data_free(mro_data* d) {
 }
 void mro_set_freeze_robot(mro_data* d, int f) { d->freeze_robot = f; }
 void mro_set_no_constraints(mro_data* d, int f) { d->no_constraints = f; }
-void mro_set_caps(mro_data* d, int ncon_cap, int nefc_cap) { d->ncon_cap = ncon_cap; d->nefc_cap = nefc_cap; }
+void mro_set_caps(mro_data* d, int ncon_cap, int nefc_cap, int nrrow_cap, int npp_cap) {
+  d->ncon_cap = ncon_cap; d->nefc_cap = nefc_cap; d->nrrow_cap = nrrow_cap; d->npp_cap = npp_cap;
+}
+int mro_overflow(const mro_data* d) { return d->overflow; }
 int mro_solver_iters(const mro_data* d) { return d->solver_iters; }
 int mro_ncon(const mro_data* d) { return d->ncon; }
 int mro_nefc(const mro_data* d) { return d->nefc; }
@@ -878,23 +881,38 @@ static void make_constraint(const mro_model* m, mro_data* d) {
     }
   }
   d->nl = d->nefc - d->ne;
-  /* contacts (mj_instantiateContact, elliptic cones, condim 3) */
-  for (int c = 0; c < d->ncon; c++) {
-    mro_contact_t* con = &d->contact[c];
-    con->efc_address = -1;
-    if (con->dist >= con->includemargin) continue;
-    if (d->nefc + 3 > MRO_MAXEFC) break;
-    jac_point(m, d, con->body1, con->pos, jp1, NULL);
-    jac_point(m, d, con->body2, con->pos, jp2, NULL);
-    double da = d->body_invweight0[con->body1][0] + d->body_invweight0[con->body2][0];
-    con->efc_address = d->nefc;
-    for (int r = 0; r < 3; r++) {
-      const double* ax = con->frame + 3 * r;
-      for (int i = 0; i < nv; i++)
-        J[i] = ax[0] * (jp2[i] - jp1[i]) + ax[1] * (jp2[nv + i] - jp1[nv + i]) +
-               ax[2] * (jp2[2 * nv + i] - jp1[2 * nv + i]);
-      add_row(d, EFC_CONTACT, c, J, nv, r == 0 ? con->dist : 0.0,
-              r == 0 ? con->includemargin : 0.0, da);
+  /* contacts (mj_instantiateContact, elliptic cones, condim 3).  Optional capacity emulation of
+   * the device kernels (mro_set_caps): the first ncon_cap ACTIVE contacts are candidates; the list
+   * is cut at the first contact that would exceed the row / robot-row / cube-cube capacities. */
+  d->overflow = 0;
+  {
+    int nact = 0, rrows = d->nefc, npp = 0, stop = 0;
+    for (int c = 0; c < d->ncon; c++) {
+      mro_contact_t* con = &d->contact[c];
+      con->efc_address = -1;
+      if (con->dist >= con->includemargin || stop) continue;
+      if (d->ncon_cap > 0 && nact >= d->ncon_cap) { d->overflow = 1; stop = 1; continue; }
+      int rob = (con->body1 > 0 && m->body_propid[con->body1] < 0) || (con->body2 > 0 && m->body_propid[con->body2] < 0);
+      int two = m->body_propid[con->body1] >= 0 && m->body_propid[con->body2] >= 0;
+      if ((d->nefc_cap > 0 && d->nefc + 3 > d->nefc_cap) || (d->nrrow_cap > 0 && rob && rrows + 3 > d->nrrow_cap) ||
+          (d->npp_cap > 0 && two && npp >= d->npp_cap) || d->nefc + 3 > MRO_MAXEFC) {
+        d->overflow = 1; stop = 1; continue;
+      }
+      nact++;
+      if (rob) rrows += 3;
+      if (two) npp++;
+      jac_point(m, d, con->body1, con->pos, jp1, NULL);
+      jac_point(m, d, con->body2, con->pos, jp2, NULL);
+      double da = d->body_invweight0[con->body1][0] + d->body_invweight0[con->body2][0];
+      con->efc_address = d->nefc;
+      for (int r = 0; r < 3; r++) {
+        const double* ax = con->frame + 3 * r;
+        for (int i = 0; i < nv; i++)
+          J[i] = ax[0] * (jp2[i] - jp1[i]) + ax[1] * (jp2[nv + i] - jp1[nv + i]) +
+                 ax[2] * (jp2[2 * nv + i] - jp1[2 * nv + i]);
+        add_row(d, EFC_CONTACT, c, J, nv, r == 0 ? con->dist : 0.0,
+                r == 0 ? con->includemargin : 0.0, da);
+      }
     }
   }
 }

@@ -56,7 +56,8 @@ void mro_set_freeze_robot(mro_data*, int freeze);
 /* test switches: drop all constraints (smooth-dynamics parity slice); emulate the
  * device capacity limits (active contacts / rows beyond the caps are dropped) */
 void mro_set_no_constraints(mro_data*, int flag);
-void mro_set_caps(mro_data*, int ncon_cap, int nefc_cap);
+void mro_set_caps(mro_data*, int ncon_cap, int nefc_cap, int nrrow_cap, int npp_cap);
+int mro_overflow(const mro_data*);
 /* solver telemetry of the last solve */
 int mro_solver_iters(const mro_data*);
 

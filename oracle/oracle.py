@@ -50,7 +50,8 @@ def lib() -> C.CDLL:
         L.mro_set_freeze_robot.argtypes = [C.c_void_p, C.c_int]
         L.mro_solver_iters.argtypes = [C.c_void_p]
         L.mro_set_no_constraints.argtypes = [C.c_void_p, C.c_int]
-        L.mro_set_caps.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.mro_set_caps.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.mro_overflow.argtypes = [C.c_void_p]
         L.mro_get.restype = C.POINTER(C.c_double)
         L.mro_get.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int)]
         L.mro_ncon.argtypes = [C.c_void_p]
@@ -122,8 +123,13 @@ class Env:
     def no_constraints(self, flag: bool):
         lib().mro_set_no_constraints(self.ptr, int(flag))
 
-    def set_caps(self, ncon_cap: int, nefc_cap: int):
-        lib().mro_set_caps(self.ptr, int(ncon_cap), int(nefc_cap))
+    def set_caps(self, ncon_cap: int = 32, nefc_cap: int = 112, nrrow_cap: int = 50, npp_cap: int = 8):
+        """Emulate the device capacities (csrc/mre_dev.h: NCON_MAX, NEFC_MAX, NRROW_MAX, NPP_MAX)."""
+        lib().mro_set_caps(self.ptr, int(ncon_cap), int(nefc_cap), int(nrrow_cap), int(npp_cap))
+
+    @property
+    def overflow(self) -> bool:
+        return bool(lib().mro_overflow(self.ptr))
 
     @property
     def ncon(self):

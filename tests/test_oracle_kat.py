@@ -174,3 +174,21 @@ def test_osc_holds_current_pose_and_tracks_a_step(oracle_model):
     assert not e.osc_converged(p)
     assert e.run_controller(p, 0.0, 400, 5)  # converges within the 2 s window (rearrangement.py:371)
     assert np.linalg.norm(e.arr("site_xpos")[:3] - np.array(p.target_pos)) < 5e-3
+
+
+def test_capacity_emulation_cuts_the_contact_list(oracle_model):
+    """mro_set_caps reproduces the device capacities: contacts beyond them are dropped in order
+    and the overflow flag is raised (device: MRE_ST_CONTACT_OVERFLOW)."""
+    e = _env(oracle_model, 4)
+    init_oracle_env(e, 4, z_extra=-1e-4)
+    e.forward()
+    assert e.nefc == 7 + 3 * 16 and not e.overflow
+    e.set_caps(ncon_cap=10, nefc_cap=112, nrrow_cap=50, npp_cap=8)
+    e.forward()
+    assert e.nefc == 7 + 3 * 10 and e.overflow
+    e.set_caps(ncon_cap=32, nefc_cap=7 + 3 * 5 + 2, nrrow_cap=50, npp_cap=8)
+    e.forward()
+    assert e.nefc == 7 + 3 * 5 and e.overflow
+    e.set_caps(0, 0, 0, 0)
+    e.forward()
+    assert e.nefc == 7 + 3 * 16 and not e.overflow
