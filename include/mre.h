@@ -123,6 +123,11 @@ int mre_get_status(mre_env*, uint32_t* status);
 /* telemetry: per-env [ncon, nefc, solver_iters, reserved] of the last step */
 int mre_get_solver_stats(mre_env*, int32_t* stats);
 
+/* dispatch order: workgroup b of the step kernel advances env order[b] (a permutation of
+ * 0..N-1, host or device pointer; NULL = identity).  Lock-step batches end with their slowest
+ * env, so callers may put envs with many constraint rows first (see mre_get_solver_stats). */
+int mre_set_env_order(mre_env*, const int32_t* order);
+
 /* measurement support for bench.py: when enabled every step-kernel launch is
  * bracketed by hipEvents on the handle's stream; mre_profile_read synchronises and
  * returns the summed kernel time [ms] and launch count since enable (and resets). */

@@ -53,6 +53,8 @@ struct mre_env {
   float* trace = nullptr;
   int trace_nenv = 0, trace_max = 0, trace_pos = 0;
   long long env_id_offset = 0;
+  int* order = nullptr;       // dispatch permutation (heavy-first), device
+  bool use_order = false;
   bool profiling = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
   size_t events_used = 0;
@@ -262,6 +264,7 @@ extern "C" int mre_create(const void* blob, size_t nbytes, int num_envs, int dev
   HIPCHK(hipMalloc(&e->converged, N)); HIPCHK(hipMalloc(&e->mask, N));
   HIPCHK(hipMalloc(&e->sites, N * 16 * 4));
   HIPCHK(hipMalloc(&e->status, N * 4)); HIPCHK(hipMalloc(&e->stats, N * 4 * 4));
+  HIPCHK(hipMalloc(&e->order, N * 4));
   HIPCHK(hipMemset(e->status, 0, N * 4)); HIPCHK(hipMemset(e->stats, 0, N * 16));
   HIPCHK(hipMemset(e->grip_closed, 0, N)); HIPCHK(hipMemset(e->osc_target, 0, N * 64));
   HIPCHK(hipMemset(e->sites, 0, N * 64));
@@ -286,7 +289,7 @@ extern "C" int mre_destroy(mre_env* e) {
   (void)hipSetDevice(e->device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   void* ptrs[] = {e->dM, e->qpos, e->qvel, e->qacc_ws, e->ctrl, e->nprops, e->prop_size, e->osc_target,
-                  e->grip_closed, e->converged, e->mask, e->sites, e->status, e->stats, e->d_osc};
+                  e->grip_closed, e->converged, e->mask, e->sites, e->status, e->stats, e->d_osc, e->order};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
@@ -371,6 +374,7 @@ static void fill_args(mre_env* e, StepArgs& a) {
   a.control_steps = 1; a.mode = CTRL_HELD;
   a.osc = e->d_osc; a.osc_target = e->osc_target; a.grip_closed = e->grip_closed;
   a.sites = e->sites; a.status = e->status; a.stats = e->stats;
+  a.env_order = e->use_order ? e->order : nullptr;
   a.trace = e->trace; a.trace_nenv = e->trace_nenv; a.trace_max = e->trace_max; a.trace_base = e->trace_pos;
 }
 
@@ -637,5 +641,15 @@ extern "C" int mre_profile_read(mre_env* e, float* total_ms, int* launches) {
   }
   *total_ms = tot; *launches = (int)e->events_used;
   e->events_used = 0;
+  return MRE_OK;
+}
+
+extern "C" int mre_set_env_order(mre_env* e, const int32_t* order) {
+  if (!e) return fail(MRE_ERR_ARG, "null handle");
+  if (!order) { e->use_order = false; return MRE_OK; }
+  int rc = copy_in(e, e->order, order, (size_t)e->N * 4);
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(e->stream));
+  e->use_order = true;
   return MRE_OK;
 }

@@ -109,6 +109,7 @@ struct StepArgs {
   float* trace;              // [max_steps][trace_nenv][NQP] or null
   int trace_nenv, trace_max, trace_base;
   const uint8_t* env_mask;   // [N] or null: envs with 0 are skipped by this launch
+  const int* env_order;      // [N] or null: workgroup b steps env env_order[b] (heavy-first dispatch)
 };
 
 }  // namespace mre

@@ -473,9 +473,9 @@ MRE_PHASE_FN void integrate(const DevModel* M, Sm& s, int l, bool grip_clamped, 
 __global__ __launch_bounds__(64, 2) void k_step(StepArgs a) {
   __shared__ Sm s;
   OscSm& osc = s.osc;
-  const int env = blockIdx.x;
+  if ((int)blockIdx.x >= a.N) return;
+  const int env = a.env_order != nullptr ? a.env_order[blockIdx.x] : (int)blockIdx.x;
   const int l = threadIdx.x;
-  if (env >= a.N) return;
   if (a.env_mask != nullptr && a.env_mask[env] == 0) return;
   const DevModel* M = a.M;
 

@@ -25,7 +25,7 @@ EXPORTS = [
     "mre_set_warmstart", "mre_get_warmstart", "mre_set_ctrl", "mre_step", "mre_rollout",
     "mre_set_trace", "mre_osc_set_target", "mre_osc_configure", "mre_gripper_set",
     "mre_run_controller", "mre_get_sites", "mre_get_status", "mre_get_solver_stats",
-    "mre_profile_enable", "mre_profile_read", "mre_set_env_id_offset",
+    "mre_profile_enable", "mre_profile_read", "mre_set_env_id_offset", "mre_set_env_order",
 ]
 
 
@@ -93,6 +93,7 @@ def lib() -> C.CDLL:
     L.mre_get_status.argtypes = [vp, fp]
     L.mre_get_solver_stats.argtypes = [vp, fp]
     L.mre_set_env_id_offset.argtypes = [vp, C.c_longlong]
+    L.mre_set_env_order.argtypes = [vp, fp]
     L.mre_profile_enable.argtypes = [vp, ci]
     L.mre_profile_read.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(ci)]
     for name in EXPORTS:

@@ -84,6 +84,15 @@ class BatchedPhysics:
         check(_lib.lib().mre_reset(self._h, _ptr(m)), "mre_reset")
         self.sync()
 
+    def set_env_order(self, order=None) -> None:
+        """Heavy-first dispatch: workgroup b advances env order[b] (None = identity)."""
+        if order is None:
+            check(_lib.lib().mre_set_env_order(self._h, None), "mre_set_env_order")
+            return
+        o = np.ascontiguousarray(order, np.int32)
+        assert sorted(o.tolist()) == list(range(self.num_envs)), "order must be a permutation"
+        check(_lib.lib().mre_set_env_order(self._h, _ptr(o)), "mre_set_env_order")
+
     def set_env_id_offset(self, offset: int) -> None:
         check(_lib.lib().mre_set_env_id_offset(self._h, int(offset)), "mre_set_env_id_offset")
 

@@ -113,3 +113,25 @@ def test_nonfinite_state_is_flagged(compiled_model):
     st = phys.status()
     assert (st[1] & 2) != 0 and (st[0] & 2) == 0 and (st[2] & 2) == 0
     phys.close()
+
+
+def test_dispatch_order_does_not_change_results(compiled_model):
+    """mre_set_env_order only permutes which workgroup advances which env."""
+    import torch
+    from mujoco_robot_environments_amd import rng
+    A, _ = compiled_model
+    N = 64
+    ids = np.arange(N)
+    seq_np = rng.random_actions(4, ids, np.arange(4), scale=0.2).astype(np.float32)
+    out = []
+    for order in (None, np.random.RandomState(1).permutation(N)):
+        phys = _phys(N, A)
+        nprops, sizes = rng.prop_params(4, ids)
+        phys.set_props(nprops, sizes)
+        phys.reset()
+        phys.place_props(4, (0.35, -0.4, 0.43), (0.55, 0.4, 0.435), settle_steps=50)
+        phys.set_env_order(order)
+        phys.rollout(torch.from_numpy(seq_np).to(phys.device).contiguous(), control_steps=5)
+        out.append(phys.get_state())
+        phys.close()
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
