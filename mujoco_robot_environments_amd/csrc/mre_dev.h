@@ -28,7 +28,7 @@ constexpr int NCON_MAX = 32;  // active contacts kept per env
 constexpr int NEFC_MAX = 112; // constraint rows per env (7 equality + limits + 3 per contact)
 constexpr int NRROW_MAX = 50; // rows with a robot part (7 equality + limits + 3 per robot contact)
 constexpr int NPP_MAX = 8;    // cube-cube contacts (rows with two prop parts)
-constexpr int MAXBLK = 56;    // 7 equality + <=15 limit rows + NCON_MAX contacts
+constexpr int MAXBLK = 40;    // <= 8 scalar-row triples + NCON_MAX contact blocks (also bounds the schedule length)
 
 struct DevModel {
   // ---- bodies (index = body id)

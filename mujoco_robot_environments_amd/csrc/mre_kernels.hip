@@ -67,11 +67,11 @@ struct Sm {
   float Jr[NRROW_MAX][NRV], Br[NRROW_MAX][NRV];
   // constraint rows: regulariser R, aref (S1) -> efc_b (S2), 1/A_ii
   float rowR[NEFC_MAX], rowB[NEFC_MAX], rowAinv[NEFC_MAX];
-  float Ablk[NCON_MAX + 8][9];  // contact blocks, then scalar-row triples
+  float Ablk[NCON_MAX + 8][6];  // symmetric 3x3 blocks (upper triangle): contacts, then scalar-row triples
   // constraint blocks (scalar row or 3-row contact) and their island schedule
   int blk_info[MAXBLK];
   uint16_t hdr[NEFC_MAX];  // per row: robot slot | propA << 8 | propB << 12
-  int8_t sched[MAXBLK][5];
+  int sched[MAXBLK][5];   // per (schedule step, island): block descriptor word or -1
 
   float con_fric[NCON_MAX];
   float zpad[4];  // zeros: operand source for lanes / rows outside a block

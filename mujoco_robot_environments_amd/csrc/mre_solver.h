@@ -369,7 +369,10 @@ MRE_PHASE_FN void assemble_constraints(const DevModel* M, Sm& s, int l) {
     if (r == 0) acc[0] = scalar ? acc[0] : diag;
     if (r == 1) acc[1] = scalar ? acc[1] : diag;
     if (r == 2) acc[2] = scalar ? acc[2] : diag;
-    s.Ablk[slot][3 * r] = acc[0]; s.Ablk[slot][3 * r + 1] = acc[1]; s.Ablk[slot][3 * r + 2] = acc[2];
+    // symmetric block, upper triangle packed as (00,01,02,11,12,22) -- like the mirrored AR of mj_projectConstraint
+    if (r == 0) { s.Ablk[slot][0] = acc[0]; s.Ablk[slot][1] = acc[1]; s.Ablk[slot][2] = acc[2]; }
+    if (r == 1) { s.Ablk[slot][3] = acc[1]; s.Ablk[slot][4] = acc[2]; }
+    if (r == 2) { s.Ablk[slot][5] = acc[2]; }
     s.rowAinv[i] = 1.0f / diag;
   }
   __syncthreads();
@@ -419,6 +422,24 @@ MRE_DEV float island_sum(float v) {
   return v;
 }
 
+// three island sums at once, level by level: the three chains interleave, which hides the DPP
+// read-after-write wait states the single-chain form pays with s_nop
+template <int CTRL, int ROW_MASK>
+MRE_DEV void dpp_add3(float& x, float& y, float& z) {
+  const int tx = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, ROW_MASK, 0xF, false);
+  const int ty = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y), CTRL, ROW_MASK, 0xF, false);
+  const int tz = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, z), CTRL, ROW_MASK, 0xF, false);
+  x += __builtin_bit_cast(float, tx);
+  y += __builtin_bit_cast(float, ty);
+  z += __builtin_bit_cast(float, tz);
+}
+MRE_DEV void island_sum3(float& x, float& y, float& z) {
+  dpp_add3<0xB1, 0xF>(x, y, z);
+  dpp_add3<0x4E, 0xF>(x, y, z);
+  dpp_add3<0x141, 0xF>(x, y, z);
+  dpp_add3<0x140, 0x1>(x, y, z);
+}
+
 // J / B entry of row `row` for the dof this lane owns (rs = robot slot or NONE, slot = which
 // prop part of the row belongs to this lane's cube)
 MRE_DEV void lane_JB(const Sm& s, int row, int rs, int l, int lk, int slot, float linvM, float& j, float& b) {
@@ -457,7 +478,7 @@ MRE_DEV void build_schedule(const DevModel* M, Sm& s) {
     const int nr = (nscalar - i) < 3 ? (nscalar - i) : 3;
     s.blk_info[nb] = 0 | (i << 2) | (i << 9) | (0xF << 16) | (0xF << 20) | (0 << 24) | (nr << 27);
     const int st = last[0]++;
-    s.sched[st][0] = nb++;
+    s.sched[st][0] = s.blk_info[nb++];
     if (last[0] > nst) nst = last[0];
   }
   for (int c = 0; c < s.ncon; c++) {
@@ -472,14 +493,15 @@ MRE_DEV void build_schedule(const DevModel* M, Sm& s) {
     if (hr && last[0] > st) st = last[0];
     if (ha && last[1 + pa] > st) st = last[1 + pa];
     if (hb && last[1 + pb] > st) st = last[1 + pb];
-    if (hr) { last[0] = st + 1; s.sched[st][0] = nb; }
-    if (ha) { last[1 + pa] = st + 1; s.sched[st][1 + pa] = nb; }
-    if (hb) { last[1 + pb] = st + 1; s.sched[st][1 + pb] = nb; }
-    if (st + 1 > nst) nst = st + 1;
     const int rsl = hr ? rs : BLK_NONE;
     const int prim = hr ? 0 : 1 + pa;
     const int bsl = hb ? s.con_bslot[c] : 0;
-    s.blk_info[nb++] = 2 | ((nscalar + 3 * c) << 2) | (rsl << 9) | (pa << 16) | (pb << 20) | (prim << 24) | (3 << 27) | (bsl << 29);
+    const int word = 2 | ((nscalar + 3 * c) << 2) | (rsl << 9) | (pa << 16) | (pb << 20) | (prim << 24) | (3 << 27) | (bsl << 29);
+    if (hr) { last[0] = st + 1; s.sched[st][0] = word; }
+    if (ha) { last[1 + pa] = st + 1; s.sched[st][1 + pa] = word; }
+    if (hb) { last[1 + pb] = st + 1; s.sched[st][1 + pb] = word; }
+    if (st + 1 > nst) nst = st + 1;
+    s.blk_info[nb++] = word;
   }
   s.nblk = nb;
   s.nsched = nst;
@@ -574,9 +596,9 @@ MRE_PHASE_FN void solve_constraints(const DevModel* M, Sm& s, int l) {
   for (int iter = 0; iter < max_iter; iter++) {
     float impr = 0.f;
     for (int st = 0; st < nsched; st++) {
-      const int bid = (isl >= 0) ? s.sched[st][isl] : -1;
-      const bool on = bid >= 0;
-      const int info = on ? s.blk_info[bid] : 0;
+      const int word = (isl >= 0) ? s.sched[st][isl] : -1;
+      const bool on = word != -1;
+      const int info = on ? word : 0;
       const int type = blk_type(info), row0 = blk_row0(info), rs = blk_rslot(info), nr = blk_nrows(info);
       const int pa = blk_pa(info), pb = blk_pb(info);
       const int slot = (lp >= 0) ? (lp == pa ? 0 : 1) : -1;
@@ -606,7 +628,8 @@ MRE_PHASE_FN void solve_constraints(const DevModel* M, Sm& s, int l) {
       const float4 r1 = make_float4(s.rowR[rb], s.rowB[rb], 0.f, s.rowAinv[rb]);
       const float4 r2 = make_float4(s.rowR[rc], s.rowB[rc], 0.f, s.rowAinv[rc]);
       const float f0 = s.frc[ra], f1 = h1 ? s.frc[rb] : 0.f, f2 = h2 ? s.frc[rc] : 0.f;
-      float p0 = island_sum(j0 * a), p1 = island_sum(j1 * a), p2 = island_sum(j2 * a);
+      float p0 = j0 * a, p1 = j1 * a, p2 = j2 * a;
+      island_sum3(p0, p1, p2);
       if (__any(partner != l)) {
         const float q0 = __shfl(p0, partner, 64), q1 = __shfl(p1, partner, 64), q2 = __shfl(p2, partner, 64);
         if (partner != l) { p0 += q0; p1 += q1; p2 += q2; }
@@ -615,40 +638,39 @@ MRE_PHASE_FN void solve_constraints(const DevModel* M, Sm& s, int l) {
       if (on) {
         const int aslot = is3 ? (row0 - nscalar) / 3 : NCON_MAX + row0 / 3;
         const float* At = s.Ablk[aslot];
-        const float A00 = At[0], A01 = At[1], A02 = At[2], A10 = At[3], A11 = At[4], A12 = At[5],
-                    A20 = At[6], A21 = At[7], A22 = At[8];
+        const float A00 = At[0], A01 = At[1], A02 = At[2], A11 = At[3], A12 = At[4], A22 = At[5];
+        const float A10 = A01, A20 = A02, A21 = A12;
         const float res0 = p0 + r0.x * f0 + r0.y, res1 = p1 + r1.x * f1 + r1.y, res2 = p2 + r2.x * f2 + r2.y;
         if (!is3) {
-          // up to three sequential scalar updates; cross terms through the block's A entries
+          // up to three sequential scalar updates; cross terms through the block's A entries.
+          // Rows past nr are neutralised with selects (no divergent branches in this path).
+          const bool h1 = nr > 1, h2 = nr > 2;
           float fn = f0 - res0 * r0.w;
-          if (row0 >= 7 && fn < 0.f) fn = 0.f;
+          fn = (row0 >= 7 && fn < 0.f) ? 0.f : fn;
           d0 = fn - f0;
-          float ch = d0 * (0.5f * d0 * (A00 + r0.x) + res0);
-          if (ch > 1e-10f) { d0 = 0.f; ch = 0.f; }
-          change = ch;
-          if (nr > 1) {
-            const float rs1 = res1 + A10 * d0;
-            fn = f1 - rs1 * r1.w;
-            if (row0 + 1 >= 7 && fn < 0.f) fn = 0.f;
-            d1 = fn - f1;
-            ch = d1 * (0.5f * d1 * (A11 + r1.x) + rs1);
-            if (ch > 1e-10f) { d1 = 0.f; ch = 0.f; }
-            change += ch;
-          }
-          if (nr > 2) {
-            const float rs2 = res2 + A20 * d0 + A21 * d1;
-            fn = f2 - rs2 * r2.w;
-            if (row0 + 2 >= 7 && fn < 0.f) fn = 0.f;
-            d2 = fn - f2;
-            ch = d2 * (0.5f * d2 * (A22 + r2.x) + rs2);
-            if (ch > 1e-10f) { d2 = 0.f; ch = 0.f; }
-            change += ch;
-          }
+          float ch0 = d0 * (0.5f * d0 * (A00 + r0.x) + res0);
+          d0 = ch0 > 1e-10f ? 0.f : d0;
+          ch0 = ch0 > 1e-10f ? 0.f : ch0;
+          const float rs1 = res1 + A10 * d0;
+          fn = f1 - rs1 * r1.w;
+          fn = (row0 + 1 >= 7 && fn < 0.f) ? 0.f : fn;
+          d1 = h1 ? fn - f1 : 0.f;
+          float ch1 = d1 * (0.5f * d1 * (A11 + r1.x) + rs1);
+          d1 = ch1 > 1e-10f ? 0.f : d1;
+          ch1 = ch1 > 1e-10f ? 0.f : ch1;
+          const float rs2 = res2 + A20 * d0 + A21 * d1;
+          fn = f2 - rs2 * r2.w;
+          fn = (row0 + 2 >= 7 && fn < 0.f) ? 0.f : fn;
+          d2 = h2 ? fn - f2 : 0.f;
+          float ch2 = d2 * (0.5f * d2 * (A22 + r2.x) + rs2);
+          d2 = ch2 > 1e-10f ? 0.f : d2;
+          ch2 = ch2 > 1e-10f ? 0.f : ch2;
+          change = ch0 + ch1 + ch2;
         } else {
           const float fr = s.con_fric[aslot];
           float n0 = f0, n1 = f1, n2 = f2;
           if (n0 < kMinVal) {
-            n0 -= res0 * fast_rcp(A00);
+            n0 -= res0 * r0.w;  // 1/A00 (regulariser included) precomputed at assembly
             if (n0 < 0.f) n0 = 0.f;
             n1 = n2 = 0.f;
           } else {
@@ -671,8 +693,8 @@ MRE_PHASE_FN void solve_constraints(const DevModel* M, Sm& s, int l) {
             float v[2];
             const bool active = qcqp2(v, Ac, bc, fr, fr, n0);
             if (active) {
-              float sq = (v[0] * v[0] + v[1] * v[1]) * fast_rcp(fr * fr);
-              sq = sqrtf(n0 * n0 * fast_rcp(fmaxf(sq, kMinVal)));
+              // put v back on the cone: v *= n0 * mu / |v|  (= sqrt(n0^2 / sum (v_i/mu)^2))
+              const float sq = n0 * fr * __builtin_amdgcn_rsqf(fmaxf(v[0] * v[0] + v[1] * v[1], kMinVal));
               v[0] *= sq; v[1] *= sq;
             }
             n1 = v[0]; n2 = v[1];
