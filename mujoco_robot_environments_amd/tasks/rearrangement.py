@@ -22,7 +22,7 @@ from typing import Dict, Optional
 import numpy as np
 from scipy.spatial.transform import Rotation as R
 
-from .. import placement, rng
+from .. import demo_logic, placement, rng
 from ..config import Cfg, colour_separator_task_config, default_config  # noqa: F401
 from ..model import compile as _compile
 from ..model import spec as _spec
@@ -113,6 +113,7 @@ class BatchedRearrangementEnv:
                 self.overhead_camera_height, self.overhead_camera_width = int(cam.height), int(cam.width)
         self._reset_count = 0
         self._place_count = 0
+        self._place_counts = np.zeros(self.num_envs, np.int64)  # prop_place calls per env (RNG key)
         self._robot: Optional[RobotArm] = None
         self.mode = None
         self.eef_home_pose = None
@@ -330,24 +331,18 @@ class BatchedRearrangementEnv:
         lo = np.asarray(ws.min_pose if min_pose is None else min_pose, np.float64)
         hi = np.asarray(ws.max_pose if max_pose is None else max_pose, np.float64)
         p = prop_id - PROP_GEOM_ID0
-        # cubes lie flat on the table: footprint circum-radius sqrt(2)*s bounds the box distance
-        rb = np.sqrt(2.0) * self.prop_half_size[i].max(axis=1)
-        quat = home_quat()
-        for att in range(10000):
-            u = rng.uniform(self.seed + 1, [int(self.env_ids[i])], [self._place_count * 10000 + att], 3)[0, 0]
-            pos = lo + (hi - lo) * u
-            ok = True
-            for other, a in info.items():
-                if other == prop_id:
-                    continue
-                o = other - PROP_GEOM_ID0
-                if np.linalg.norm(pos - a["position"]) <= rb[p] + rb[o] + 0.05:
-                    ok = False
-                    break
-            if ok:
-                self._place_count += 1
-                return np.concatenate([pos, quat])
-        raise Exception("Failed to find collision free place pose.")
+        pos = np.zeros((1, 4, 3))
+        for pid, a in info.items():
+            pos[0, pid - PROP_GEOM_ID0] = a["position"]
+        lo4 = np.tile(lo, (1, 4, 1))
+        hi4 = np.tile(hi, (1, 4, 1))
+        pose, ok = demo_logic.batched_place_pose(self.seed, self.env_ids[i:i + 1], self._place_counts[i:i + 1], pos,
+                                                 self.nprops[i:i + 1], self.prop_half_size[i:i + 1],
+                                                 np.array([p]), lo4, hi4, np.array([True]))
+        if not ok[0]:
+            raise Exception("Failed to find collision free place pose.")
+        self._place_counts[i] += 1
+        return pose[0]
 
     def sort_colours_env(self, i: int, info: Optional[dict] = None):
         """tasks/rearrangement.py:700-751 for env i."""
@@ -363,24 +358,19 @@ class BatchedRearrangementEnv:
         return False, None, None
 
     def sort_colours(self):
-        """Batched: (in_progress[N], pick_pose[N,7], place_pose[N,7]); finished envs get
-        their home pose as a no-op target."""
+        """Batched sort_colours (demo_logic.batched_sort_colours): (in_progress[N], pick_pose[N,7],
+        place_pose[N,7]); envs with nothing left to do (or whose place sampling failed, recorded in
+        ``failed_phase``) get their home pose as a no-op target."""
         poses = self._physics.sites()[2]
-        prog = np.zeros(self.num_envs, bool)
-        pick = np.zeros((self.num_envs, 7))
-        place = np.zeros((self.num_envs, 7))
-        for i in range(self.num_envs):
-            try:
-                ip, a, b = self.sort_colours_env(i, self.props_info_env(i, poses))
-            except Exception as e:  # reference: the caller abandons the episode (data generation :137-139)
-                ip, a, b = False, None, None
-                self.failed_phase[i] = str(e)
-            prog[i] = ip
-            if ip:
-                pick[i], place[i] = a, b
-            else:
-                pick[i, :3] = place[i, :3] = self.eef_home_pose[i]
-                pick[i, 3:] = place[i, 3:] = home_quat()
+        prog, pick, place, failed, _ = demo_logic.batched_sort_colours(
+            self._cfg.task, self.seed, self.env_ids, self._place_counts, poses, self.nprops,
+            self.prop_half_size, self.prop_colours)
+        self._place_counts[prog] += 1
+        self.failed_phase[failed] = "Failed to find collision free place pose."
+        idle = ~prog
+        home = np.atleast_2d(self.eef_home_pose)
+        pick[idle, :3] = place[idle, :3] = home[idle] if len(home) == self.num_envs else home[0]
+        pick[idle, 3:] = place[idle, 3:] = home_quat()
         return prog, pick, place
 
     def random_pick_and_place(self):
