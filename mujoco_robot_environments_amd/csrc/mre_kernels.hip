@@ -43,7 +43,7 @@ struct Sm {
   float cdof[NRV][6];  // robot dofs only; cube cdofs are implicit (prop_cdof)
   union {  // R2: velocity-stage temporaries (S1b) | contact geometry (S1c) | jar + forces (S2)
     struct { float cdof_dot[NV][6], cvel[NB][6], cfrc[NB][6]; };
-    struct { float con_pos[NCON_MAX][3], con_frame[NCON_MAX][9]; };
+    struct { float con_pos[NCON_MAX][3], con_frame[NCON_MAX][9], con_dist[NCON_MAX]; };
     struct { float jar[NEFC_MAX], frc[NEFC_MAX]; };
   };
   float com_robot[3];
@@ -57,7 +57,6 @@ struct Sm {
   int nprops;
   // active contacts (pair order)
   int ncon, nefc, nl, nrrow, overflow, solver_iters;
-  float con_dist[NCON_MAX];
   uint8_t con_pair[NCON_MAX], con_rslot[NCON_MAX], con_bslot[NCON_MAX];
   uint16_t lim_info[NRV + 1];
   // ---- contiguous block [JpA .. sched]: written only after collision; hosts the per-lane
@@ -65,15 +64,15 @@ struct Sm {
   float JpA[3 * NCON_MAX][6];            // prop part A of every contact row
   float JpB[3 * NPP_MAX][6];             // prop part B (cube-cube contacts only)
   float Jr[NRROW_MAX][NRV], Br[NRROW_MAX][NRV];
-  // constraint rows: regulariser R, aref (S1) -> efc_b (S2), 1/A_ii
-  float rowR[NEFC_MAX], rowB[NEFC_MAX], rowAinv[NEFC_MAX];
-  float Ablk[NCON_MAX + 8][6];  // symmetric 3x3 blocks (upper triangle): contacts, then scalar-row triples
+  // one 64-byte record per constraint block (scalar-row triple g -> record g, contact c -> record
+  // 8 + c): [0:3] regulariser R of its rows, [3:6] aref (S1) -> efc_b (S2), [6:9] 1/A_ii,
+  // [9:15] symmetric 3x3 block of A (00,01,02,11,12,22), [15] friction coefficient
+  alignas(16) float blkrec[MAXBLK][16];
   // constraint blocks (scalar row or 3-row contact) and their island schedule
   int blk_info[MAXBLK];
   uint16_t hdr[NEFC_MAX];  // per row: robot slot | propA << 8 | propB << 12
   int sched[MAXBLK][5];   // per (schedule step, island): block descriptor word or -1
 
-  float con_fric[NCON_MAX];
   float zpad[4];  // zeros: operand source for lanes / rows outside a block
   int nblk, nsched;
 };

@@ -108,7 +108,6 @@ MRE_PHASE_FN void collide(const DevModel* M, Sm& s, int l) {
     float f[9];
     v3copy(f, normal);
     make_frame(f);
-    const float fric = M->pair_friction[l][0];
     for (int c = 0; c < n; c++) {
       const int id = off + c;
       if (id >= NCON_MAX) break;
@@ -117,7 +116,6 @@ MRE_PHASE_FN void collide(const DevModel* M, Sm& s, int l) {
       for (int k = 0; k < 9; k++) s.con_frame[id][k] = f[k];
       s.con_dist[id] = cand_dist(buf, c);
       s.con_pair[id] = l;
-      s.con_fric[id] = fric;
     }
   }
   __syncthreads();
@@ -152,6 +150,18 @@ MRE_DEV void jac_robot(const DevModel* M, Sm& s, int rs, int b, const float* p, 
     s.Jr[rs][j] += sg * (ax[0] * (c[3] + t[0]) + ax[1] * (c[4] + t[1]) + ax[2] * (c[5] + t[2]));
   }
 }
+// block record of row i (see Sm::blkrec): record index and row-in-block
+MRE_DEV int row_blk(const Sm& s, int i, int& r) {
+  const int ns = 7 + s.nl;
+  if (i < ns) { r = i % 3; return i / 3; }
+  const int cr = i - ns;
+  r = cr % 3;
+  return 8 + cr / 3;
+}
+MRE_DEV float& rowR(Sm& s, int i) { int r; const int b = row_blk(s, i, r); return s.blkrec[b][r]; }
+MRE_DEV float& rowB(Sm& s, int i) { int r; const int b = row_blk(s, i, r); return s.blkrec[b][3 + r]; }
+MRE_DEV float& rowAinv(Sm& s, int i) { int r; const int b = row_blk(s, i, r); return s.blkrec[b][6 + r]; }
+
 // prop parts of contact row i: part A (first cube of the contact) is indexed by contact row,
 // part B exists only for cube-cube contacts (slot con_bslot)
 MRE_DEV float* jpA(Sm& s, int i) { return s.JpA[i - 7 - s.nl]; }
@@ -229,8 +239,9 @@ MRE_PHASE_FN void assemble_constraints(const DevModel* M, Sm& s, int l) {
   }
   __syncthreads();
   const int nefc = s.nefc, nl = s.nl;
-  // ---- zero robot slots
+  // ---- zero robot slots and the scalar-triple records (rows past a short last triple stay 0)
   for (int e = l; e < s.nrrow * NRV; e += 64) (&s.Jr[0][0])[e] = 0.f;
+  for (int e = l; e < 8 * 16; e += 64) (&s.blkrec[0][0])[e] = 0.f;
   __syncthreads();
   // ---- rows (lane = row)
   for (int i = l; i < nefc; i += 64) {
@@ -329,7 +340,8 @@ MRE_PHASE_FN void assemble_constraints(const DevModel* M, Sm& s, int l) {
     const float vel = row_dot(s, i, s.qvel);
     const float efc_margin = fric_row ? 0.f : margin;
     const float aref = -B * vel - K * imp * (pos - efc_margin);
-    s.rowR[i] = R; s.rowB[i] = aref;
+    rowR(s, i) = R; rowB(s, i) = aref;
+    if (i >= 7 + nl && (i - 7 - nl) % 3 == 0) s.blkrec[8 + (i - 7 - nl) / 3][15] = M->pair_friction[s.con_pair[(i - 7 - nl) / 3]][0];
   }
   __syncthreads();
   // ---- Br = M^-1 Jr' (lane = robot slot, serial sparse solve in place)
@@ -348,7 +360,7 @@ MRE_PHASE_FN void assemble_constraints(const DevModel* M, Sm& s, int l) {
     const int r = scalar ? i % 3 : (i - 7 - nl) % 3;
     const int i0 = i - r;
     const int nb = scalar ? ((7 + nl - i0) < 3 ? (7 + nl - i0) : 3) : 3;
-    const int slot = scalar ? NCON_MAX + i / 3 : (i - 7 - nl) / 3;
+    const int slot = scalar ? i / 3 : 8 + (i - 7 - nl) / 3;
     float acc[3] = {0.f, 0.f, 0.f};
 #pragma unroll
     for (int cc = 0; cc < 3; cc++) {
@@ -365,15 +377,15 @@ MRE_PHASE_FN void assemble_constraints(const DevModel* M, Sm& s, int l) {
       }
       acc[cc] = a;
     }
-    const float diag = (r == 0 ? acc[0] : (r == 1 ? acc[1] : acc[2])) + s.rowR[i];
+    const float diag = (r == 0 ? acc[0] : (r == 1 ? acc[1] : acc[2])) + rowR(s, i);
     if (r == 0) acc[0] = scalar ? acc[0] : diag;
     if (r == 1) acc[1] = scalar ? acc[1] : diag;
     if (r == 2) acc[2] = scalar ? acc[2] : diag;
     // symmetric block, upper triangle packed as (00,01,02,11,12,22) -- like the mirrored AR of mj_projectConstraint
-    if (r == 0) { s.Ablk[slot][0] = acc[0]; s.Ablk[slot][1] = acc[1]; s.Ablk[slot][2] = acc[2]; }
-    if (r == 1) { s.Ablk[slot][3] = acc[1]; s.Ablk[slot][4] = acc[2]; }
-    if (r == 2) { s.Ablk[slot][5] = acc[2]; }
-    s.rowAinv[i] = 1.0f / diag;
+    if (r == 0) { s.blkrec[slot][9] = acc[0]; s.blkrec[slot][10] = acc[1]; s.blkrec[slot][11] = acc[2]; }
+    if (r == 1) { s.blkrec[slot][12] = acc[1]; s.blkrec[slot][13] = acc[2]; }
+    if (r == 2) { s.blkrec[slot][14] = acc[2]; }
+    s.blkrec[slot][6 + r] = 1.0f / diag;
   }
   __syncthreads();
 }
@@ -521,20 +533,20 @@ MRE_PHASE_FN void solve_constraints(const DevModel* M, Sm& s, int l) {
   float* jar = s.jar;
   // ---- efc_b and warm-start forces (mj_constraintUpdate on J*qacc_warmstart - aref)
   for (int i = l; i < nefc; i += 64) {
-    const float aref = s.rowB[i];
+    const float aref = rowB(s, i);
     jar[i] = row_dot(s, i, s.qacc_ws) - aref;
-    s.rowB[i] = row_dot(s, i, s.qacc_smooth) - aref;
+    rowB(s, i) = row_dot(s, i, s.qacc_smooth) - aref;
   }
   __syncthreads();
   for (int i = l; i < nefc; i += 64) {
-    const float D = 1.0f / s.rowR[i];
+    const float D = 1.0f / rowR(s, i);
     if (i < 7) s.frc[i] = -D * jar[i];
     else if (i < 7 + nl) s.frc[i] = jar[i] < 0.f ? -D * jar[i] : 0.f;
     else if ((i - 7 - nl) % 3 == 0) {
       const int c = (i - 7 - nl) / 3;
-      const float fr0 = s.con_fric[c];
-      const float D1 = 1.0f / s.rowR[i + 1], D2 = 1.0f / s.rowR[i + 2];
-      const float mu = fr0 * sqrtf(s.rowR[i + 1] / s.rowR[i]);
+      const float fr0 = s.blkrec[8 + c][15];
+      const float D1 = 1.0f / rowR(s, i + 1), D2 = 1.0f / rowR(s, i + 2);
+      const float mu = fr0 * sqrtf(rowR(s, i + 1) / rowR(s, i));
       const float j0 = jar[i], j1 = jar[i + 1], j2 = jar[i + 2];
       const float U0 = j0 * mu, U1 = j1 * fr0, U2 = j2 * fr0;
       const float N = U0, T = sqrtf(U1 * U1 + U2 * U2);
@@ -574,8 +586,8 @@ MRE_PHASE_FN void solve_constraints(const DevModel* M, Sm& s, int l) {
   float part = 0.f;
   for (int i = l; i < nefc; i += 64) {
     const float fi = s.frc[i];
-    const float Af = row_dot(s, i, s.scratch) + s.rowR[i] * fi;
-    part += fi * (0.5f * Af + s.rowB[i]);
+    const float Af = row_dot(s, i, s.scratch) + rowR(s, i) * fi;
+    part += fi * (0.5f * Af + rowB(s, i));
   }
   const float cost = wave_sum(part);
   __syncthreads();
@@ -624,9 +636,13 @@ MRE_PHASE_FN void solve_constraints(const DevModel* M, Sm& s, int l) {
       float b0 = bptr[0], b1 = h1 ? bptr[bstr] : 0.f, b2 = h2 ? bptr[2 * bstr] : 0.f;
       if (!rob_lane) { b0 = j0 * linvM; b1 = j1 * linvM; b2 = j2 * linvM; }
       const int ra = row0, rb = (nr > 1) ? row0 + 1 : row0, rc = (nr > 2) ? row0 + 2 : row0;
-      const float4 r0 = make_float4(s.rowR[ra], s.rowB[ra], 0.f, s.rowAinv[ra]);
-      const float4 r1 = make_float4(s.rowR[rb], s.rowB[rb], 0.f, s.rowAinv[rb]);
-      const float4 r2 = make_float4(s.rowR[rc], s.rowB[rc], 0.f, s.rowAinv[rc]);
+      // the block's uniform operands: one 64-byte record, four 16-byte LDS reads
+      const int bidx = is3 ? 8 + (row0 - nscalar) / 3 : row0 / 3;
+      const float4* rec = reinterpret_cast<const float4*>(s.blkrec[on ? bidx : 0]);
+      const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
+      const float4 r0 = make_float4(q0.x, q0.w, 0.f, q1.z);
+      const float4 r1 = make_float4(q0.y, q1.x, 0.f, q1.w);
+      const float4 r2 = make_float4(q0.z, q1.y, 0.f, q2.x);
       const float f0 = s.frc[ra], f1 = h1 ? s.frc[rb] : 0.f, f2 = h2 ? s.frc[rc] : 0.f;
       float p0 = j0 * a, p1 = j1 * a, p2 = j2 * a;
       island_sum3(p0, p1, p2);
@@ -636,9 +652,7 @@ MRE_PHASE_FN void solve_constraints(const DevModel* M, Sm& s, int l) {
       }
       float d0 = 0.f, d1 = 0.f, d2 = 0.f, change = 0.f;
       if (on) {
-        const int aslot = is3 ? (row0 - nscalar) / 3 : NCON_MAX + row0 / 3;
-        const float* At = s.Ablk[aslot];
-        const float A00 = At[0], A01 = At[1], A02 = At[2], A11 = At[3], A12 = At[4], A22 = At[5];
+        const float A00 = q2.y, A01 = q2.z, A02 = q2.w, A11 = q3.x, A12 = q3.y, A22 = q3.z;
         const float A10 = A01, A20 = A02, A21 = A12;
         const float res0 = p0 + r0.x * f0 + r0.y, res1 = p1 + r1.x * f1 + r1.y, res2 = p2 + r2.x * f2 + r2.y;
         if (!is3) {
@@ -667,7 +681,7 @@ MRE_PHASE_FN void solve_constraints(const DevModel* M, Sm& s, int l) {
           ch2 = ch2 > 1e-10f ? 0.f : ch2;
           change = ch0 + ch1 + ch2;
         } else {
-          const float fr = s.con_fric[aslot];
+          const float fr = q3.w;
           float n0 = f0, n1 = f1, n2 = f2;
           if (n0 < kMinVal) {
             n0 -= res0 * r0.w;  // 1/A00 (regulariser included) precomputed at assembly
