@@ -17,6 +17,7 @@
 using namespace mre;
 
 extern "C" void mre_launch_step(const StepArgs* args, hipStream_t stream);
+extern "C" void mre_launch_settle(const StepArgs* args, hipStream_t stream);
 extern "C" void mre_launch_reset(const DevModel* M, int N, float* qpos, float* qvel, float* qacc_ws,
                                  float* ctrl, uint32_t* status, const uint8_t* mask,
                                  hipStream_t stream);
@@ -611,7 +612,7 @@ extern "C" int mre_place_props(mre_env* e, const uint8_t* mask, uint64_t seed, c
     fill_args(e, a);
     a.trace = nullptr;
     a.nsteps = settle_steps; a.flags = F_FREEZE_ROBOT; a.env_mask = dmask;
-    mre_launch_step(&a, e->stream);
+    mre_launch_settle(&a, e->stream);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(e->stream));
   }

@@ -73,7 +73,6 @@ struct Sm {
   uint16_t hdr[NEFC_MAX];  // per row: robot slot | propA << 8 | propB << 12
   int sched[MAXBLK][5];   // per (schedule step, island): block descriptor word or -1
 
-  float zpad[4];  // zeros: operand source for lanes / rows outside a block
   int nblk, nsched;
 };
 
@@ -469,8 +468,9 @@ MRE_PHASE_FN void integrate(const DevModel* M, Sm& s, int l, bool grip_clamped, 
 }
 
 // =========================================================================
-__global__ __launch_bounds__(64, 2) void k_step(StepArgs a) {
-  __shared__ Sm s;
+// Body of one launch (nsteps physics steps of one env per workgroup); instantiated by the two
+// entry points below so that profiler summaries separate control ticks from settling launches.
+MRE_DEV void step_body(const StepArgs& a, Sm& s) {
   OscSm& osc = s.osc;
   if ((int)blockIdx.x >= a.N) return;
   const int env = a.env_order != nullptr ? a.env_order[blockIdx.x] : (int)blockIdx.x;
@@ -487,7 +487,6 @@ __global__ __launch_bounds__(64, 2) void k_step(StepArgs a) {
     s.qacc[l] = 0.f;
   }
   if (l < NU) s.ctrl[l] = a.ctrl[(size_t)env * NU + l];
-  if (l < 4) s.zpad[l] = 0.f;
   if (l == 0) { s.nprops = a.nprops[env]; s.overflow = 0; s.ncon = 0; s.nefc = 0; s.solver_iters = 0; }
   if (l < NPROP * 3) {
     const float sz = a.prop_size[(size_t)env * NPROP * 3 + l];
@@ -603,6 +602,18 @@ __global__ __launch_bounds__(64, 2) void k_step(StepArgs a) {
   }
 }
 
+// control ticks: mre_step / mre_rollout / mre_run_controller
+__global__ __launch_bounds__(64, 2) void k_step(StepArgs a) {
+  __shared__ Sm s;
+  step_body(a, s);
+}
+
+// frozen-robot settling after prop placement (mre_place_props): same body, own name in traces
+__global__ __launch_bounds__(64, 2) void k_settle(StepArgs a) {
+  __shared__ Sm s;
+  step_body(a, s);
+}
+
 // Physics.reset() + arm home pose (tasks/rearrangement.py:302-306); cubes parked
 __global__ __launch_bounds__(64) void k_reset(const DevModel* M, int N, float* qpos, float* qvel,
                                               float* qacc_ws, float* ctrl, uint32_t* status,
@@ -633,4 +644,8 @@ extern "C" void mre_launch_reset(const mre::DevModel* M, int N, float* qpos, flo
 
 extern "C" void mre_launch_step(const mre::StepArgs* args, hipStream_t stream) {
   hipLaunchKernelGGL(mre::k_step, dim3(args->N), dim3(64), 0, stream, *args);
+}
+
+extern "C" void mre_launch_settle(const mre::StepArgs* args, hipStream_t stream) {
+  hipLaunchKernelGGL(mre::k_settle, dim3(args->N), dim3(64), 0, stream, *args);
 }

@@ -19,6 +19,10 @@ namespace mre {
 
 constexpr int HDR_NONE = 0xFF;
 constexpr int BLK_NONE = 0x7F;
+// solver operand table (solve_constraints): entries for MAXBLK steps x 5 islands, one all-off
+// entry, then a pad of zeros that idle islands read their Jacobian rows from
+constexpr int TAB_OFF = MAXBLK * 5;
+constexpr int TAB_ZEROS = 48;
 
 MRE_DEV void build_schedule(const DevModel* M, Sm& s);
 
@@ -604,51 +608,97 @@ MRE_PHASE_FN void solve_constraints(const DevModel* M, Sm& s, int l) {
   const float scale = 1.0f / ((msum / nva) * nva);
   const int nsched = s.nsched, max_iter = M->iterations, nscalar = 7 + nl;
   const float tol = M->tolerance;
+  // Operand table: the schedule's descriptor words expanded once per solve into LDS byte offsets,
+  // so that a sweep step costs one 8-byte read per lane instead of a decode.  It lives in the
+  // body-frame arrays and region R1, which nothing reads between the controller and the next
+  // position stage.  Entry (step, island):
+  //   x = offset of the island's first Jacobian row | offset of the block record << 16
+  //   y = row0 | nrows << 7 | on << 9 | contact << 10 | primary << 11 | partner lane << 12 | coupled << 18
+  static_assert(offsetof(Sm, xpos) % 8 == 0 &&
+                offsetof(Sm, cdof) - offsetof(Sm, xpos) >= sizeof(uint2) * (TAB_OFF + 1) + sizeof(float) * TAB_ZEROS,
+                "operand table must fit in the body-frame arrays + region R1");
+  static_assert(TAB_ZEROS * 4 >= 4 * (NRV - 1) + 2 * 4 * NRV + 4, "zero pad covers three robot rows");
+  char* const sb = reinterpret_cast<char*>(&s);
+  uint2* const tab = reinterpret_cast<uint2*>(&s.xpos[0][0]);
+  float* const zeros = reinterpret_cast<float*>(tab + TAB_OFF + 1);
+  for (int e = l; e < nsched * 5; e += 64) {
+    const int st = e / 5, is = e - 5 * st;
+    const int word = s.sched[st][is];
+    const bool on = word != -1;
+    const int info = on ? word : 0;
+    const int type = blk_type(info), row0 = blk_row0(info), rs = blk_rslot(info), nr = blk_nrows(info);
+    const int pa = blk_pa(info), pb = blk_pb(info), ip = is - 1;
+    const bool is3 = on && type == 2;
+    int partner = 0, coupled = 0;
+    if (is3) {
+      if (is == 0) { if (pa != 0xF) { partner = 16 + 8 * pa; coupled = 1; } }
+      else if (rs != BLK_NONE) { partner = 0; coupled = 1; }
+      else if (pb != 0xF) { partner = 16 + 8 * (ip == pa ? pb : pa); coupled = 1; }
+    }
+    const float* jrow = zeros;
+    if (on) jrow = (is == 0) ? &s.Jr[rs][0] : (ip == pa ? &s.JpA[row0 - nscalar][0] : &s.JpB[3 * blk_bslot(info)][0]);
+    const int bidx = is3 ? 8 + (row0 - nscalar) / 3 : row0 / 3;
+    const unsigned joff = (unsigned)(reinterpret_cast<const char*>(jrow) - sb);
+    const unsigned roff = (unsigned)(reinterpret_cast<const char*>(s.blkrec[on ? bidx : 0]) - sb);
+    uint2 ent;
+    ent.x = joff | (roff << 16);
+    ent.y = (unsigned)row0 | ((unsigned)nr << 7) | ((unsigned)on << 9) | ((unsigned)is3 << 10) |
+            ((unsigned)(on && is == blk_primary(info)) << 11) | ((unsigned)partner << 12) | ((unsigned)coupled << 18);
+    tab[e] = ent;
+  }
+  if (l == 63) {
+    uint2 ent;
+    ent.x = (unsigned)(reinterpret_cast<const char*>(zeros) - sb) | ((unsigned)(reinterpret_cast<const char*>(s.blkrec[0]) - sb) << 16);
+    ent.y = 0u;
+    tab[TAB_OFF] = ent;
+  }
+  if (l < TAB_ZEROS) zeros[l] = 0.f;
+  __syncthreads();
+  // per-lane constants: lanes that own no dof read the all-off entry at every step
+  const bool rob_lane = l < NRV;
+  const unsigned tab0 = (unsigned)(reinterpret_cast<const char*>(tab) - sb);
+  const unsigned tbase = tab0 + 8u * (lvalid ? (unsigned)isl : (unsigned)TAB_OFF);
+  const unsigned tstep = lvalid ? 40u : 0u;
+  const unsigned loff = 4u * (rob_lane ? (unsigned)l : (unsigned)lk);
+  const unsigned lstr = rob_lane ? 4u * NRV : 24u;
+  const unsigned broff = (unsigned)(reinterpret_cast<const char*>(&s.Br[0][0]) - reinterpret_cast<const char*>(&s.Jr[0][0]));
+  const float* const frc = s.frc;
   int iters = 0;
   for (int iter = 0; iter < max_iter; iter++) {
     float impr = 0.f;
     for (int st = 0; st < nsched; st++) {
-      const int word = (isl >= 0) ? s.sched[st][isl] : -1;
-      const bool on = word != -1;
-      const int info = on ? word : 0;
-      const int type = blk_type(info), row0 = blk_row0(info), rs = blk_rslot(info), nr = blk_nrows(info);
-      const int pa = blk_pa(info), pb = blk_pb(info);
-      const int slot = (lp >= 0) ? (lp == pa ? 0 : 1) : -1;
-      const bool is3 = on && type == 2;
-      // partner island of a coupled contact block: a lane holding the other island's partial sums
-      int partner = l;
-      if (is3) {
-        if (isl == 0) { if (pa != 0xF) partner = 16 + 8 * pa; }
-        else if (rs != BLK_NONE) partner = 0;
-        else if (pb != 0xF) partner = 16 + 8 * (lp == pa ? pb : pa);
-      }
-      // branch-free operand fetch: every lane loads three rows through a per-lane base
-      // pointer / stride (a zero pad for lanes or rows that do not take part), then masks
-      const bool rob_lane = l < NRV, rob_row = rs != BLK_NONE;
-      const bool take = on && lvalid && (rob_lane ? rob_row : (slot >= 0));
-      const float* jptr = take ? (rob_lane ? &s.Jr[rs][l] : (slot == 0 ? &s.JpA[row0 - nscalar][lk] : &s.JpB[3 * blk_bslot(info)][lk])) : s.zpad;
-      const float* bptr = (take && rob_lane) ? &s.Br[rs][l] : s.zpad;
-      const int jstr = take ? (rob_lane ? NRV : 6) : 0;
-      const int bstr = (take && rob_lane) ? NRV : 0;
-      // (select, not multiply: rows past the block may hold stale non-finite LDS contents)
+      const uint2 ent = *reinterpret_cast<const uint2*>(sb + tbase + tstep * (unsigned)st);
+      const unsigned w1 = ent.y;
+      const bool on = (w1 & 0x200u) != 0u, is3 = (w1 & 0x400u) != 0u;
+      const int row0 = (int)(w1 & 0x7Fu), nr = (int)((w1 >> 7) & 3u);
       const bool h1 = nr > 1, h2 = nr > 2;
-      const float j0 = jptr[0], j1 = h1 ? jptr[jstr] : 0.f, j2 = h2 ? jptr[2 * jstr] : 0.f;
-      float b0 = bptr[0], b1 = h1 ? bptr[bstr] : 0.f, b2 = h2 ? bptr[2 * bstr] : 0.f;
-      if (!rob_lane) { b0 = j0 * linvM; b1 = j1 * linvM; b2 = j2 * linvM; }
-      const int ra = row0, rb = (nr > 1) ? row0 + 1 : row0, rc = (nr > 2) ? row0 + 2 : row0;
+      // operands: three rows through the lane's offset / stride (rows past the block may hold
+      // stale non-finite LDS contents: select, never multiply by zero)
+      const char* jp = sb + ((ent.x & 0xFFFFu) + loff);
+      const float j0 = *reinterpret_cast<const float*>(jp);
+      const float j1r = *reinterpret_cast<const float*>(jp + lstr);
+      const float j2r = *reinterpret_cast<const float*>(jp + 2u * lstr);
+      const float b0r = *reinterpret_cast<const float*>(jp + broff);
+      const float b1r = *reinterpret_cast<const float*>(jp + lstr + broff);
+      const float b2r = *reinterpret_cast<const float*>(jp + 2u * lstr + broff);
+      const float j1 = h1 ? j1r : 0.f, j2 = h2 ? j2r : 0.f;
+      const float b1 = h1 ? b1r : 0.f, b2 = h2 ? b2r : 0.f;
       // the block's uniform operands: one 64-byte record, four 16-byte LDS reads
-      const int bidx = is3 ? 8 + (row0 - nscalar) / 3 : row0 / 3;
-      const float4* rec = reinterpret_cast<const float4*>(s.blkrec[on ? bidx : 0]);
+      const float4* rec = reinterpret_cast<const float4*>(sb + (ent.x >> 16));
       const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
       const float4 r0 = make_float4(q0.x, q0.w, 0.f, q1.z);
       const float4 r1 = make_float4(q0.y, q1.x, 0.f, q1.w);
       const float4 r2 = make_float4(q0.z, q1.y, 0.f, q2.x);
-      const float f0 = s.frc[ra], f1 = h1 ? s.frc[rb] : 0.f, f2 = h2 ? s.frc[rc] : 0.f;
+      const float f0 = frc[row0], f1r = frc[row0 + 1], f2r = frc[row0 + 2];
+      const float f1 = h1 ? f1r : 0.f, f2 = h2 ? f2r : 0.f;
       float p0 = j0 * a, p1 = j1 * a, p2 = j2 * a;
       island_sum3(p0, p1, p2);
-      if (__any(partner != l)) {
-        const float q0 = __shfl(p0, partner, 64), q1 = __shfl(p1, partner, 64), q2 = __shfl(p2, partner, 64);
-        if (partner != l) { p0 += q0; p1 += q1; p2 += q2; }
+      if (__any((w1 & 0x40000u) != 0u)) {
+        const int src = (int)((w1 >> 10) & 0xFCu);  // partner lane * 4
+        const float x0 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, p0)));
+        const float x1 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, p1)));
+        const float x2 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, p2)));
+        if ((w1 & 0x40000u) != 0u) { p0 += x0; p1 += x1; p2 += x2; }
       }
       float d0 = 0.f, d1 = 0.f, d2 = 0.f, change = 0.f;
       if (on) {
@@ -658,7 +708,6 @@ MRE_PHASE_FN void solve_constraints(const DevModel* M, Sm& s, int l) {
         if (!is3) {
           // up to three sequential scalar updates; cross terms through the block's A entries.
           // Rows past nr are neutralised with selects (no divergent branches in this path).
-          const bool h1 = nr > 1, h2 = nr > 2;
           float fn = f0 - res0 * r0.w;
           fn = (row0 >= 7 && fn < 0.f) ? 0.f : fn;
           d0 = fn - f0;
@@ -719,15 +768,19 @@ MRE_PHASE_FN void solve_constraints(const DevModel* M, Sm& s, int l) {
           change = 0.5f * (d0 * Ad0 + d1 * Ad1 + d2 * Ad2) + d0 * res0 + d1 * res1 + d2 * res2;
           if (change > 1e-10f) { d0 = d1 = d2 = 0.f; change = 0.f; }
         }
-        if (isl == blk_primary(info)) impr -= change;
+        if ((w1 & 0x800u) != 0u) impr -= change;
         if (leader) {
           s.frc[row0] = f0 + d0;
-          if (nr > 1) s.frc[row0 + 1] = f1 + d1;
-          if (nr > 2) s.frc[row0 + 2] = f2 + d2;
+          if (h1) s.frc[row0 + 1] = f1 + d1;
+          if (h2) s.frc[row0 + 2] = f2 + d2;
         }
       }
-      a += b0 * d0 + b1 * d1 + b2 * d2;
-      w += j0 * d0 + j1 * d1 + j2 * d2;
+      // a += B'd, w += J'd (cube lanes: B = J / M_dof; lanes of an idle island keep d = 0, and
+      // their B operands are unspecified, hence the select)
+      const float wu = j0 * d0 + j1 * d1 + j2 * d2;
+      const float au = b0r * d0 + b1 * d1 + b2 * d2;
+      a += rob_lane ? (on ? au : 0.f) : linvM * wu;
+      w += wu;
       __syncthreads();
     }
     iters = iter + 1;

@@ -1,0 +1,29 @@
+"""Oracle PGS iteration histogram on the bench workload (CPU)."""
+import sys, numpy as np
+sys.path.insert(0, '.')
+import bench as B
+from mujoco_robot_environments_amd import placement, rng
+from mujoco_robot_environments_amd.model import compile as MC
+from oracle import oracle as O
+A = MC.compile_scene(); m = O.Model(MC.to_blob(A))
+nenv = 16; seed = 0; ids = np.arange(nenv)
+nprops, sizes = rng.prop_params(seed, ids)
+pose, _ = placement.sample_poses(seed, ids, nprops, sizes, B.WS_MIN, B.WS_MAX)
+envs = []
+for i in range(nenv):
+    e = O.Env(m, int(nprops[i]), sizes[i]); q = e.arr("qpos"); q[:7] = A["home_qpos"]
+    for p in range(int(nprops[i])): q[15+7*p:22+7*p] = pose[i, p]
+    e.freeze_robot(True); e.forward(); envs.append(e)
+O.batch_step(m, envs, None, 300, 8)
+for e in envs: e.freeze_robot(False)
+its = []
+for t in range(60):
+    acts = rng.random_actions(seed, ids, [t])[0]
+    for k in range(5):
+        for i, e in enumerate(envs):
+            e.arr("ctrl")[:8] = acts[i]
+            e.step(1)
+            its.append((e.solver_iters, e.nefc))
+its = np.array(its)
+print("iters: mean %.1f median %d p10 %d p90 %d max %d; frac==100: %.2f" % (its[:,0].mean(), np.median(its[:,0]), np.percentile(its[:,0],10), np.percentile(its[:,0],90), its[:,0].max(), (its[:,0]>=100).mean()))
+print("nefc mean", its[:,1].mean())
