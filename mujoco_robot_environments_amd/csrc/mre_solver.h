@@ -438,22 +438,27 @@ MRE_DEV float island_sum(float v) {
   return v;
 }
 
-// three island sums at once, level by level: the three chains interleave, which hides the DPP
-// read-after-write wait states the single-chain form pays with s_nop
-template <int CTRL, int ROW_MASK>
-MRE_DEV void dpp_add3(float& x, float& y, float& z) {
-  const int tx = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, ROW_MASK, 0xF, false);
-  const int ty = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y), CTRL, ROW_MASK, 0xF, false);
-  const int tz = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, z), CTRL, ROW_MASK, 0xF, false);
-  x += __builtin_bit_cast(float, tx);
-  y += __builtin_bit_cast(float, ty);
-  z += __builtin_bit_cast(float, tz);
-}
+// three island sums at once
 MRE_DEV void island_sum3(float& x, float& y, float& z) {
-  dpp_add3<0xB1, 0xF>(x, y, z);
-  dpp_add3<0x4E, 0xF>(x, y, z);
-  dpp_add3<0x141, 0xF>(x, y, z);
-  dpp_add3<0x140, 0x1>(x, y, z);
+  // one v_add_f32_dpp per value and level; the three chains interleave, which also provides the
+  // two wait states a DPP read needs after the VALU write of its source (s_nop covers the entry).
+  // The last level runs on DPP row 0 only: the other rows keep their 8-lane sums.
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %2, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_mirror row_mask:0x1 bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %1, %1 row_mirror row_mask:0x1 bank_mask:0xf\n\t"
+      "v_add_f32_dpp %2, %2, %2 row_mirror row_mask:0x1 bank_mask:0xf\n\t"
+      "s_nop 1"
+      : "+v"(x), "+v"(y), "+v"(z));
 }
 
 // J / B entry of row `row` for the dof this lane owns (rs = robot slot or NONE, slot = which
