@@ -39,17 +39,33 @@ def algorithmic_bytes_per_env_step(nprops: np.ndarray) -> float:
     return float(np.mean(4.0 * (2 * (15 + 7 * n) + 4 * (15 + 6 * n) + 8)))
 
 
-def pmc_traffic():
-    """HBM bytes per launch from the latest committed PMC pass (profiles/*_pmc_summary.json:
-    separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same bench command); the
-    counters cannot be read from inside the process, so the figure is carried over."""
+def pmc_summary():
+    """Latest committed PMC pass (profiles/*_pmc_summary.json: separate rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE / SQ_* runs of this same bench command); the counters cannot be read from inside
+    the process, so the per-launch figures are carried over."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
     if not files:
-        return None, None
+        return {}, None
     with open(files[-1]) as f:
-        d = json.load(f)
-    return d.get("traffic_bytes_per_launch"), os.path.basename(files[-1])
+        return json.load(f), os.path.basename(files[-1])
+
+
+def pmc_traffic():
+    d, name = pmc_summary()
+    return d.get("traffic_bytes_per_launch"), name
+
+
+def valu_issue(avg_launch_s):
+    """What actually bounds the kernel: VALU issue slots.  A wave64 VALU instruction occupies its
+    SIMD for 4 cycles (16 lanes per SIMD), so  util = SQ_INSTS_VALU * 4 / (SIMDs * clock * time)."""
+    d, name = pmc_summary()
+    n = d.get("SQ_INSTS_VALU_per_launch")
+    if not n or avg_launch_s <= 0:
+        return None
+    simds, clock = 256 * 4, 2.4e9  # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, 2.4 GHz peak engine clock
+    return {"valu_insts_per_launch": n, "cycles_per_wave64_inst": 4, "simds": simds, "clock_hz": clock,
+            "util": n * 4.0 / (simds * clock * avg_launch_s), "source": name}
 
 
 def setup_envs(phys, seed, env_ids, settle_steps=300):
@@ -208,7 +224,9 @@ def main():
                      "traffic_source": pmc_traffic()[1],
                      "kernel": "mre::k_step", "avg_launch_ms": avg_launch_s * 1e3, "launches": launches,
                      "algorithmic_bytes_per_launch": bytes_per_launch,
-                     "note": "path is dependency/latency bound (tree depth, PGS sweeps), not HBM bound"},
+                     "valu_issue": valu_issue(avg_launch_s) if (F == 1 and n_local == ENVS_PER_GPU) else None,
+                     "note": "path is bound by VALU issue of the sequential Gauss-Seidel sweeps (see valu_issue), "
+                             "not by HBM: per-env state stays in LDS across the 5 fused steps"},
         "health": {"nan_envs": int(((status & 2) != 0).sum()), "overflow_envs": int(((status & 4) != 0).sum()),
                    "mean_ncon": float(stats[:, 0].mean()), "mean_nefc": float(stats[:, 1].mean()),
                    "mean_pgs_iters": float(stats[:, 2].mean())},

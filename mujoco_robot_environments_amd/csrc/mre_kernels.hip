@@ -468,6 +468,19 @@ MRE_PHASE_FN void integrate(const DevModel* M, Sm& s, int l, bool grip_clamped, 
 }
 
 // =========================================================================
+// Diagnostic builds only (-DMRE_PHASE_STAMPS=set): per-phase s_memtime deltas of the launch are
+// summed into four buckets and returned through the stats rows (tools/phase_stamps.py).
+#ifdef MRE_PHASE_STAMPS
+#define MRE_STAMP(k)                                                         \
+  do {                                                                       \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();            \
+    if ((k) / 4 == MRE_PHASE_STAMPS) stamp_acc[(k) % 4] += now_ - stamp_t;   \
+    stamp_t = now_;                                                          \
+  } while (0)
+#else
+#define MRE_STAMP(k) do {} while (0)
+#endif
+
 // Body of one launch (nsteps physics steps of one env per workgroup); instantiated by the two
 // entry points below so that profiler summaries separate control ticks from settling launches.
 MRE_DEV void step_body(const StepArgs& a, Sm& s) {
@@ -503,6 +516,10 @@ MRE_DEV void step_body(const StepArgs& a, Sm& s) {
   }
   __syncthreads();
 
+#ifdef MRE_PHASE_STAMPS
+  unsigned long long stamp_acc[4] = {0, 0, 0, 0};
+  unsigned long long stamp_t = __builtin_amdgcn_s_memtime();
+#endif
   bool arm_converged = false;
   float grip_cmd = 0.f;
   if (a.mode == CTRL_OSC) {
@@ -513,25 +530,28 @@ MRE_DEV void step_body(const StepArgs& a, Sm& s) {
   }
   for (int step = 0; step < a.nsteps; ++step) {
     // ------------------------------------------------ S1: position stage
-
+    MRE_STAMP(7);
     position_stage(M, s, l);
     crb_mass_matrix(M, s, l);
     __syncthreads();
     for (int e = l; e < NMR; e += 64) s.qLD[e] = s.qM[e];
     __syncthreads();
     factor_robot(M, s.qLD, s.qLDinv, l);
+    MRE_STAMP(0);
     // ------------------------------------------------ S1b: velocity stage (before collision:
     // its temporaries share LDS region R2 with the contact geometry)
 
     velocity_stage(M, s, l);
     __syncthreads();
+    MRE_STAMP(1);
     // ------------------------------------------------ S1c: collision + constraint assembly
     const bool constrained = (a.flags & F_NO_CONSTRAINTS) == 0;
     if (constrained) {
 
       collide(M, s, l);
-
+      MRE_STAMP(2);
       assemble_constraints(M, s, l);
+      MRE_STAMP(3);
     }
 
     // ------------------------------------------------ control at tick boundary
@@ -549,10 +569,12 @@ MRE_DEV void step_body(const StepArgs& a, Sm& s) {
       __syncthreads();
     }
     // ------------------------------------------------ S2
+    MRE_STAMP(4);
     const bool clamped = smooth_forces(M, s, l);
-
+    MRE_STAMP(5);
     if (constrained) {
       solve_constraints(M, s, l);
+      MRE_STAMP(6);
     } else {
       if (l < NVP) { s.qacc[l] = s.qacc_smooth[l]; s.qfrc_con[l] = 0.f; }
       __syncthreads();
@@ -564,6 +586,7 @@ MRE_DEV void step_body(const StepArgs& a, Sm& s) {
         a.trace[((size_t)(a.trace_base + step) * a.trace_nenv + env) * NQP + l] = s.qpos[l];
     }
   }
+  MRE_STAMP(7);
   // ---- final kinematics for site queries
   kinematics_only(M, s, l);
   if (a.mode == CTRL_OSC && a.nsteps > 0) {
@@ -598,6 +621,9 @@ MRE_DEV void step_body(const StepArgs& a, Sm& s) {
     if (a.stats != nullptr && a.nsteps > 0) {
       a.stats[env * 4 + 0] = s.ncon; a.stats[env * 4 + 1] = s.nefc;
       a.stats[env * 4 + 2] = s.solver_iters; a.stats[env * 4 + 3] = s.nl;
+#ifdef MRE_PHASE_STAMPS
+      for (int k = 0; k < 4; k++) a.stats[env * 4 + k] = (int)(stamp_acc[k] >> 4);
+#endif
     }
   }
 }

@@ -62,10 +62,11 @@ def lib() -> C.CDLL:
     global _LIB
     if _LIB is not None:
         return _LIB
-    if not os.path.exists(_SO):
-        raise MreError(f"{_SO} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+    so = os.environ.get("MRE_LIB", _SO)  # diagnostic builds (tools/phase_stamps.py) only
+    if not os.path.exists(so):
+        raise MreError(f"{so} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                        "(the HIP extension is the only implementation of the step)")
-    L = C.CDLL(_SO)
+    L = C.CDLL(so)
     vp, ci, cu, fp = C.c_void_p, C.c_int, C.c_uint, C.c_void_p
     L.mre_create.argtypes = [C.c_char_p, C.c_size_t, ci, ci, C.POINTER(vp)]
     L.mre_destroy.argtypes = [vp]
