@@ -229,7 +229,7 @@ def main():
                              "not by HBM: per-env state stays in LDS across the 5 fused steps"},
         "health": {"nan_envs": int(((status & 2) != 0).sum()), "overflow_envs": int(((status & 4) != 0).sum()),
                    "mean_ncon": float(stats[:, 0].mean()), "mean_nefc": float(stats[:, 1].mean()),
-                   "mean_pgs_iters": float(stats[:, 2].mean())},
+                   "mean_pgs_iters": float(stats[:, 2].mean()), "capacity_fallback": phys.fallback_stats()},
         "gather_ms": gather_ms,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -128,6 +128,18 @@ int mre_get_solver_stats(mre_env*, int32_t* stats);
  * env, so callers may put envs with many constraint rows first (see mre_get_solver_stats). */
 int mre_set_env_order(mre_env*, const int32_t* order);
 
+/* Constraint capacities.  The library holds the step kernel in two capacity sets
+ * (csrc/mre_dev.h): compact (32 contacts / 112 rows / 50 robot rows / 8 cube-cube contacts, 8
+ * workgroups per CU) and large (48 / 160 / 100 / 16, 5 per CU).  By default every launch runs each
+ * env on the compact kernel, re-runs from the saved pre-launch state on the large kernel the envs
+ * that overflowed it, and keeps them there until their contact set has shrunk again -- results
+ * never depend on the compact capacities, and MRE_ST_CONTACT_OVERFLOW reports an overflow of the
+ * LARGE ones only.  mre_set_fallback(0) pins all envs to the compact kernel (status then reports
+ * compact overflows; profiling and capacity tests).  Stats: out4 = {envs currently on the large
+ * kernel, env launches re-run so far, promotions, demotions}. */
+int mre_set_fallback(mre_env*, int enabled);
+int mre_get_fallback_stats(mre_env*, long long* out4);
+
 /* measurement support for bench.py: when enabled every step-kernel launch is
  * bracketed by hipEvents on the handle's stream; mre_profile_read synchronises and
  * returns the summed kernel time [ms] and launch count since enable (and resets). */

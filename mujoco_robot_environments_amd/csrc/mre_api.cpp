@@ -18,6 +18,16 @@ using namespace mre;
 
 extern "C" void mre_launch_step(const StepArgs* args, hipStream_t stream);
 extern "C" void mre_launch_settle(const StepArgs* args, hipStream_t stream);
+extern "C" void mre_launch_step_large(const StepArgs* args, hipStream_t stream);
+extern "C" void mre_launch_prepare(const uint8_t* user_mask, const uint8_t* large, int N, uint8_t* mask_compact,
+                                   uint8_t* mask_large, int* launch_info, const float* qpos, float* sv_qpos,
+                                   const float* qvel, float* sv_qvel, const float* qacc_ws, float* sv_qacc_ws,
+                                   const float* ctrl, float* sv_ctrl, const uint32_t* status, uint32_t* sv_status,
+                                   hipStream_t stream);
+extern "C" void mre_launch_restore_rows(const uint8_t* sel, int N, float* qpos, const float* sv_qpos, float* qvel,
+                                        const float* sv_qvel, float* qacc_ws, const float* sv_qacc_ws, float* ctrl,
+                                        const float* sv_ctrl, uint32_t* status, const uint32_t* sv_status,
+                                        hipStream_t stream);
 extern "C" void mre_launch_reset(const DevModel* M, int N, float* qpos, float* qvel, float* qacc_ws,
                                  float* ctrl, uint32_t* status, const uint8_t* mask,
                                  hipStream_t stream);
@@ -59,10 +69,33 @@ struct mre_env {
   bool profiling = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
   size_t events_used = 0;
+  // ---- capacity fallback (see launch_step): per-env kernel choice, pre-launch state copies
+  bool fallback = true;
+  hipStream_t stream2 = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  uint8_t *d_large = nullptr, *mask_c = nullptr, *mask_l = nullptr, *mask_r = nullptr;
+  float *sv_qpos = nullptr, *sv_qvel = nullptr, *sv_qacc_ws = nullptr, *sv_ctrl = nullptr;
+  uint32_t* sv_status = nullptr;
+  int* launch_info = nullptr;    // device [N][4]
+  int* h_launch_info = nullptr;  // pinned host mirror
+  std::vector<uint8_t> h_large, h_rerun;
+  int n_large = 0;
+  long long n_reruns = 0, n_promotions = 0, n_demotions = 0;
 };
 
-// launch the step kernel, optionally bracketed by HIP events on the handle's stream
-static int launch_step(mre_env* e, const StepArgs& a) {
+// Launch the step kernel, optionally bracketed by HIP events on the handle's stream.
+//
+// Capacity fallback.  The compact kernel (8 workgroups/CU) holds at most NCON_MAX / NEFC_MAX /
+// NRROW_MAX / NPP_MAX constraints per env; a grasp or a pile needs more.  Every launch therefore
+//   1. copies the state rows (qpos, qvel, warm start, ctrl, status) aside (one small kernel),
+//   2. runs the envs currently marked "large" on the large-capacity kernel (second stream, own
+//      mask) next to the compact kernel for all others,
+//   3. reads back per-env launch info (overflow flag + high-water marks of the launch),
+//   4. restores the envs that overflowed on the compact kernel to their saved rows, marks them
+//      large and runs them again on the large kernel -- so no result ever depends on the compact
+//      capacities -- and demotes large envs whose high-water marks fell below 3/4 of them.
+// Only an overflow of the LARGE capacities is reported (MRE_ST_CONTACT_OVERFLOW).
+static int launch_step(mre_env* e, const StepArgs& a, bool settle = false) {
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (e->profiling) {
     if (e->events_used == e->events.size()) {
@@ -74,8 +107,60 @@ static int launch_step(mre_env* e, const StepArgs& a) {
     e->events_used++;
     HIPCHK(hipEventRecord(e0, e->stream));
   }
-  mre_launch_step(&a, e->stream);
-  HIPCHK(hipGetLastError());
+  const bool guarded = e->fallback && a.nsteps > 0 && (a.flags & F_NO_CONSTRAINTS) == 0;
+  if (!guarded) {
+    if (settle) mre_launch_settle(&a, e->stream); else mre_launch_step(&a, e->stream);
+    HIPCHK(hipGetLastError());
+  } else {
+    const size_t N = (size_t)e->N;
+    mre_launch_prepare(a.env_mask, e->d_large, e->N, e->mask_c, e->mask_l, e->launch_info, e->qpos, e->sv_qpos,
+                       e->qvel, e->sv_qvel, e->qacc_ws, e->sv_qacc_ws, e->ctrl, e->sv_ctrl, e->status, e->sv_status,
+                       e->stream);
+    StepArgs ac = a;
+    ac.env_mask = e->mask_c; ac.launch_info = e->launch_info;
+    if (e->n_large > 0) {
+      HIPCHK(hipEventRecord(e->ev_fork, e->stream));
+      HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_fork, 0));
+      StepArgs al = a;
+      al.env_mask = e->mask_l; al.launch_info = e->launch_info;
+      mre_launch_step_large(&al, e->stream2);
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipEventRecord(e->ev_join, e->stream2));
+    }
+    if (settle) mre_launch_settle(&ac, e->stream); else mre_launch_step(&ac, e->stream);
+    HIPCHK(hipGetLastError());
+    if (e->n_large > 0) HIPCHK(hipStreamWaitEvent(e->stream, e->ev_join, 0));
+    HIPCHK(hipMemcpyAsync(e->h_launch_info, e->launch_info, N * 16, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    int nrerun = 0;
+    bool changed = false;
+    for (size_t i = 0; i < N; i++) {
+      const int* li = e->h_launch_info + 4 * i;
+      e->h_rerun[i] = 0;
+      if (li[0] < 0) continue;
+      if (!e->h_large[i]) {
+        if (li[0] > 0) { e->h_rerun[i] = 1; e->h_large[i] = 1; nrerun++; changed = true; e->n_large++; e->n_promotions++; }
+      } else if (li[0] == 0 && 4 * li[1] <= 3 * NCON_MAX && 4 * li[2] <= 3 * NEFC_MAX &&
+                 4 * (li[3] & 0xFFFF) <= 3 * NRROW_MAX && 4 * (li[3] >> 16) <= 3 * NPP_MAX) {
+        e->h_large[i] = 0; changed = true; e->n_large--; e->n_demotions++;
+      }
+    }
+    if (nrerun > 0) {
+      HIPCHK(hipMemcpyAsync(e->mask_r, e->h_rerun.data(), N, hipMemcpyHostToDevice, e->stream));
+      mre_launch_restore_rows(e->mask_r, e->N, e->qpos, e->sv_qpos, e->qvel, e->sv_qvel, e->qacc_ws, e->sv_qacc_ws,
+                              e->ctrl, e->sv_ctrl, e->status, e->sv_status, e->stream);
+      StepArgs ar = a;
+      ar.env_mask = e->mask_r; ar.launch_info = nullptr;
+      mre_launch_step_large(&ar, e->stream);
+      HIPCHK(hipGetLastError());
+      e->n_reruns += nrerun;
+    }
+    if (changed) {
+      // the staged copy must outlive the async upload: h_large is only touched after a stream sync
+      HIPCHK(hipMemcpyAsync(e->d_large, e->h_large.data(), N, hipMemcpyHostToDevice, e->stream));
+      HIPCHK(hipStreamSynchronize(e->stream));
+    }
+  }
   if (e1) HIPCHK(hipEventRecord(e1, e->stream));
   return MRE_OK;
 }
@@ -266,6 +351,24 @@ extern "C" int mre_create(const void* blob, size_t nbytes, int num_envs, int dev
   HIPCHK(hipMalloc(&e->sites, N * 16 * 4));
   HIPCHK(hipMalloc(&e->status, N * 4)); HIPCHK(hipMalloc(&e->stats, N * 4 * 4));
   HIPCHK(hipMalloc(&e->order, N * 4));
+  HIPCHK(hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking));
+  HIPCHK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
+  HIPCHK(hipMalloc(&e->d_large, N)); HIPCHK(hipMalloc(&e->mask_c, N)); HIPCHK(hipMalloc(&e->mask_l, N));
+  HIPCHK(hipMalloc(&e->mask_r, N));
+  HIPCHK(hipMalloc(&e->sv_qpos, N * NQP * 4)); HIPCHK(hipMalloc(&e->sv_qvel, N * NVP * 4));
+  HIPCHK(hipMalloc(&e->sv_qacc_ws, N * NVP * 4)); HIPCHK(hipMalloc(&e->sv_ctrl, N * NU * 4));
+  HIPCHK(hipMalloc(&e->sv_status, N * 4)); HIPCHK(hipMalloc(&e->launch_info, N * 16));
+  HIPCHK(hipHostMalloc((void**)&e->h_launch_info, N * 16, hipHostMallocDefault));
+  HIPCHK(hipMemset(e->d_large, 0, N));
+  e->h_large.assign(N, 0); e->h_rerun.assign(N, 0);
+  if (const char* fb = getenv("MRE_NO_FALLBACK")) e->fallback = atoi(fb) == 0;  // profiling knob only
+  if (const char* fl = getenv("MRE_FORCE_LARGE")) {  // profiling knob only: start every env on the large kernel
+    if (atoi(fl) != 0) {
+      e->h_large.assign(N, 1); e->n_large = num_envs;
+      HIPCHK(hipMemset(e->d_large, 1, N));
+    }
+  }
   HIPCHK(hipMemset(e->status, 0, N * 4)); HIPCHK(hipMemset(e->stats, 0, N * 16));
   HIPCHK(hipMemset(e->grip_closed, 0, N)); HIPCHK(hipMemset(e->osc_target, 0, N * 64));
   HIPCHK(hipMemset(e->sites, 0, N * 64));
@@ -289,9 +392,16 @@ extern "C" int mre_destroy(mre_env* e) {
   if (!e) return MRE_OK;
   (void)hipSetDevice(e->device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
+  if (e->stream2) (void)hipStreamSynchronize(e->stream2);
   void* ptrs[] = {e->dM, e->qpos, e->qvel, e->qacc_ws, e->ctrl, e->nprops, e->prop_size, e->osc_target,
-                  e->grip_closed, e->converged, e->mask, e->sites, e->status, e->stats, e->d_osc, e->order};
+                  e->grip_closed, e->converged, e->mask, e->sites, e->status, e->stats, e->d_osc, e->order,
+                  e->d_large, e->mask_c, e->mask_l, e->mask_r, e->sv_qpos, e->sv_qvel, e->sv_qacc_ws, e->sv_ctrl,
+                  e->sv_status, e->launch_info};
   for (void* p : ptrs) if (p) (void)hipFree(p);
+  if (e->h_launch_info) (void)hipHostFree(e->h_launch_info);
+  if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+  if (e->ev_join) (void)hipEventDestroy(e->ev_join);
+  if (e->stream2) (void)hipStreamDestroy(e->stream2);
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
   return MRE_OK;
@@ -337,6 +447,26 @@ extern "C" int mre_reset(mre_env* e, const uint8_t* mask) {
   if (rc) return rc;
   mre_launch_reset(e->dM, e->N, e->qpos, e->qvel, e->qacc_ws, e->ctrl, e->status, dmask, e->stream);
   HIPCHK(hipGetLastError());
+  // a reset env starts on the compact kernel again
+  bool changed = false;
+  for (int i = 0; i < e->N; i++)
+    if (e->h_large[i] && (!mask || mask[i])) { e->h_large[i] = 0; e->n_large--; changed = true; }
+  if (changed) {
+    HIPCHK(hipMemcpyAsync(e->d_large, e->h_large.data(), (size_t)e->N, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+  }
+  return MRE_OK;
+}
+
+extern "C" int mre_set_fallback(mre_env* e, int enabled) {
+  if (!e) return fail(MRE_ERR_ARG, "null handle");
+  e->fallback = enabled != 0;
+  return MRE_OK;
+}
+
+extern "C" int mre_get_fallback_stats(mre_env* e, long long* out4) {
+  if (!e || !out4) return fail(MRE_ERR_ARG, "mre_get_fallback_stats: null");
+  out4[0] = e->n_large; out4[1] = e->n_reruns; out4[2] = e->n_promotions; out4[3] = e->n_demotions;
   return MRE_OK;
 }
 
@@ -612,8 +742,11 @@ extern "C" int mre_place_props(mre_env* e, const uint8_t* mask, uint64_t seed, c
     fill_args(e, a);
     a.trace = nullptr;
     a.nsteps = settle_steps; a.flags = F_FREEZE_ROBOT; a.env_mask = dmask;
-    mre_launch_settle(&a, e->stream);
-    HIPCHK(hipGetLastError());
+    const bool prof = e->profiling;
+    e->profiling = false;  // setup, not a control tick
+    rc = launch_step(e, a, /*settle=*/true);
+    e->profiling = prof;
+    if (rc) return rc;
     HIPCHK(hipStreamSynchronize(e->stream));
   }
   return MRE_OK;

@@ -24,11 +24,26 @@ constexpr int NSITE = 2;
 constexpr int NEQ = 3;
 constexpr int MAXCHAIN = 9;   // longest dof chain root->leaf (7 arm + 2 finger)
 constexpr int MAXFAC = 45;    // (i,j) ancestor pairs touched by one elimination step
-constexpr int NCON_MAX = 32;  // active contacts kept per env
-constexpr int NEFC_MAX = 112; // constraint rows per env (7 equality + limits + 3 per contact)
-constexpr int NRROW_MAX = 50; // rows with a robot part (7 equality + limits + 3 per robot contact)
-constexpr int NPP_MAX = 8;    // cube-cube contacts (rows with two prop parts)
-constexpr int MAXBLK = 40;    // <= 8 scalar-row triples + NCON_MAX contact blocks (also bounds the schedule length)
+// Per-env constraint capacities (LDS is sized for them).  The library carries the step kernel in
+// two capacity sets: the compact one keeps a workgroup at 20 KB of LDS (8 workgroups per CU) and
+// covers cubes resting / sliding on the table; the large one (5 per CU) covers grasps and piles.
+// mre_api.cpp runs every env on the compact kernel and re-runs, from the saved pre-launch state, the
+// envs that report an overflow on the large kernel, so results never depend on the compact caps.
+#ifdef MRE_LARGE_CAPS
+constexpr int NCON_MAX = 48;   // active contacts kept per env
+constexpr int NEFC_MAX = 160;  // constraint rows per env (7 equality + limits + 3 per contact)
+constexpr int NRROW_MAX = 100; // rows with a robot part (7 equality + limits + 3 per robot contact)
+constexpr int NPP_MAX = 16;    // cube-cube contacts (rows with two prop parts)
+constexpr int MAXBLK = 56;     // <= 8 scalar-row triples + NCON_MAX contact blocks (also bounds the schedule length)
+#else
+constexpr int NCON_MAX = 32;
+constexpr int NEFC_MAX = 112;
+constexpr int NRROW_MAX = 50;
+constexpr int NPP_MAX = 8;
+constexpr int MAXBLK = 40;
+#endif
+static_assert(NEFC_MAX <= 256 && NRROW_MAX < 127 && NPP_MAX <= 16 && MAXBLK >= 8 + NCON_MAX,
+              "capacities must fit the block descriptor fields (mre_solver.h)");
 
 struct DevModel {
   // ---- bodies (index = body id)
@@ -110,6 +125,8 @@ struct StepArgs {
   int trace_nenv, trace_max, trace_base;
   const uint8_t* env_mask;   // [N] or null: envs with 0 are skipped by this launch
   const int* env_order;      // [N] or null: workgroup b steps env env_order[b] (heavy-first dispatch)
+  int* launch_info;          // [N][4] or null: {overflowed in this launch, max ncon, max nefc,
+                             //  max robot rows | max cube-cube contacts << 16} over the launch's steps
 };
 
 }  // namespace mre

@@ -27,6 +27,20 @@ struct OscSm {
   float ep[3], eo[3], F[6], LF[6], tn[7], Jbt[6], xd[6], w[6];
 };
 
+// constraint block: a triple of scalar rows (type 0) or the three rows of a contact (type 2)
+struct alignas(8) Blk {
+  uint16_t row0;            // first efc row
+  uint8_t type, nrows;
+  uint8_t rslot;            // first robot-row slot or BLK_NONE
+  uint8_t pa, pb;           // cubes touched (0xF = none)
+  uint8_t primary : 4;      // island that accounts the block's cost change
+  uint8_t bslot : 4;        // slot of the second cube's Jacobian part (cube-cube contacts)
+};
+
+// bytes the solver's operand table needs on top of the body-frame arrays (mre_solver.h)
+constexpr int TAB_BYTES = 8 * (MAXBLK * 5 + 1) + 4 * 48;
+constexpr int R1_MIN = TAB_BYTES - 4 * (NB * 16) > 0 ? TAB_BYTES - 4 * (NB * 16) : 4;
+
 struct Sm {
   // state
   float qpos[NQP], qvel[NVP], qacc_ws[NVP], ctrl[NU];
@@ -39,6 +53,7 @@ struct Sm {
   union {  // R1: spatial inertias (S1a/S1b) | OSC scratch (tick boundary)
     struct { float cinert[NB][10], crb[NRB][10]; };
     OscSm osc;
+    char tab_room[R1_MIN];  // (solve) tail of the operand table
   };
   float cdof[NRV][6];  // robot dofs only; cube cdofs are implicit (prop_cdof)
   union {  // R2: velocity-stage temporaries (S1b) | contact geometry (S1c) | jar + forces (S2)
@@ -56,7 +71,7 @@ struct Sm {
   float osc_tgt[16];
   int nprops;
   // active contacts (pair order)
-  int ncon, nefc, nl, nrrow, overflow, solver_iters;
+  int ncon, nefc, nl, nrrow, npp, overflow, solver_iters;
   uint8_t con_pair[NCON_MAX], con_rslot[NCON_MAX], con_bslot[NCON_MAX];
   uint16_t lim_info[NRV + 1];
   // ---- contiguous block [JpA .. sched]: written only after collision; hosts the per-lane
@@ -69,9 +84,9 @@ struct Sm {
   // [9:15] symmetric 3x3 block of A (00,01,02,11,12,22), [15] friction coefficient
   alignas(16) float blkrec[MAXBLK][16];
   // constraint blocks (scalar row or 3-row contact) and their island schedule
-  int blk_info[MAXBLK];
+  Blk blk[MAXBLK];
   uint16_t hdr[NEFC_MAX];  // per row: robot slot | propA << 8 | propB << 12
-  int sched[MAXBLK][5];   // per (schedule step, island): block descriptor word or -1
+  uint8_t sched[MAXBLK][8];  // per (schedule step, island < 5): block index or SCHED_NONE
 
   int nblk, nsched;
 };
@@ -522,6 +537,7 @@ MRE_DEV void step_body(const StepArgs& a, Sm& s) {
 #endif
   bool arm_converged = false;
   float grip_cmd = 0.f;
+  int hw_ncon = 0, hw_nefc = 0, hw_nrrow = 0, hw_npp = 0;  // high-water marks of this launch
   if (a.mode == CTRL_OSC) {
     if (l < 16) s.osc_tgt[l] = a.osc_target[(size_t)env * 16 + l];
     // MinMax.compute_control_output: max_val 255 (closed) / min_val 0 (open), min_max.yaml:3-4
@@ -552,6 +568,8 @@ MRE_DEV void step_body(const StepArgs& a, Sm& s) {
       MRE_STAMP(2);
       assemble_constraints(M, s, l);
       MRE_STAMP(3);
+      hw_ncon = max(hw_ncon, s.ncon); hw_nefc = max(hw_nefc, s.nefc);
+      hw_nrrow = max(hw_nrrow, s.nrrow); hw_npp = max(hw_npp, s.npp);
     }
 
     // ------------------------------------------------ control at tick boundary
@@ -613,6 +631,10 @@ MRE_DEV void step_body(const StepArgs& a, Sm& s) {
     a.qacc_ws[(size_t)env * NVP + l] = s.qacc_ws[l];
   }
   if (l < NU) a.ctrl[(size_t)env * NU + l] = s.ctrl[l];
+  if (l == 0 && a.launch_info != nullptr) {
+    int* li = a.launch_info + (size_t)env * 4;
+    li[0] = s.overflow; li[1] = hw_ncon; li[2] = hw_nefc; li[3] = hw_nrrow | (hw_npp << 16);
+  }
   if (l == 0 && a.status != nullptr) {
     unsigned st = 0;
     for (int k = 0; k < NQ; k++) if (!isfinite(s.qpos[k])) st |= 2u;
@@ -628,6 +650,18 @@ MRE_DEV void step_body(const StepArgs& a, Sm& s) {
   }
 }
 
+#ifdef MRE_LARGE_CAPS
+// large-capacity instantiation (second translation unit, see mre_dev.h)
+__global__ __launch_bounds__(64, 2) void k_step_large(StepArgs a) {
+  __shared__ Sm s;
+  step_body(a, s);
+}
+}  // namespace mre
+
+extern "C" void mre_launch_step_large(const mre::StepArgs* args, hipStream_t stream) {
+  hipLaunchKernelGGL(mre::k_step_large, dim3(args->N), dim3(64), 0, stream, *args);
+}
+#else
 // control ticks: mre_step / mre_rollout / mre_run_controller
 __global__ __launch_bounds__(64, 2) void k_step(StepArgs a) {
   __shared__ Sm s;
@@ -661,7 +695,66 @@ __global__ __launch_bounds__(64) void k_reset(const DevModel* M, int N, float* q
   if (l == 0) status[env] = 0u;
 }
 
+// ---- capacity fallback helpers (mre_api.cpp: launch_step)
+// one pass before a guarded launch (one workgroup per env): copy the env's state rows aside, mark its
+// launch info "not part of this launch", and split the launch between the two kernels -- envs flagged
+// `large` run on the large-capacity kernel
+__global__ __launch_bounds__(64) void k_prepare(const uint8_t* user_mask, const uint8_t* large, int N,
+                                                uint8_t* mask_compact, uint8_t* mask_large, int* launch_info,
+                                                const float* qpos, float* sv_qpos, const float* qvel, float* sv_qvel,
+                                                const float* qacc_ws, float* sv_qacc_ws, const float* ctrl,
+                                                float* sv_ctrl, const uint32_t* status, uint32_t* sv_status) {
+  const int env = blockIdx.x, l = threadIdx.x;
+  if (env >= N) return;
+  if (l < NQP) sv_qpos[(size_t)env * NQP + l] = qpos[(size_t)env * NQP + l];
+  if (l < NVP) {
+    sv_qvel[(size_t)env * NVP + l] = qvel[(size_t)env * NVP + l];
+    sv_qacc_ws[(size_t)env * NVP + l] = qacc_ws[(size_t)env * NVP + l];
+  }
+  if (l < NU) sv_ctrl[(size_t)env * NU + l] = ctrl[(size_t)env * NU + l];
+  if (l < 4) launch_info[(size_t)env * 4 + l] = -1;
+  if (l == 0) {
+    sv_status[env] = status[env];
+    const bool on = user_mask == nullptr || user_mask[env] != 0;
+    mask_compact[env] = on && !large[env];
+    mask_large[env] = on && large[env];
+  }
+}
+
+// put the selected envs back to their saved pre-launch state (one workgroup per env)
+__global__ __launch_bounds__(64) void k_restore_rows(const uint8_t* sel, int N, float* qpos, const float* sv_qpos,
+                                                     float* qvel, const float* sv_qvel, float* qacc_ws,
+                                                     const float* sv_qacc_ws, float* ctrl, const float* sv_ctrl,
+                                                     uint32_t* status, const uint32_t* sv_status) {
+  const int env = blockIdx.x, l = threadIdx.x;
+  if (env >= N || sel[env] == 0) return;
+  if (l < NQP) qpos[(size_t)env * NQP + l] = sv_qpos[(size_t)env * NQP + l];
+  if (l < NVP) {
+    qvel[(size_t)env * NVP + l] = sv_qvel[(size_t)env * NVP + l];
+    qacc_ws[(size_t)env * NVP + l] = sv_qacc_ws[(size_t)env * NVP + l];
+  }
+  if (l < NU) ctrl[(size_t)env * NU + l] = sv_ctrl[(size_t)env * NU + l];
+  if (l == 0) status[env] = sv_status[env];
+}
+
 }  // namespace mre
+
+extern "C" void mre_launch_prepare(const uint8_t* user_mask, const uint8_t* large, int N, uint8_t* mask_compact,
+                                   uint8_t* mask_large, int* launch_info, const float* qpos, float* sv_qpos,
+                                   const float* qvel, float* sv_qvel, const float* qacc_ws, float* sv_qacc_ws,
+                                   const float* ctrl, float* sv_ctrl, const uint32_t* status, uint32_t* sv_status,
+                                   hipStream_t stream) {
+  hipLaunchKernelGGL(mre::k_prepare, dim3(N), dim3(64), 0, stream, user_mask, large, N, mask_compact, mask_large,
+                     launch_info, qpos, sv_qpos, qvel, sv_qvel, qacc_ws, sv_qacc_ws, ctrl, sv_ctrl, status, sv_status);
+}
+
+extern "C" void mre_launch_restore_rows(const uint8_t* sel, int N, float* qpos, const float* sv_qpos, float* qvel,
+                                        const float* sv_qvel, float* qacc_ws, const float* sv_qacc_ws, float* ctrl,
+                                        const float* sv_ctrl, uint32_t* status, const uint32_t* sv_status,
+                                        hipStream_t stream) {
+  hipLaunchKernelGGL(mre::k_restore_rows, dim3(N), dim3(64), 0, stream, sel, N, qpos, sv_qpos, qvel, sv_qvel,
+                     qacc_ws, sv_qacc_ws, ctrl, sv_ctrl, status, sv_status);
+}
 
 extern "C" void mre_launch_reset(const mre::DevModel* M, int N, float* qpos, float* qvel, float* qacc_ws,
                                  float* ctrl, uint32_t* status, const uint8_t* mask, hipStream_t stream) {
@@ -675,3 +768,4 @@ extern "C" void mre_launch_step(const mre::StepArgs* args, hipStream_t stream) {
 extern "C" void mre_launch_settle(const mre::StepArgs* args, hipStream_t stream) {
   hipLaunchKernelGGL(mre::k_settle, dim3(args->N), dim3(64), 0, stream, *args);
 }
+#endif  // MRE_LARGE_CAPS

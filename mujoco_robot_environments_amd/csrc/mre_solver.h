@@ -19,10 +19,12 @@ namespace mre {
 
 constexpr int HDR_NONE = 0xFF;
 constexpr int BLK_NONE = 0x7F;
+constexpr int SCHED_NONE = 0xFF;
 // solver operand table (solve_constraints): entries for MAXBLK steps x 5 islands, one all-off
-// entry, then a pad of zeros that idle islands read their Jacobian rows from
+// entry, then a pad of zeros that idle islands read their Jacobian rows from (TAB_BYTES in all)
 constexpr int TAB_OFF = MAXBLK * 5;
 constexpr int TAB_ZEROS = 48;
+static_assert(TAB_BYTES == 8 * (TAB_OFF + 1) + 4 * TAB_ZEROS, "operand table size");
 
 MRE_DEV void build_schedule(const DevModel* M, Sm& s);
 
@@ -239,6 +241,7 @@ MRE_PHASE_FN void assemble_constraints(const DevModel* M, Sm& s, int l) {
     s.ncon = kept;
     s.nefc = base + 3 * kept;
     s.nrrow = rnext;
+    s.npp = bnext;
     build_schedule(M, s);
   }
   __syncthreads();
@@ -473,16 +476,7 @@ MRE_DEV void lane_JB(const Sm& s, int row, int rs, int l, int lk, int slot, floa
   }
 }
 
-// block descriptor helpers
-MRE_DEV int blk_type(int info) { return info & 3; }
-MRE_DEV int blk_row0(int info) { return (info >> 2) & 0x7F; }
-MRE_DEV int blk_rslot(int info) { return (info >> 9) & 0x7F; }
-MRE_DEV int blk_pa(int info) { return (info >> 16) & 0xF; }
-MRE_DEV int blk_pb(int info) { return (info >> 20) & 0xF; }
-MRE_DEV int blk_primary(int info) { return (info >> 24) & 0x7; }
-MRE_DEV int blk_nrows(int info) { return (info >> 27) & 0x3; }
-MRE_DEV int blk_bslot(int info) { return (info >> 29) & 0x7; }
-
+// (block descriptor: struct Blk, declared next to struct Sm)
 
 // Build the block list (global MuJoCo row order) and its ASAP schedule: block b runs at
 // step 1 + max(last step of every island it touches).  Blocks of one step touch disjoint
@@ -494,12 +488,14 @@ MRE_DEV void build_schedule(const DevModel* M, Sm& s) {
   const int nscalar = 7 + s.nl;
   int nb = 0, nst = 0;
   for (int st = 0; st < MAXBLK; st++)
-    for (int k = 0; k < 5; k++) s.sched[st][k] = -1;
+    for (int k = 0; k < 5; k++) s.sched[st][k] = SCHED_NONE;
   for (int i = 0; i < nscalar; i += 3) {
-    const int nr = (nscalar - i) < 3 ? (nscalar - i) : 3;
-    s.blk_info[nb] = 0 | (i << 2) | (i << 9) | (0xF << 16) | (0xF << 20) | (0 << 24) | (nr << 27);
+    Blk b;
+    b.row0 = (uint16_t)i; b.type = 0; b.nrows = (uint8_t)((nscalar - i) < 3 ? (nscalar - i) : 3);
+    b.rslot = (uint8_t)i; b.pa = 0xF; b.pb = 0xF; b.primary = 0; b.bslot = 0;
     const int st = last[0]++;
-    s.sched[st][0] = s.blk_info[nb++];
+    s.sched[st][0] = (uint8_t)nb;
+    s.blk[nb++] = b;
     if (last[0] > nst) nst = last[0];
   }
   for (int c = 0; c < s.ncon; c++) {
@@ -514,15 +510,15 @@ MRE_DEV void build_schedule(const DevModel* M, Sm& s) {
     if (hr && last[0] > st) st = last[0];
     if (ha && last[1 + pa] > st) st = last[1 + pa];
     if (hb && last[1 + pb] > st) st = last[1 + pb];
-    const int rsl = hr ? rs : BLK_NONE;
-    const int prim = hr ? 0 : 1 + pa;
-    const int bsl = hb ? s.con_bslot[c] : 0;
-    const int word = 2 | ((nscalar + 3 * c) << 2) | (rsl << 9) | (pa << 16) | (pb << 20) | (prim << 24) | (3 << 27) | (bsl << 29);
-    if (hr) { last[0] = st + 1; s.sched[st][0] = word; }
-    if (ha) { last[1 + pa] = st + 1; s.sched[st][1 + pa] = word; }
-    if (hb) { last[1 + pb] = st + 1; s.sched[st][1 + pb] = word; }
+    Blk b;
+    b.row0 = (uint16_t)(nscalar + 3 * c); b.type = 2; b.nrows = 3;
+    b.rslot = (uint8_t)(hr ? rs : BLK_NONE); b.pa = (uint8_t)pa; b.pb = (uint8_t)pb;
+    b.primary = (uint8_t)(hr ? 0 : 1 + pa); b.bslot = (uint8_t)(hb ? s.con_bslot[c] : 0);
+    if (hr) { last[0] = st + 1; s.sched[st][0] = (uint8_t)nb; }
+    if (ha) { last[1 + pa] = st + 1; s.sched[st][1 + pa] = (uint8_t)nb; }
+    if (hb) { last[1 + pb] = st + 1; s.sched[st][1 + pb] = (uint8_t)nb; }
     if (st + 1 > nst) nst = st + 1;
-    s.blk_info[nb++] = word;
+    s.blk[nb++] = b;
   }
   s.nblk = nb;
   s.nsched = nst;
@@ -576,9 +572,9 @@ MRE_PHASE_FN void solve_constraints(const DevModel* M, Sm& s, int l) {
   // ---- a = M^-1 J' f, w = J' f for the warm start (lane = dof in the solver layout)
   float a = 0.f, w = 0.f;
   for (int bi = 0; bi < s.nblk; bi++) {
-    const int info = s.blk_info[bi];
-    const int row0 = blk_row0(info), rs = blk_rslot(info), nr = blk_nrows(info);
-    const int slot = (lp >= 0 && lvalid) ? (lp == blk_pa(info) ? 0 : (lp == blk_pb(info) ? 1 : -1)) : -1;
+    const Blk bk = s.blk[bi];
+    const int row0 = bk.row0, rs = bk.rslot, nr = bk.nrows;
+    const int slot = (lp >= 0 && lvalid) ? (lp == bk.pa ? 0 : (lp == bk.pb ? 1 : -1)) : -1;
     for (int r = 0; r < nr; r++) {
       const float fi = s.frc[row0 + r];
       float j, b;
@@ -618,7 +614,7 @@ MRE_PHASE_FN void solve_constraints(const DevModel* M, Sm& s, int l) {
   // body-frame arrays and region R1, which nothing reads between the controller and the next
   // position stage.  Entry (step, island):
   //   x = offset of the island's first Jacobian row | offset of the block record << 16
-  //   y = row0 | nrows << 7 | on << 9 | contact << 10 | primary << 11 | partner lane << 12 | coupled << 18
+  //   y = row0 | nrows << 8 | on << 10 | contact << 11 | primary << 12 | partner lane << 13 | coupled << 19
   static_assert(offsetof(Sm, xpos) % 8 == 0 &&
                 offsetof(Sm, cdof) - offsetof(Sm, xpos) >= sizeof(uint2) * (TAB_OFF + 1) + sizeof(float) * TAB_ZEROS,
                 "operand table must fit in the body-frame arrays + region R1");
@@ -628,11 +624,11 @@ MRE_PHASE_FN void solve_constraints(const DevModel* M, Sm& s, int l) {
   float* const zeros = reinterpret_cast<float*>(tab + TAB_OFF + 1);
   for (int e = l; e < nsched * 5; e += 64) {
     const int st = e / 5, is = e - 5 * st;
-    const int word = s.sched[st][is];
-    const bool on = word != -1;
-    const int info = on ? word : 0;
-    const int type = blk_type(info), row0 = blk_row0(info), rs = blk_rslot(info), nr = blk_nrows(info);
-    const int pa = blk_pa(info), pb = blk_pb(info), ip = is - 1;
+    const int bi = s.sched[st][is];
+    const bool on = bi != SCHED_NONE;
+    const Blk bk = s.blk[on ? bi : 0];
+    const int type = bk.type, row0 = on ? bk.row0 : 0, rs = bk.rslot, nr = on ? bk.nrows : 0;
+    const int pa = bk.pa, pb = bk.pb, ip = is - 1;
     const bool is3 = on && type == 2;
     int partner = 0, coupled = 0;
     if (is3) {
@@ -641,14 +637,14 @@ MRE_PHASE_FN void solve_constraints(const DevModel* M, Sm& s, int l) {
       else if (pb != 0xF) { partner = 16 + 8 * (ip == pa ? pb : pa); coupled = 1; }
     }
     const float* jrow = zeros;
-    if (on) jrow = (is == 0) ? &s.Jr[rs][0] : (ip == pa ? &s.JpA[row0 - nscalar][0] : &s.JpB[3 * blk_bslot(info)][0]);
+    if (on) jrow = (is == 0) ? &s.Jr[rs][0] : (ip == pa ? &s.JpA[row0 - nscalar][0] : &s.JpB[3 * bk.bslot][0]);
     const int bidx = is3 ? 8 + (row0 - nscalar) / 3 : row0 / 3;
     const unsigned joff = (unsigned)(reinterpret_cast<const char*>(jrow) - sb);
     const unsigned roff = (unsigned)(reinterpret_cast<const char*>(s.blkrec[on ? bidx : 0]) - sb);
     uint2 ent;
     ent.x = joff | (roff << 16);
-    ent.y = (unsigned)row0 | ((unsigned)nr << 7) | ((unsigned)on << 9) | ((unsigned)is3 << 10) |
-            ((unsigned)(on && is == blk_primary(info)) << 11) | ((unsigned)partner << 12) | ((unsigned)coupled << 18);
+    ent.y = (unsigned)row0 | ((unsigned)nr << 8) | ((unsigned)on << 10) | ((unsigned)is3 << 11) |
+            ((unsigned)(on && is == bk.primary) << 12) | ((unsigned)partner << 13) | ((unsigned)coupled << 19);
     tab[e] = ent;
   }
   if (l == 63) {
@@ -674,8 +670,8 @@ MRE_PHASE_FN void solve_constraints(const DevModel* M, Sm& s, int l) {
     for (int st = 0; st < nsched; st++) {
       const uint2 ent = *reinterpret_cast<const uint2*>(sb + tbase + tstep * (unsigned)st);
       const unsigned w1 = ent.y;
-      const bool on = (w1 & 0x200u) != 0u, is3 = (w1 & 0x400u) != 0u;
-      const int row0 = (int)(w1 & 0x7Fu), nr = (int)((w1 >> 7) & 3u);
+      const bool on = (w1 & 0x400u) != 0u, is3 = (w1 & 0x800u) != 0u;
+      const int row0 = (int)(w1 & 0xFFu), nr = (int)((w1 >> 8) & 3u);
       const bool h1 = nr > 1, h2 = nr > 2;
       // operands: three rows through the lane's offset / stride (rows past the block may hold
       // stale non-finite LDS contents: select, never multiply by zero)
@@ -698,12 +694,12 @@ MRE_PHASE_FN void solve_constraints(const DevModel* M, Sm& s, int l) {
       const float f1 = h1 ? f1r : 0.f, f2 = h2 ? f2r : 0.f;
       float p0 = j0 * a, p1 = j1 * a, p2 = j2 * a;
       island_sum3(p0, p1, p2);
-      if (__any((w1 & 0x40000u) != 0u)) {
-        const int src = (int)((w1 >> 10) & 0xFCu);  // partner lane * 4
+      if (__any((w1 & 0x80000u) != 0u)) {
+        const int src = (int)((w1 >> 11) & 0xFCu);  // partner lane * 4
         const float x0 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, p0)));
         const float x1 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, p1)));
         const float x2 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, p2)));
-        if ((w1 & 0x40000u) != 0u) { p0 += x0; p1 += x1; p2 += x2; }
+        if ((w1 & 0x80000u) != 0u) { p0 += x0; p1 += x1; p2 += x2; }
       }
       float d0 = 0.f, d1 = 0.f, d2 = 0.f, change = 0.f;
       if (on) {
@@ -773,7 +769,7 @@ MRE_PHASE_FN void solve_constraints(const DevModel* M, Sm& s, int l) {
           change = 0.5f * (d0 * Ad0 + d1 * Ad1 + d2 * Ad2) + d0 * res0 + d1 * res1 + d2 * res2;
           if (change > 1e-10f) { d0 = d1 = d2 = 0.f; change = 0.f; }
         }
-        if ((w1 & 0x800u) != 0u) impr -= change;
+        if ((w1 & 0x1000u) != 0u) impr -= change;
         if (leader) {
           s.frc[row0] = f0 + d0;
           if (h1) s.frc[row0 + 1] = f1 + d1;

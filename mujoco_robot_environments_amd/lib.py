@@ -26,6 +26,7 @@ EXPORTS = [
     "mre_set_trace", "mre_osc_set_target", "mre_osc_configure", "mre_gripper_set",
     "mre_run_controller", "mre_get_sites", "mre_get_status", "mre_get_solver_stats",
     "mre_profile_enable", "mre_profile_read", "mre_set_env_id_offset", "mre_set_env_order",
+    "mre_set_fallback", "mre_get_fallback_stats",
 ]
 
 
@@ -49,11 +50,22 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return _SO
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-           "-Wno-unused-value", "-o", _SO] + [os.path.join(_CSRC, s) for s in _SOURCES]
+    base = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
     if verbose:
-        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-    subprocess.check_call(cmd)
+        base.insert(1, "-Rpass-analysis=kernel-resource-usage")
+    bdir = os.path.join(_CSRC, "_build")
+    os.makedirs(bdir, exist_ok=True)
+    # the step kernel is instantiated twice (compact / large constraint capacities, mre_dev.h)
+    units = [("kernels", "mre_kernels.hip", []), ("kernels_large", "mre_kernels.hip", ["-DMRE_LARGE_CAPS"]),
+             ("api", "mre_api.cpp", [])]
+    procs = [(name, subprocess.Popen(base + flags + ["-c", os.path.join(_CSRC, src), "-o",
+                                                     os.path.join(bdir, name + ".o")]))
+             for name, src, flags in units]
+    for name, pr in procs:
+        if pr.wait() != 0:
+            raise MreError(f"hipcc failed on translation unit {name}")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", _SO] +
+                          [os.path.join(bdir, name + ".o") for name, _, _ in units])
     return _SO
 
 
@@ -97,6 +109,8 @@ def lib() -> C.CDLL:
     L.mre_set_env_order.argtypes = [vp, fp]
     L.mre_profile_enable.argtypes = [vp, ci]
     L.mre_profile_read.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(ci)]
+    L.mre_set_fallback.argtypes = [vp, ci]
+    L.mre_get_fallback_stats.argtypes = [vp, C.POINTER(C.c_longlong)]
     for name in EXPORTS:
         if name not in ("mre_last_error", "mre_stream"):
             getattr(L, name).restype = ci

@@ -230,6 +230,15 @@ class BatchedPhysics:
         return st
 
     # ---------------------------------------------------------- measurement
+    def set_fallback(self, enabled: bool = True) -> None:
+        """Capacity fallback (include/mre.h): on by default; off pins every env to the compact kernel."""
+        check(_lib.lib().mre_set_fallback(self._h, int(enabled)), "mre_set_fallback")
+
+    def fallback_stats(self) -> dict:
+        out = (C.c_longlong * 4)()
+        check(_lib.lib().mre_get_fallback_stats(self._h, out), "mre_get_fallback_stats")
+        return {"large_envs": int(out[0]), "reruns": int(out[1]), "promotions": int(out[2]), "demotions": int(out[3])}
+
     def profile_enable(self, on: bool = True) -> None:
         check(_lib.lib().mre_profile_enable(self._h, int(on)), "mre_profile_enable")
 

@@ -87,6 +87,7 @@ def test_capacity_overflow_flag_matches_oracle_emulation(compiled_model, oracle_
     e.forward()
     assert e.overflow
     phys = _phys(2, A)
+    phys.set_fallback(False)  # pin the envs to the compact kernel: this test is about ITS capacities
     qp = phys.qpos().copy()
     qp[:, :43] = q[:43]
     phys.set_state(qp, np.zeros((2, 39), np.float32))
@@ -100,6 +101,60 @@ def test_capacity_overflow_flag_matches_oracle_emulation(compiled_model, oracle_
     if not e.overflow:
         assert stats[0, 1] == e.nefc
     phys.close()
+
+
+def test_capacity_fallback_reruns_overflowing_envs_on_the_large_kernel(compiled_model, oracle_model):
+    """A stack of three cubes, the middle one yawed by 45 degrees, has 2 x 8 cube-cube contacts: more
+    than the compact kernel keeps (8; it lets the top cube sink), within the large one's 16.  With the fallback (default) the env is re-run from its saved
+    state on the large kernel: no overflow status, the trajectory follows the oracle with the large
+    capacities, and an env that never overflowed is bit-identical to a compact-only run."""
+    from oracle import oracle as O
+    A, _ = compiled_model
+    rows = np.zeros((2, 3, 7))
+    c8, s8 = np.cos(np.pi / 8), np.sin(np.pi / 8)
+    rows[0] = [[0.45, 0, 0.4154, 1, 0, 0, 0], [0.45, 0, 0.4463, c8, 0, 0, s8], [0.45, 0, 0.4772, 1, 0, 0, 0]]
+    for p in range(3):
+        rows[1, p] = [0.40 + 0.05 * p, -0.3 + 0.2 * p, 0.4155, 1, 0, 0, 0]      # far apart
+    nsteps = 40
+    envs = []
+    for i in range(2):
+        e = O.Env(oracle_model, 3)
+        q = e.arr("qpos")
+        q[:7] = HOME
+        q[15:36] = rows[i].reshape(-1)
+        e.set_caps(32, 112, 50, 8)
+        e.forward()
+        envs.append(e)
+    assert envs[0].overflow and not envs[1].overflow
+    for e in envs:
+        e.set_caps(48, 160, 100, 16)
+        e.forward()
+        for _ in range(nsteps):
+            e.step(1)
+            assert not e.overflow
+    results = {}
+    for fb in (True, False):
+        phys = _phys(2, A)
+        phys.set_fallback(fb)
+        phys.set_props(np.array([3, 3], np.int32), np.full((2, 4, 3), 0.0155, np.float32))
+        qp = phys.qpos().copy()
+        for i in range(2):
+            qp[i, :7] = HOME
+            qp[i, 15:36] = rows[i].reshape(-1)
+        phys.set_state(qp, np.zeros((2, 39), np.float32))
+        phys.step(nsteps)
+        results[fb] = (phys.qpos().copy(), phys.status().copy(), phys.fallback_stats())
+        phys.close()
+    q_fb, st_fb, stats_fb = results[True]
+    q_nofb, st_nofb, stats_nofb = results[False]
+    assert (st_fb & 4).tolist() == [0, 0]
+    assert (st_nofb & 4).tolist() == [4, 0]
+    assert stats_fb["promotions"] == 1 and stats_fb["reruns"] == 1 and stats_nofb["promotions"] == 0
+    assert np.array_equal(q_fb[1], q_nofb[1])  # untouched env: same kernel, same bits
+    err_fb = [np.abs(q_fb[i, :36] - envs[i].arr("qpos")[:36]).max() for i in range(2)]
+    assert max(err_fb) < 1e-4, err_fb
+    # the compact-only run dropped contacts of env 0 and drifts away from the oracle
+    assert np.abs(q_nofb[0, :36] - envs[0].arr("qpos")[:36]).max() > err_fb[0]
 
 
 def test_nonfinite_state_is_flagged(compiled_model):

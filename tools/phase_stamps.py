@@ -13,9 +13,14 @@ NAMES = ["position+crb+factor", "velocity", "collide", "assemble", "control", "s
 if sys.argv[1] == "build":
     os.makedirs(DIAG, exist_ok=True)
     for k in (0, 1):
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-                               "-Wno-unused-value", f"-DMRE_PHASE_STAMPS={k}", "-o", os.path.join(DIAG, f"libmre_stamps{k}.so"),
-                               os.path.join(CSRC, "mre_kernels.hip"), os.path.join(CSRC, "mre_api.cpp")])
+        base = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
+        objs = []
+        for name, src, flags in (("k", "mre_kernels.hip", [f"-DMRE_PHASE_STAMPS={k}"]),
+                                 ("kl", "mre_kernels.hip", ["-DMRE_LARGE_CAPS"]), ("api", "mre_api.cpp", [])):
+            objs.append(os.path.join(DIAG, f"{name}{k}.o"))
+            subprocess.check_call(base + flags + ["-c", os.path.join(CSRC, src), "-o", objs[-1]])
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o",
+                               os.path.join(DIAG, f"libmre_stamps{k}.so")] + objs)
 elif sys.argv[1] == "run":
     if "MRE_LIB" not in os.environ:
         tot = []
