@@ -117,9 +117,17 @@ def cpu_baseline(seed, budget_s=12.0, nenv=64):
             break
     dt = time.perf_counter() - t0
     finite = sum(bool(np.isfinite(e.arr("qpos")[:43]).all()) for e in envs)
+    # the same loop on ONE thread (SURVEY section 8d asks for both), a few seconds on the first 4 envs
+    t1, ticks1 = time.perf_counter(), 0
+    while time.perf_counter() - t1 < 4.0:
+        acts = rng.random_actions(seed, ids[:4], [ticks + ticks1])[0]
+        O.batch_step(m, envs[:4], acts, CONTROL_STEPS, 1)
+        ticks1 += 1
+    dt1 = time.perf_counter() - t1
     return {"finite_envs": finite, "value": nenv * ticks * CONTROL_STEPS / dt, "unit": "env-steps/s", "cores": threads,
             "kind": "port", "sample": f"{nenv} envs x {ticks} ticks x {CONTROL_STEPS} steps, fp64 oracle "
-            f"(PGS, same scene/actions), OpenMP {threads} threads, {dt:.1f} s"}
+            f"(PGS, same scene/actions), OpenMP {threads} threads, {dt:.1f} s",
+            "single_thread_value": 4 * ticks1 * CONTROL_STEPS / dt1}
 
 
 def main():

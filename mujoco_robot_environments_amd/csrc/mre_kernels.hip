@@ -101,6 +101,9 @@ MRE_DEV bool body_is_active(const DevModel* M, const Sm& s, int b) {
 }
 
 // ------------------------------------------------------------ mj_kinematics
+// writeback: store the normalised free-joint quaternions in qpos (mj_kinematics does); the
+// query-only pass at the end of a launch must leave the state bits alone
+template <bool WRITEBACK>
 MRE_DEV void kinematics(const DevModel* M, Sm& s, int l, BodyRegs& br) {
   if (l == 0) {
     v3zero(s.xpos[0]);
@@ -117,7 +120,7 @@ MRE_DEV void kinematics(const DevModel* M, Sm& s, int l, BodyRegs& br) {
         v3copy(xp, &s.qpos[qa]);
         for (int k = 0; k < 4; k++) xq[k] = s.qpos[qa + 3 + k];
         qnormalize(xq);
-        for (int k = 0; k < 4; k++) s.qpos[qa + 3 + k] = xq[k];
+        if (WRITEBACK) for (int k = 0; k < 4; k++) s.qpos[qa + 3 + k] = xq[k];
         v3copy(br.anchor, xp);
         br.axis[0] = 0.f; br.axis[1] = 0.f; br.axis[2] = 1.f;
       } else {
@@ -210,14 +213,14 @@ MRE_DEV void com_pos(const DevModel* M, Sm& s, int l, const BodyRegs& br) {
 // (anchor, axis, inertial frame) never leave the register file
 MRE_PHASE_FN void position_stage(const DevModel* M, Sm& s, int l) {
   BodyRegs br;
-  kinematics(M, s, l, br);
+  kinematics<true>(M, s, l, br);
   com_pos(M, s, l, br);
   __syncthreads();
 }
 // kinematics only (site queries at the end of a launch)
 MRE_PHASE_FN void kinematics_only(const DevModel* M, Sm& s, int l) {
   BodyRegs br;
-  kinematics(M, s, l, br);
+  kinematics<false>(M, s, l, br);
   __syncthreads();
 }
 
