@@ -299,6 +299,43 @@ static int build_model(const void* blob, size_t nbytes, DevModel& m) {
     for (int j = i; j >= 0; j = m.dof_parent[j], adr++) { m.M_i[adr] = i; m.M_j[adr] = j; }
     if (adr != m.dof_Madr[i + 1]) return fail(MRE_ERR_MODEL, "dof_Madr inconsistent");
   }
+  for (int i = 0; i < NRV; i++)
+    if (m.dof_parent[i] != ROBOT_DOF_PARENT[i] || m.dof_Madr[i] != robot_dof_madr(i))
+      return fail(MRE_ERR_MODEL, "robot dof tree differs from the one the kernels are unrolled for (mre_dev.h)");
+  // tables of the level-parallel robot solve
+  {
+    int depth[NRV];
+    m.sol_maxdepth = 0;
+    for (int i = 0; i < NRV; i++) {
+      depth[i] = m.dof_parent[i] < 0 ? 0 : depth[m.dof_parent[i]] + 1;  // parents precede children
+      m.sol_depth[i] = depth[i];
+      if (depth[i] > m.sol_maxdepth) m.sol_maxdepth = depth[i];
+    }
+    m.sol_depth[NRV] = -1;
+    for (int i = 0; i <= NRV; i++) {
+      uint16_t desc[14], anc[8];
+      for (auto& v : desc) v = 0xFFFF;
+      for (auto& v : anc) v = 0xFFFF;
+      if (i < NRV) {
+        int nd = 0, na = 0;
+        for (int c = NRV - 1; c > i; c--) {  // descendants of i, descending
+          bool is_desc = false;
+          for (int j = m.dof_parent[c]; j >= 0; j = m.dof_parent[j]) if (j == i) is_desc = true;
+          if (!is_desc) continue;
+          if (nd >= 14) return fail(MRE_ERR_MODEL, "solve table: too many descendants");
+          desc[nd++] = (uint16_t)(c | ((m.dof_Madr[c] + depth[c] - depth[i]) << 8));
+        }
+        for (int a = m.dof_Madr[i] + 1; a < m.dof_Madr[i + 1]; a++) {
+          if (na >= 8) return fail(MRE_ERR_MODEL, "solve table: too many ancestors");
+          int j = i;
+          for (int k = 0; k < a - m.dof_Madr[i]; k++) j = m.dof_parent[j];
+          anc[na++] = (uint16_t)(j | (a << 8));
+        }
+      }
+      for (int k = 0; k < 7; k++) m.sol_desc[i][k] = desc[2 * k] | ((uint32_t)desc[2 * k + 1] << 16);
+      for (int k = 0; k < 4; k++) m.sol_anc[i][k] = anc[2 * k] | ((uint32_t)anc[2 * k + 1] << 16);
+    }
+  }
   for (int k = 0; k < NRV; k++) {
     int anc[MAXCHAIN + 1], n = 0;
     for (int j = m.dof_parent[k]; j >= 0; j = m.dof_parent[j]) anc[++n] = j;  // 1-based positions

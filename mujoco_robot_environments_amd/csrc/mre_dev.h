@@ -24,6 +24,18 @@ constexpr int NSITE = 2;
 constexpr int NEQ = 3;
 constexpr int MAXCHAIN = 9;   // longest dof chain root->leaf (7 arm + 2 finger)
 constexpr int MAXFAC = 45;    // (i,j) ancestor pairs touched by one elimination step
+// dof tree of the robot block (arm chain 0..6, four two-dof finger branches off dof 6); the
+// register-resident L'DL solve is unrolled over it at compile time, mre_create checks the blob
+constexpr int ROBOT_DOF_PARENT[NRV] = {-1, 0, 1, 2, 3, 4, 5, 6, 7, 6, 9, 6, 11, 6, 13};
+constexpr int robot_dof_depth(int i) { return ROBOT_DOF_PARENT[i] < 0 ? 0 : 1 + robot_dof_depth(ROBOT_DOF_PARENT[i]); }
+constexpr int robot_dof_madr(int i) { return i == 0 ? 0 : robot_dof_madr(i - 1) + robot_dof_depth(i - 1) + 1; }
+constexpr int robot_dof_anc(int i, int k) {  // k-th ancestor (0 = parent), -1 past the root
+  int j = ROBOT_DOF_PARENT[i];
+  for (int t = 0; t < k && j >= 0; t++) j = ROBOT_DOF_PARENT[j];
+  return j;
+}
+static_assert(robot_dof_madr(NRV) == NMR, "robot mass-matrix size");
+
 // Per-env constraint capacities (LDS is sized for them).  The library carries the step kernel in
 // two capacity sets: the compact one keeps a workgroup at 20 KB of LDS (8 workgroups per CU) and
 // covers cubes resting / sliding on the table; the large one (5 per CU) covers grasps and piles.
@@ -64,6 +76,11 @@ struct DevModel {
   int M_i[NMR], M_j[NMR];        // entry e = M(i, j), j ancestor-or-self of i
   int fac_n[NRV];                // elimination step k: number of (i,j) updates
   uint8_t fac_dst[NRV][MAXFAC], fac_a[NRV][MAXFAC], fac_b[NRV][MAXFAC];
+  // level-parallel L'DL solve (solve_robot_par): per dof its depth in the dof tree, its
+  // descendants in descending order and its ancestors nearest first, each entry packed as
+  // dof | (address of the L entry in qLD) << 8, two entries per word (0xFFFF = none)
+  int sol_depth[NRV + 1], sol_maxdepth;
+  uint32_t sol_desc[NRV + 1][7], sol_anc[NRV + 1][4];
   float robot_mass;              // sum of robot body masses (subtree mass of link1)
   float M0_diag_robot_sum;       // sum_i M0(i,i) over robot dofs (meaninertia)
   // ---- geoms / pairs / sites

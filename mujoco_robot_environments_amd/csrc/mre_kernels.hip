@@ -288,19 +288,115 @@ MRE_DEV void factor_robot(const DevModel* M, float* LD, float* dinv, int l) {
   }
 }
 
-// x <- M^-1 x on the robot block (serial, one lane; x lives in LDS)
+// x <- M^-1 x on the robot block (serial, one lane; x lives in LDS).  The ancestor of entry a
+// comes from the M_j table by loop index (independent, prefetchable loads) rather than by walking
+// dof_parent (a chain of dependent loads); same operations in the same order as mj_solveLD.
 MRE_DEV void solve_robot_serial(const DevModel* M, const float* LD, const float* dinv, float* x) {
   for (int i = NRV - 1; i >= 0; --i) {
     const float xi = x[i];
-    int a = M->dof_Madr[i] + 1;
-    for (int j = M->dof_parent[i]; j >= 0; j = M->dof_parent[j]) x[j] -= LD[a++] * xi;
+    const int a1 = M->dof_Madr[i + 1];
+    for (int a = M->dof_Madr[i] + 1; a < a1; ++a) x[M->M_j[a]] -= LD[a] * xi;
   }
   for (int i = 0; i < NRV; ++i) x[i] *= dinv[i];
   for (int i = 0; i < NRV; ++i) {
-    int a = M->dof_Madr[i] + 1;
+    const int a1 = M->dof_Madr[i + 1];
     float xi = x[i];
-    for (int j = M->dof_parent[i]; j >= 0; j = M->dof_parent[j]) xi -= LD[a++] * x[j];
+    for (int a = M->dof_Madr[i] + 1; a < a1; ++a) xi -= LD[a] * x[M->M_j[a]];
     x[i] = xi;
+  }
+}
+
+// x <- M^-1 x with x in registers: mj_solveLD unrolled over the compile-time dof tree
+// (ROBOT_DOF_PARENT), every lane solving its own right-hand side; the factor entries are LDS
+// reads at constant offsets.  Same operations in the same order as the serial routine.
+typedef const __attribute__((address_space(3))) float* lds_cfloat_p;
+template <int I, int K>
+MRE_DEV void solve_regs_back(float (&x)[NRV], lds_cfloat_p LD, float xi) {
+  constexpr int j = robot_dof_anc(I, K);
+  if constexpr (j >= 0) {
+    constexpr int adr = robot_dof_madr(I) + 1 + K;
+    x[j] -= LD[adr] * xi;
+    solve_regs_back<I, K + 1>(x, LD, xi);
+  }
+}
+template <int I>
+MRE_DEV void solve_regs_back_rows(float (&x)[NRV], lds_cfloat_p LD) {
+  solve_regs_back<I, 0>(x, LD, x[I]);
+  __builtin_amdgcn_sched_barrier(0);  // keep the factor reads of later rows out of the live set
+  if constexpr (I > 0) solve_regs_back_rows<I - 1>(x, LD);
+}
+template <int I, int K>
+MRE_DEV void solve_regs_fwd(float (&x)[NRV], lds_cfloat_p LD, float& xi) {
+  constexpr int j = robot_dof_anc(I, K);
+  if constexpr (j >= 0) {
+    constexpr int adr = robot_dof_madr(I) + 1 + K;
+    xi -= LD[adr] * x[j];
+    solve_regs_fwd<I, K + 1>(x, LD, xi);
+  }
+}
+template <int I>
+MRE_DEV void solve_regs_fwd_rows(float (&x)[NRV], lds_cfloat_p LD) {
+  float xi = x[I];
+  solve_regs_fwd<I, 0>(x, LD, xi);
+  x[I] = xi;
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (I + 1 < NRV) solve_regs_fwd_rows<I + 1>(x, LD);
+}
+MRE_DEV void solve_robot_regs(const float* LD_, const float* dinv_, float (&x)[NRV]) {
+  // explicit LDS pointers, opaque to loop strength reduction: every factor entry is then one
+  // ds_read at base + immediate offset (otherwise each address is hoisted into a register of its own)
+  lds_cfloat_p LD = (lds_cfloat_p)LD_;
+  lds_cfloat_p dinv = (lds_cfloat_p)dinv_;
+  asm volatile("" : "+v"(LD), "+v"(dinv));
+  solve_regs_back_rows<NRV - 1>(x, LD);
+#pragma unroll
+  for (int i = 0; i < NRV; i++) x[i] *= dinv[i];
+  solve_regs_fwd_rows<0>(x, LD);
+}
+
+// x <- M^-1 x for up to four right-hand sides at once, level-parallel: lane = (group g = l / 16,
+// dof i = l % 16), group g works on xb + g * xstride (LDS).  Backward pass from the deepest dofs
+// up (a dof folds in all its descendants, which are final), scaling, forward pass from the roots
+// down; the terms of every sum are applied in mj_solveLD's order, so the result is bit-identical
+// to the serial routine.  The dof tree is at most sol_maxdepth + 1 levels deep (9 for this robot).
+MRE_PHASE_FN void solve_robot_par(const DevModel* M, const float* LD, const float* dinv, float* xb, int xstride,
+                                  int ngroups, int l) {
+  const int g = l >> 4, i = l & 15;
+  const bool on = i < NRV && g < ngroups;
+  float* x = xb + g * xstride;
+  const int ii = on ? i : NRV;  // row NRV of the tables is empty
+  const int depth = M->sol_depth[ii];
+  uint32_t dw[7], aw[4];
+#pragma unroll
+  for (int k = 0; k < 7; k++) dw[k] = M->sol_desc[ii][k];
+#pragma unroll
+  for (int k = 0; k < 4; k++) aw[k] = M->sol_anc[ii][k];
+  const int maxd = M->sol_maxdepth;
+  for (int d = maxd; d >= 0; --d) {
+    if (depth == d) {
+      float acc = x[i];
+#pragma unroll
+      for (int k = 0; k < 14; k++) {
+        const uint32_t e = (dw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+        if (e != 0xFFFFu) acc -= LD[e >> 8] * x[e & 0xFFu];
+      }
+      x[i] = acc;
+    }
+    __syncthreads();
+  }
+  if (on) x[i] *= dinv[i];
+  __syncthreads();
+  for (int d = 1; d <= maxd; ++d) {
+    if (depth == d) {
+      float acc = x[i];
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const uint32_t e = (aw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+        if (e != 0xFFFFu) acc -= LD[e >> 8] * x[e & 0xFFu];
+      }
+      x[i] = acc;
+    }
+    __syncthreads();
   }
 }
 
@@ -424,7 +520,7 @@ MRE_DEV bool smooth_forces(const DevModel* M, Sm& s, int l) {
     s.qacc_smooth[l] = f;
   }
   __syncthreads();
-  if (l == 0) solve_robot_serial(M, s.qLD, s.qLDinv, s.qacc_smooth);
+  solve_robot_par(M, s.qLD, s.qLDinv, s.qacc_smooth, 0, 1, l);
   if (l >= NRV && l < NV) {
     const int p = (l - NRV) / 6, k = (l - NRV) % 6;
     const float md = (k < 3) ? s.prop_mass[p] : s.prop_inertia[p][k - 3];
@@ -454,8 +550,7 @@ MRE_PHASE_FN void integrate(const DevModel* M, Sm& s, int l, bool grip_clamped, 
   if (l < NRV) s.scratch[l] = s.qfrc_smooth[l] + s.qfrc_con[l];
   __syncthreads();
   factor_robot(M, s.qLD, s.qLDinv, l);
-  if (l == 0) solve_robot_serial(M, s.qLD, s.qLDinv, s.scratch);
-  __syncthreads();
+  solve_robot_par(M, s.qLD, s.qLDinv, s.scratch, 0, 1, l);
   const bool freeze = (flags & F_FREEZE_ROBOT) != 0;
   if (l < NV) {
     const int b = M->dof_body[l];

@@ -201,6 +201,20 @@ MRE_DEV float row_dot(const Sm& s, int i, const float* vec) {
   return acc;
 }
 
+// Br = M^-1 Jr' (lane = robot slot; register-resident sparse solve unrolled over the dof tree).
+// A function of its own: the unrolled solve wants ~100 registers for the factor entries.
+MRE_PHASE_FN void solve_robot_rows(Sm& s, int l) {
+  for (int rs = l; rs < s.nrrow; rs += 64) {
+    float x[NRV];
+#pragma unroll
+    for (int k = 0; k < NRV; k++) x[k] = s.Jr[rs][k];
+    solve_robot_regs(s.qLD, s.qLDinv, x);
+#pragma unroll
+    for (int k = 0; k < NRV; k++) s.Br[rs][k] = x[k];
+  }
+  __syncthreads();
+}
+
 // ------------------------- mj_makeConstraint + mj_makeImpedance + reference + project
 MRE_PHASE_FN void assemble_constraints(const DevModel* M, Sm& s, int l) {
   // ---- joint limits: lane = robot body; at most one side can be violated
@@ -351,12 +365,8 @@ MRE_PHASE_FN void assemble_constraints(const DevModel* M, Sm& s, int l) {
     if (i >= 7 + nl && (i - 7 - nl) % 3 == 0) s.blkrec[8 + (i - 7 - nl) / 3][15] = M->pair_friction[s.con_pair[(i - 7 - nl) / 3]][0];
   }
   __syncthreads();
-  // ---- Br = M^-1 Jr' (lane = robot slot, serial sparse solve in place)
-  for (int rs = l; rs < s.nrrow; rs += 64) {
-    for (int j = 0; j < NRV; j++) s.Br[rs][j] = s.Jr[rs][j];
-    solve_robot_serial(M, s.qLD, s.qLDinv, s.Br[rs]);
-  }
-  __syncthreads();
+  // ---- Br = M^-1 Jr'
+  solve_robot_rows(s, l);
   // ---- diagonal blocks of A = J M^-1 J' + R.  Contacts: 3x3 block of the contact's rows.
   // Scalar rows (equality / limit, robot-only) are grouped in consecutive triples whose
   // 3x3 block lets one solver step apply the three sequential scalar updates exactly.
