@@ -32,6 +32,8 @@ extern "C" void mre_launch_reset(const DevModel* M, int N, float* qpos, float* q
                                  float* ctrl, uint32_t* status, const uint8_t* mask,
                                  hipStream_t stream);
 
+constexpr int MAXBLK_ANY = 64;  // upper bound of the schedule length in either capacity set
+
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) {
   g_err = msg;
@@ -65,7 +67,10 @@ struct mre_env {
   int trace_nenv = 0, trace_max = 0, trace_pos = 0;
   long long env_id_offset = 0;
   int* order = nullptr;       // dispatch permutation (heavy-first), device
-  bool use_order = false;
+  bool use_order = false;     // caller-supplied permutation (mre_set_env_order)
+  int* auto_order = nullptr;  // permutation maintained by launch_step: longest Gauss-Seidel schedule first
+  int* h_auto_order = nullptr;  // pinned host staging
+  bool have_auto_order = false;
   bool profiling = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
   size_t events_used = 0;
@@ -140,9 +145,37 @@ static int launch_step(mre_env* e, const StepArgs& a, bool settle = false) {
       if (li[0] < 0) continue;
       if (!e->h_large[i]) {
         if (li[0] > 0) { e->h_rerun[i] = 1; e->h_large[i] = 1; nrerun++; changed = true; e->n_large++; e->n_promotions++; }
-      } else if (li[0] == 0 && 4 * li[1] <= 3 * NCON_MAX && 4 * li[2] <= 3 * NEFC_MAX &&
+      } else if (li[0] == 0 && 4 * (li[1] & 0xFFFF) <= 3 * NCON_MAX && 4 * li[2] <= 3 * NEFC_MAX &&
                  4 * (li[3] & 0xFFFF) <= 3 * NRROW_MAX && 4 * (li[3] >> 16) <= 3 * NPP_MAX) {
         e->h_large[i] = 0; changed = true; e->n_large--; e->n_demotions++;
+      }
+    }
+    // Dispatch order for the next launch: a launch ends with its slowest wavefront, and an env's
+    // time is set by the length of its Gauss-Seidel schedule (robot contacts are sequential), so the
+    // envs with the longest schedules go first (counting sort, stable; results do not depend on it).
+    if (!e->use_order) {
+      int count[MAXBLK_ANY + 2] = {0};
+      bool any_long = false;
+      for (size_t i = 0; i < N; i++) {
+        const int li1 = e->h_launch_info[4 * i + 1];
+        int c = e->h_launch_info[4 * i] < 0 ? 0 : (li1 >> 16);
+        if (c > MAXBLK_ANY) c = MAXBLK_ANY;
+        if (c > 8) any_long = true;
+        count[MAXBLK_ANY - c + 1]++;
+      }
+      if (any_long) {
+        for (int k = 1; k <= MAXBLK_ANY + 1; k++) count[k] += count[k - 1];
+        for (size_t i = 0; i < N; i++) {
+          const int li1 = e->h_launch_info[4 * i + 1];
+          int c = e->h_launch_info[4 * i] < 0 ? 0 : (li1 >> 16);
+          if (c > MAXBLK_ANY) c = MAXBLK_ANY;
+          e->h_auto_order[count[MAXBLK_ANY - c]++] = (int)i;
+        }
+        // (the pinned staging buffer is rewritten only after the next launch's read-back sync)
+        HIPCHK(hipMemcpyAsync(e->auto_order, e->h_auto_order, N * 4, hipMemcpyHostToDevice, e->stream));
+        e->have_auto_order = true;
+      } else {
+        e->have_auto_order = false;
       }
     }
     if (nrerun > 0) {
@@ -387,7 +420,8 @@ extern "C" int mre_create(const void* blob, size_t nbytes, int num_envs, int dev
   HIPCHK(hipMalloc(&e->converged, N)); HIPCHK(hipMalloc(&e->mask, N));
   HIPCHK(hipMalloc(&e->sites, N * 16 * 4));
   HIPCHK(hipMalloc(&e->status, N * 4)); HIPCHK(hipMalloc(&e->stats, N * 4 * 4));
-  HIPCHK(hipMalloc(&e->order, N * 4));
+  HIPCHK(hipMalloc(&e->order, N * 4)); HIPCHK(hipMalloc(&e->auto_order, N * 4));
+  HIPCHK(hipHostMalloc((void**)&e->h_auto_order, N * 4, hipHostMallocDefault));
   HIPCHK(hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking));
   HIPCHK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
@@ -433,9 +467,10 @@ extern "C" int mre_destroy(mre_env* e) {
   void* ptrs[] = {e->dM, e->qpos, e->qvel, e->qacc_ws, e->ctrl, e->nprops, e->prop_size, e->osc_target,
                   e->grip_closed, e->converged, e->mask, e->sites, e->status, e->stats, e->d_osc, e->order,
                   e->d_large, e->mask_c, e->mask_l, e->mask_r, e->sv_qpos, e->sv_qvel, e->sv_qacc_ws, e->sv_ctrl,
-                  e->sv_status, e->launch_info};
+                  e->sv_status, e->launch_info, e->auto_order};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (e->h_launch_info) (void)hipHostFree(e->h_launch_info);
+  if (e->h_auto_order) (void)hipHostFree(e->h_auto_order);
   if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
   if (e->ev_join) (void)hipEventDestroy(e->ev_join);
   if (e->stream2) (void)hipStreamDestroy(e->stream2);
@@ -542,7 +577,7 @@ static void fill_args(mre_env* e, StepArgs& a) {
   a.control_steps = 1; a.mode = CTRL_HELD;
   a.osc = e->d_osc; a.osc_target = e->osc_target; a.grip_closed = e->grip_closed;
   a.sites = e->sites; a.status = e->status; a.stats = e->stats;
-  a.env_order = e->use_order ? e->order : nullptr;
+  a.env_order = e->use_order ? e->order : (e->have_auto_order ? e->auto_order : nullptr);
   a.trace = e->trace; a.trace_nenv = e->trace_nenv; a.trace_max = e->trace_max; a.trace_base = e->trace_pos;
 }
 

@@ -142,8 +142,9 @@ struct StepArgs {
   int trace_nenv, trace_max, trace_base;
   const uint8_t* env_mask;   // [N] or null: envs with 0 are skipped by this launch
   const int* env_order;      // [N] or null: workgroup b steps env env_order[b] (heavy-first dispatch)
-  int* launch_info;          // [N][4] or null: {overflowed in this launch, max ncon, max nefc,
-                             //  max robot rows | max cube-cube contacts << 16} over the launch's steps
+  int* launch_info;          // [N][4] or null: {overflowed in this launch, max ncon | max schedule
+                             //  length << 16, max nefc, max robot rows | max cube-cube contacts << 16}
+                             //  over the launch's steps
 };
 
 }  // namespace mre

@@ -635,7 +635,7 @@ MRE_DEV void step_body(const StepArgs& a, Sm& s) {
 #endif
   bool arm_converged = false;
   float grip_cmd = 0.f;
-  int hw_ncon = 0, hw_nefc = 0, hw_nrrow = 0, hw_npp = 0;  // high-water marks of this launch
+  int hw_ncon = 0, hw_nefc = 0, hw_nrrow = 0, hw_npp = 0, hw_nsched = 0;  // high-water marks of this launch
   if (a.mode == CTRL_OSC) {
     if (l < 16) s.osc_tgt[l] = a.osc_target[(size_t)env * 16 + l];
     // MinMax.compute_control_output: max_val 255 (closed) / min_val 0 (open), min_max.yaml:3-4
@@ -666,7 +666,7 @@ MRE_DEV void step_body(const StepArgs& a, Sm& s) {
       MRE_STAMP(2);
       assemble_constraints(M, s, l);
       MRE_STAMP(3);
-      hw_ncon = max(hw_ncon, s.ncon); hw_nefc = max(hw_nefc, s.nefc);
+      hw_ncon = max(hw_ncon, s.ncon); hw_nefc = max(hw_nefc, s.nefc); hw_nsched = max(hw_nsched, s.nsched);
       hw_nrrow = max(hw_nrrow, s.nrrow); hw_npp = max(hw_npp, s.npp);
     }
 
@@ -731,7 +731,7 @@ MRE_DEV void step_body(const StepArgs& a, Sm& s) {
   if (l < NU) a.ctrl[(size_t)env * NU + l] = s.ctrl[l];
   if (l == 0 && a.launch_info != nullptr) {
     int* li = a.launch_info + (size_t)env * 4;
-    li[0] = s.overflow; li[1] = hw_ncon; li[2] = hw_nefc; li[3] = hw_nrrow | (hw_npp << 16);
+    li[0] = s.overflow; li[1] = hw_ncon | (hw_nsched << 16); li[2] = hw_nefc; li[3] = hw_nrrow | (hw_npp << 16);
   }
   if (l == 0 && a.status != nullptr) {
     unsigned st = 0;

@@ -414,6 +414,7 @@ MRE_DEV bool qcqp2(float* res, const float* A, const float* b, float d0, float d
   const float b1 = b[0] * d0, b2 = b[1] * d1;
   const float A11 = A[0] * d0 * d0, A22 = A[3] * d1 * d1, A12 = A[1] * d0 * d1;
   float la = 0.f, v1 = 0.f, v2 = 0.f;
+  const float r2 = r * r;
   for (int iter = 0; iter < 20; iter++) {
     const float det = (A11 + la) * (A22 + la) - A12 * A12;
     if (det < 1e-10f) { res[0] = res[1] = 0.f; return false; }
@@ -422,7 +423,10 @@ MRE_DEV bool qcqp2(float* res, const float* A, const float* b, float d0, float d
     v1 = -P11 * b1 - P12 * b2;
     v2 = -P12 * b1 - P22 * b2;
     const float val = v1 * v1 + v2 * v2 - r * r;
-    if (val < 1e-10f) break;
+    // mju_QCQP2 stops at val < 1e-10; in fp32 |v|^2 - r^2 cannot be resolved below ~1e-7 r^2, so a
+    // sliding contact would spin through all 20 Newton steps on rounding noise: stop at fp32
+    // resolution instead (the caller rescales v onto the cone exactly afterwards)
+    if (val < fmaxf(1e-10f, 1e-6f * r2)) break;
     const float deriv = -2.0f * (P11 * v1 * v1 + 2.0f * P12 * v1 * v2 + P22 * v2 * v2);
     const float delta = -val * fast_rcp(deriv);
     if (delta < 1e-10f) break;
