@@ -74,6 +74,10 @@ def lib() -> C.CDLL:
     global _LIB
     if _LIB is not None:
         return _LIB
+    # torch first: its wheel bundles a HIP runtime of the same soname, and a process must hold ONE
+    # runtime (libmre.so loaded first would bind /opt/rocm's copy and see no device once torch has
+    # initialised its own)
+    import torch  # noqa: F401
     so = os.environ.get("MRE_LIB", _SO)  # diagnostic builds (tools/phase_stamps.py) only
     if not os.path.exists(so):
         raise MreError(f"{so} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
