@@ -394,18 +394,8 @@ static int build_model(const void* blob, size_t nbytes, DevModel& m) {
 // ------------------------------------------------------------------- lifecycle
 extern "C" const char* mre_last_error(void) { return g_err.c_str(); }
 
-extern "C" int mre_create(const void* blob, size_t nbytes, int num_envs, int device_id, mre_env** out) {
-  if (!blob || !out || num_envs <= 0) return fail(MRE_ERR_ARG, "mre_create: bad argument");
-  *out = nullptr;
-  mre_env* e = new mre_env();
-  int rc = build_model(blob, nbytes, e->hM);
-  if (rc != MRE_OK) { delete e; return rc; }
-  if (const char* it = getenv("MRE_DEBUG_ITERS")) e->hM.iterations = atoi(it);  // profiling knob only
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
-    delete e;
-    return fail(MRE_ERR_NOGPU, "mre_create: no HIP device visible (the HIP path has no CPU fallback)");
-  }
+// allocation part of mre_create: on any failure the caller releases what exists via mre_destroy
+static int create_buffers(mre_env* e, int num_envs, int device_id) {
   e->N = num_envs;
   e->device = device_id;
   HIPCHK(hipSetDevice(device_id));
@@ -453,10 +443,36 @@ extern "C" int mre_create(const void* blob, size_t nbytes, int num_envs, int dev
                      5e-3f, 68e-3f, 0};
   HIPCHK(hipMalloc(&e->d_osc, sizeof(OscConfig)));
   HIPCHK(hipMemcpy(e->d_osc, &e->osc, sizeof(OscConfig), hipMemcpyHostToDevice));
-  *out = e;
-  rc = mre_reset(e, nullptr);
+  int rc = mre_reset(e, nullptr);
   if (rc != MRE_OK) return rc;
   return mre_sync(e);
+}
+
+extern "C" int mre_create(const void* blob, size_t nbytes, int num_envs, int device_id, mre_env** out) {
+  if (!blob || !out || num_envs <= 0) return fail(MRE_ERR_ARG, "mre_create: bad argument");
+  *out = nullptr;
+  mre_env* e = new mre_env();
+  int rc = build_model(blob, nbytes, e->hM);
+  if (rc != MRE_OK) { delete e; return rc; }
+  if (const char* it = getenv("MRE_DEBUG_ITERS")) e->hM.iterations = atoi(it);  // profiling knob only
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    delete e;
+    return fail(MRE_ERR_NOGPU, "mre_create: no HIP device visible (the HIP path has no CPU fallback)");
+  }
+  if (device_id < 0 || device_id >= ndev) {
+    delete e;
+    return fail(MRE_ERR_ARG, "mre_create: device_id out of range");
+  }
+  rc = create_buffers(e, num_envs, device_id);
+  if (rc != MRE_OK) {
+    const std::string msg = g_err;  // mre_destroy must not clobber the reason
+    mre_destroy(e);
+    g_err = msg;
+    return rc;
+  }
+  *out = e;
+  return MRE_OK;
 }
 
 extern "C" int mre_destroy(mre_env* e) {

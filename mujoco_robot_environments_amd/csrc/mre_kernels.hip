@@ -72,7 +72,7 @@ struct Sm {
   int nprops;
   // active contacts (pair order)
   int ncon, nefc, nl, nrrow, npp, overflow, solver_iters;
-  uint8_t con_pair[NCON_MAX], con_rslot[NCON_MAX], con_bslot[NCON_MAX];
+  uint8_t con_pair[NCON_MAX], con_rslot[NCON_MAX], con_bslot[NCON_MAX], con_b1[NCON_MAX], con_b2[NCON_MAX];
   uint16_t lim_info[NRV + 1];
   // ---- contiguous block [JpA .. sched]: written only after collision; hosts the per-lane
   // clip buffers of the narrow phase (mre_solver.h: collide)
@@ -261,54 +261,9 @@ MRE_DEV void crb_mass_matrix(const DevModel* M, Sm& s, int l) {
   }
 }
 
-// sparse L'DL of the robot block: elimination steps k = NRV-1..0, lane = (i,j) update
-MRE_DEV void factor_robot(const DevModel* M, float* LD, float* dinv, int l) {
-  for (int k = NRV - 1; k >= 0; --k) {
-    const int akk = M->dof_Madr[k];
-    const int nup = M->fac_n[k];
-    const int nanc = M->dof_Madr[k + 1] - akk - 1;
-    const float dkk = LD[akk];
-    float a = 0.f, b = 0.f, old = 0.f;
-    int dst = -1;
-    if (l < nup) {
-      dst = M->fac_dst[k][l];
-      a = LD[akk + M->fac_a[k][l]];
-      b = LD[akk + M->fac_b[k][l]];
-      old = LD[dst];
-    }
-    float sc = 0.f;
-    const int ls = l - MAXFAC;
-    if (ls >= 0 && ls < nanc) sc = LD[akk + 1 + ls];
-    __syncthreads();
-    const float inv = 1.0f / dkk;
-    if (dst >= 0) LD[dst] = old - (a * inv) * b;
-    if (ls >= 0 && ls < nanc) LD[akk + 1 + ls] = sc * inv;
-    if (l == 0) dinv[k] = inv;
-    __syncthreads();
-  }
-}
-
-// x <- M^-1 x on the robot block (serial, one lane; x lives in LDS).  The ancestor of entry a
-// comes from the M_j table by loop index (independent, prefetchable loads) rather than by walking
-// dof_parent (a chain of dependent loads); same operations in the same order as mj_solveLD.
-MRE_DEV void solve_robot_serial(const DevModel* M, const float* LD, const float* dinv, float* x) {
-  for (int i = NRV - 1; i >= 0; --i) {
-    const float xi = x[i];
-    const int a1 = M->dof_Madr[i + 1];
-    for (int a = M->dof_Madr[i] + 1; a < a1; ++a) x[M->M_j[a]] -= LD[a] * xi;
-  }
-  for (int i = 0; i < NRV; ++i) x[i] *= dinv[i];
-  for (int i = 0; i < NRV; ++i) {
-    const int a1 = M->dof_Madr[i + 1];
-    float xi = x[i];
-    for (int a = M->dof_Madr[i] + 1; a < a1; ++a) xi -= LD[a] * x[M->M_j[a]];
-    x[i] = xi;
-  }
-}
-
 // x <- M^-1 x with x in registers: mj_solveLD unrolled over the compile-time dof tree
 // (ROBOT_DOF_PARENT), every lane solving its own right-hand side; the factor entries are LDS
-// reads at constant offsets.  Same operations in the same order as the serial routine.
+// reads at constant offsets.  Same operations in the same order as mj_solveLD.
 typedef const __attribute__((address_space(3))) float* lds_cfloat_p;
 template <int I, int K>
 MRE_DEV void solve_regs_back(float (&x)[NRV], lds_cfloat_p LD, float xi) {
@@ -354,11 +309,58 @@ MRE_DEV void solve_robot_regs(const float* LD_, const float* dinv_, float (&x)[N
   solve_regs_fwd_rows<0>(x, LD);
 }
 
+// mj_factorM on the robot block with the matrix in registers: every lane runs the whole
+// elimination (312 multiply-adds, unrolled over the compile-time dof tree) on its own copy, which
+// replaces 15 lock-step elimination rounds of table loads + LDS round trips; the wave then stores
+// the factor (all lanes hold the same values).  Same operations as mj_factorM: for k = nv-1..0, for
+// every ancestor i of k: tmp = L(k,i) / L(k,k), row i -= tmp * row k (ancestors of i), L(k,i) = tmp.
+typedef __attribute__((address_space(3))) float* lds_float_p;
+template <int K, int P, int Q>
+MRE_DEV void factor_regs_upd(float (&A)[NMR], float tmp) {
+  if constexpr (Q <= robot_dof_depth(K)) {
+    constexpr int i = robot_dof_anc(K, P - 1);
+    constexpr int dst = robot_dof_madr(i) + (Q - P), src = robot_dof_madr(K) + Q;
+    A[dst] -= tmp * A[src];
+    factor_regs_upd<K, P, Q + 1>(A, tmp);
+  }
+}
+template <int K, int P>
+MRE_DEV void factor_regs_anc(float (&A)[NMR], float inv) {
+  if constexpr (P <= robot_dof_depth(K)) {
+    constexpr int kp = robot_dof_madr(K) + P;
+    const float tmp = A[kp] * inv;
+    factor_regs_upd<K, P, P>(A, tmp);
+    A[kp] = tmp;
+    factor_regs_anc<K, P + 1>(A, inv);
+  }
+}
+template <int K>
+MRE_DEV void factor_regs_rows(float (&A)[NMR], lds_float_p dinv) {
+  constexpr int kk = robot_dof_madr(K);
+  const float inv = 1.0f / A[kk];
+  dinv[K] = inv;
+  factor_regs_anc<K, 1>(A, inv);
+  if constexpr (K > 0) factor_regs_rows<K - 1>(A, dinv);
+}
+// src: the matrix (qM, or M - h dF/dv already formed in LD); LD / dinv: factor and 1/D (all LDS)
+MRE_PHASE_FN void factor_robot_regs(const float* src_, float* LD_, float* dinv_) {
+  lds_cfloat_p src = (lds_cfloat_p)src_;
+  lds_float_p LD = (lds_float_p)LD_, dinv = (lds_float_p)dinv_;
+  asm volatile("" : "+v"(src), "+v"(LD), "+v"(dinv));
+  float A[NMR];
+#pragma unroll
+  for (int e = 0; e < NMR; e++) A[e] = src[e];
+  factor_regs_rows<NRV - 1>(A, dinv);
+#pragma unroll
+  for (int e = 0; e < NMR; e++) LD[e] = A[e];
+  __syncthreads();
+}
+
 // x <- M^-1 x for up to four right-hand sides at once, level-parallel: lane = (group g = l / 16,
 // dof i = l % 16), group g works on xb + g * xstride (LDS).  Backward pass from the deepest dofs
 // up (a dof folds in all its descendants, which are final), scaling, forward pass from the roots
 // down; the terms of every sum are applied in mj_solveLD's order, so the result is bit-identical
-// to the serial routine.  The dof tree is at most sol_maxdepth + 1 levels deep (9 for this robot).
+// to the serial algorithm.  The dof tree is at most sol_maxdepth + 1 levels deep (9 for this robot).
 MRE_PHASE_FN void solve_robot_par(const DevModel* M, const float* LD, const float* dinv, float* xb, int xstride,
                                   int ngroups, int l) {
   const int g = l >> 4, i = l & 15;
@@ -549,7 +551,7 @@ MRE_PHASE_FN void integrate(const DevModel* M, Sm& s, int l, bool grip_clamped, 
   }
   if (l < NRV) s.scratch[l] = s.qfrc_smooth[l] + s.qfrc_con[l];
   __syncthreads();
-  factor_robot(M, s.qLD, s.qLDinv, l);
+  factor_robot_regs(s.qLD, s.qLD, s.qLDinv);
   solve_robot_par(M, s.qLD, s.qLDinv, s.scratch, 0, 1, l);
   const bool freeze = (flags & F_FREEZE_ROBOT) != 0;
   if (l < NV) {
@@ -648,9 +650,7 @@ MRE_DEV void step_body(const StepArgs& a, Sm& s) {
     position_stage(M, s, l);
     crb_mass_matrix(M, s, l);
     __syncthreads();
-    for (int e = l; e < NMR; e += 64) s.qLD[e] = s.qM[e];
-    __syncthreads();
-    factor_robot(M, s.qLD, s.qLDinv, l);
+    factor_robot_regs(s.qM, s.qLD, s.qLDinv);
     MRE_STAMP(0);
     // ------------------------------------------------ S1b: velocity stage (before collision:
     // its temporaries share LDS region R2 with the contact geometry)

@@ -230,14 +230,20 @@ MRE_PHASE_FN void assemble_constraints(const DevModel* M, Sm& s, int l) {
   for (int k = 0; k < l; k++) lim_idx += s.iscr[k];
   if (l == 63) s.nl = lim_idx + lim;
   if (lim) s.lim_info[lim_idx] = l | ((lim_side > 0 ? 1 : 0) << 8);
+  // bodies of every contact's geoms (lane = contact): the serial loops below then read LDS only
+  // instead of chasing pair -> geom -> body through the model tables once per contact
+  if (l < s.ncon) {
+    const int pr = s.con_pair[l];
+    s.con_b1[l] = (uint8_t)M->geom_body[M->pair_g1[pr]];
+    s.con_b2[l] = (uint8_t)M->geom_body[M->pair_g2[pr]];
+  }
   __syncthreads();
   // ---- robot-slot assignment and capacity (serial, lane 0)
   if (l == 0) {
     const int base = 7 + s.nl;
     int rnext = base, ncon = s.ncon, kept = 0, bnext = 0;
     for (int c = 0; c < ncon; c++) {
-      const int pr = s.con_pair[c];
-      const int cb1 = M->geom_body[M->pair_g1[pr]], cb2 = M->geom_body[M->pair_g2[pr]];
+      const int cb1 = s.con_b1[c], cb2 = s.con_b2[c];
       const bool rob = cb1 < NRB && cb1 > 0;
       const bool rob2 = cb2 < NRB && cb2 > 0;
       const bool two_props = cb1 >= NRB && cb2 >= NRB;
@@ -312,7 +318,7 @@ MRE_PHASE_FN void assemble_constraints(const DevModel* M, Sm& s, int l) {
     } else {
       const int c = (i - 7 - nl) / 3, r = (i - 7 - nl) % 3;
       const int pr = s.con_pair[c];
-      const int b1 = M->geom_body[M->pair_g1[pr]], b2 = M->geom_body[M->pair_g2[pr]];
+      const int b1 = s.con_b1[c], b2 = s.con_b2[c];
       const float* ax = &s.con_frame[c][3 * r];
       const float* p = s.con_pos[c];
       const int rs0 = s.con_rslot[c];
@@ -446,15 +452,7 @@ MRE_DEV int lane_dof(int l) {
   if (l >= 16 && l < 48 && ((l - 16) & 7) < 6) return NRV + 6 * ((l - 16) >> 3) + ((l - 16) & 7);
   return -1;
 }
-// sum over the lanes of one island: 8-lane halves everywhere, full 16 lanes on DPP row 0
-MRE_DEV float island_sum(float v) {
-  v = dpp_add<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
-  v = dpp_add<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
-  v = dpp_add<0x141, 0xF>(v);  // row_half_mirror
-  v = dpp_add<0x140, 0x1>(v);  // row_mirror, row 0 only (robot island spans 16 lanes)
-  return v;
-}
-
+// sums over the lanes of one island (8-lane halves everywhere, full 16 lanes on DPP row 0),
 // three island sums at once
 MRE_DEV void island_sum3(float& x, float& y, float& z) {
   // one v_add_f32_dpp per value and level; the three chains interleave, which also provides the
@@ -513,8 +511,7 @@ MRE_DEV void build_schedule(const DevModel* M, Sm& s) {
     if (last[0] > nst) nst = last[0];
   }
   for (int c = 0; c < s.ncon; c++) {
-    const int pr = s.con_pair[c];
-    const int b1 = M->geom_body[M->pair_g1[pr]], b2 = M->geom_body[M->pair_g2[pr]];
+    const int b1 = s.con_b1[c], b2 = s.con_b2[c];
     const int rs = s.con_rslot[c];
     int pa = 0xF, pb = 0xF;
     if (b1 >= NRB) pa = b1 - NRB;
