@@ -80,6 +80,9 @@ int mre_place_props(mre_env*, const uint8_t* mask, uint64_t seed, const float* w
 /* global id of env 0 of this handle (rank r of a sharded batch: r * num_envs); random
  * draws are keyed by global id so results do not depend on the sharding */
 int mre_set_env_id_offset(mre_env*, long long offset);
+/* explicit global ids [N] instead of offset + index (NULL = back to the offset form): lets several
+ * envs share one id, i.e. one scene -- a population of controllers on the same scene replicates */
+int mre_set_env_ids(mre_env*, const long long* ids);
 
 /* physics.bind(joints).qpos / .qvel access: rows [N][MRE_NQ_PAD] / [N][MRE_NV_PAD] */
 int mre_set_state(mre_env*, const float* qpos, const float* qvel);
@@ -109,6 +112,11 @@ int mre_osc_set_target(mre_env*, const float* pos, const float* quat, const floa
  * gains[6] = kp_pos,kd_pos,kp_ori,kd_ori,kp_null,kd_null; null_q[7]; thresholds[2] */
 int mre_osc_configure(mre_env*, const float* gains, const float* null_q, const float* thresholds,
                       int pinv_always);
+/* one parameter set PER ENV (gains [N][6] = kp/kd position, orientation, nullspace; null_q [N][7];
+ * thr [N][2]; NULL = the shared set's values): a population of controllers evaluated as one batch,
+ * the batched form of automated_controller_tuning/rearrangement_controller_tuning.py:144-197
+ * (`controller_gains = {...}` per candidate).  mre_osc_configure returns to one shared set. */
+int mre_osc_configure_env(mre_env*, const float* gains, const float* null_q, const float* thr);
 /* MinMax.status = "max"/"min" (tasks/rearrangement.py:380,422): closed[N] 1 -> 255, 0 -> 0 */
 int mre_gripper_set(mre_env*, const uint8_t* closed);
 /* RobotArm.run_controller(duration) (models/robot_arm.py:61-94): nticks control

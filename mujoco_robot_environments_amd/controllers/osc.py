@@ -38,6 +38,13 @@ class OSC:
                    g["nullspace"]["kp"], g["nullspace"]["kd"]],
             null_q=self.nullspace_config, thresholds=[self.position_threshold, self.orientation_threshold])
 
+    def set_gains_per_env(self, gains):
+        """A population of gain sets evaluated as one batch (one candidate per env): gains [N, 6] =
+        kp, kd of position / orientation / nullspace -- the batched form of assigning
+        ``controller_gains`` per candidate in automated_controller_tuning/
+        rearrangement_controller_tuning.py:164-168.  ``_push_config`` returns to the shared set."""
+        self.physics.osc_configure_env(gains=np.asarray(gains, np.float32))
+
     def _b(self, x, w):
         x = np.asarray(x, np.float64)
         if x.ndim == 1:

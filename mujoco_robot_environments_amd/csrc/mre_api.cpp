@@ -63,9 +63,11 @@ struct mre_env {
   int* stats = nullptr;
   OscConfig osc;
   OscConfig* d_osc = nullptr;
+  OscConfig* d_osc_env = nullptr;  // [N] per-env controller parameters (mre_osc_configure_env) or null
   float* trace = nullptr;
   int trace_nenv = 0, trace_max = 0, trace_pos = 0;
   long long env_id_offset = 0;
+  std::vector<long long> env_ids;  // explicit global ids (mre_set_env_ids) or empty = offset + index
   int* order = nullptr;       // dispatch permutation (heavy-first), device
   bool use_order = false;     // caller-supplied permutation (mre_set_env_order)
   int* auto_order = nullptr;  // permutation maintained by launch_step: longest Gauss-Seidel schedule first
@@ -481,7 +483,7 @@ extern "C" int mre_destroy(mre_env* e) {
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   if (e->stream2) (void)hipStreamSynchronize(e->stream2);
   void* ptrs[] = {e->dM, e->qpos, e->qvel, e->qacc_ws, e->ctrl, e->nprops, e->prop_size, e->osc_target,
-                  e->grip_closed, e->converged, e->mask, e->sites, e->status, e->stats, e->d_osc, e->order,
+                  e->grip_closed, e->converged, e->mask, e->sites, e->status, e->stats, e->d_osc, e->d_osc_env, e->order,
                   e->d_large, e->mask_c, e->mask_l, e->mask_r, e->sv_qpos, e->sv_qvel, e->sv_qacc_ws, e->sv_ctrl,
                   e->sv_status, e->launch_info, e->auto_order};
   for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -591,7 +593,8 @@ static void fill_args(mre_env* e, StepArgs& a) {
   a.qpos = e->qpos; a.qvel = e->qvel; a.qacc_ws = e->qacc_ws; a.ctrl = e->ctrl;
   a.nprops = e->nprops; a.prop_size = e->prop_size;
   a.control_steps = 1; a.mode = CTRL_HELD;
-  a.osc = e->d_osc; a.osc_target = e->osc_target; a.grip_closed = e->grip_closed;
+  a.osc = e->d_osc_env ? e->d_osc_env : e->d_osc; a.osc_stride = e->d_osc_env ? 1 : 0;
+  a.osc_target = e->osc_target; a.grip_closed = e->grip_closed;
   a.sites = e->sites; a.status = e->status; a.stats = e->stats;
   a.env_order = e->use_order ? e->order : (e->have_auto_order ? e->auto_order : nullptr);
   a.trace = e->trace; a.trace_nenv = e->trace_nenv; a.trace_max = e->trace_max; a.trace_base = e->trace_pos;
@@ -651,6 +654,29 @@ extern "C" int mre_osc_configure(mre_env* e, const float* gains, const float* nu
   e->osc.pinv_always = pinv_always;
   HIPCHK(hipStreamSynchronize(e->stream));
   HIPCHK(hipMemcpy(e->d_osc, &e->osc, sizeof(OscConfig), hipMemcpyHostToDevice));
+  if (e->d_osc_env) { (void)hipFree(e->d_osc_env); e->d_osc_env = nullptr; }
+  return MRE_OK;
+}
+
+// per-env controller parameters (a population of gain sets, one per env): any NULL array keeps the
+// shared configuration's values; mre_osc_configure afterwards returns to one shared set
+extern "C" int mre_osc_configure_env(mre_env* e, const float* gains, const float* null_q, const float* thr) {
+  if (!e) return fail(MRE_ERR_ARG, "null handle");
+  const size_t N = (size_t)e->N;
+  std::vector<OscConfig> h(N, e->osc);
+  for (size_t i = 0; i < N; i++) {
+    if (gains) {
+      const float* g = gains + 6 * i;
+      for (int k = 0; k < 6; k++)
+        if (!(g[k] >= 0.f) || !std::isfinite(g[k])) return fail(MRE_ERR_ARG, "mre_osc_configure_env: gains must be finite and >= 0");
+      h[i].kp_pos = g[0]; h[i].kd_pos = g[1]; h[i].kp_ori = g[2]; h[i].kd_ori = g[3]; h[i].kp_null = g[4]; h[i].kd_null = g[5];
+    }
+    if (null_q) for (int k = 0; k < 7; k++) h[i].null_q[k] = null_q[7 * i + k];
+    if (thr) { h[i].pos_thresh = thr[2 * i]; h[i].ori_thresh = thr[2 * i + 1]; }
+  }
+  HIPCHK(hipStreamSynchronize(e->stream));
+  if (!e->d_osc_env) HIPCHK(hipMalloc(&e->d_osc_env, N * sizeof(OscConfig)));
+  HIPCHK(hipMemcpy(e->d_osc_env, h.data(), N * sizeof(OscConfig), hipMemcpyHostToDevice));
   return MRE_OK;
 }
 
@@ -784,7 +810,7 @@ extern "C" int mre_place_props(mre_env* e, const uint8_t* mask, uint64_t seed, c
   for (int k = 0; k < 3; k++) { lo[k] = ws_min[k]; hi[k] = ws_max[k]; }
   for (size_t i = 0; i < N; i++) {
     if (!hm[i]) continue;
-    const uint64_t gid = (uint64_t)(e->env_id_offset + (long long)i);
+    const uint64_t gid = (uint64_t)(e->env_ids.empty() ? e->env_id_offset + (long long)i : e->env_ids[i]);
     double rb[NPROP], pose[NPROP][7];
     for (int p = 0; p < NPROP; p++) {
       const float* z = &ps[(i * NPROP + p) * 3];
@@ -840,8 +866,15 @@ extern "C" int mre_place_props(mre_env* e, const uint8_t* mask, uint64_t seed, c
   return MRE_OK;
 }
 
+extern "C" int mre_set_env_ids(mre_env* e, const long long* ids) {
+  if (!e) return fail(MRE_ERR_ARG, "null handle");
+  if (ids) e->env_ids.assign(ids, ids + e->N); else e->env_ids.clear();
+  return MRE_OK;
+}
+
 extern "C" int mre_set_env_id_offset(mre_env* e, long long offset) {
   if (!e) return fail(MRE_ERR_ARG, "null handle");
+  e->env_ids.clear();
   e->env_id_offset = offset;
   return MRE_OK;
 }

@@ -130,7 +130,8 @@ struct StepArgs {
   int nsteps, control_steps, mode;
   unsigned flags;
   // OSC
-  const OscConfig* osc;      // device copy of the controller parameters
+  const OscConfig* osc;      // device copy of the controller parameters: one, or one per env
+  int osc_stride;            // 0 = shared by all envs, 1 = osc[env]
   const float* osc_target;   // [N][16]: pos3 quat4 vel3 angvel3 pad3
   const uint8_t* grip_closed;  // [N]
   uint8_t* converged;        // [N] or null

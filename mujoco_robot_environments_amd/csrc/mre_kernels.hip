@@ -637,6 +637,7 @@ MRE_DEV void step_body(const StepArgs& a, Sm& s) {
 #endif
   bool arm_converged = false;
   float grip_cmd = 0.f;
+  const OscConfig* oscp = a.osc + (size_t)env * a.osc_stride;  // per-env gains when tuning a population
   int hw_ncon = 0, hw_nefc = 0, hw_nrrow = 0, hw_npp = 0, hw_nsched = 0;  // high-water marks of this launch
   if (a.mode == CTRL_OSC) {
     if (l < 16) s.osc_tgt[l] = a.osc_target[(size_t)env * 16 + l];
@@ -679,8 +680,8 @@ MRE_DEV void step_body(const StepArgs& a, Sm& s) {
     if (a.mode == CTRL_OSC && (step % a.control_steps) == 0) {
       // RobotArm.run_controller tick (robot_arm.py:69-88): is_converged() of the previous
       // tick is evaluated on the same (step1-fresh) state the next torque is computed from
-      if (step > 0 && osc_converged(M, s, a.osc, s.osc_tgt)) arm_converged = true;
-      osc_compute(M, s, osc, a.osc, s.osc_tgt, l);
+      if (step > 0 && osc_converged(M, s, oscp, s.osc_tgt)) arm_converged = true;
+      osc_compute(M, s, osc, oscp, s.osc_tgt, l);
       if (l == 0) s.ctrl[NU - 1] = grip_cmd;
       __syncthreads();
     }
@@ -706,7 +707,7 @@ MRE_DEV void step_body(const StepArgs& a, Sm& s) {
   // ---- final kinematics for site queries
   kinematics_only(M, s, l);
   if (a.mode == CTRL_OSC && a.nsteps > 0) {
-    if (osc_converged(M, s, a.osc, s.osc_tgt)) arm_converged = true;
+    if (osc_converged(M, s, oscp, s.osc_tgt)) arm_converged = true;
     if (l == 0) {
       if (a.converged != nullptr) a.converged[env] = arm_converged ? 1 : 0;
       if (!arm_converged && a.status != nullptr) a.status[env] |= 1u;

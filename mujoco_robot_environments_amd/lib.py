@@ -26,7 +26,7 @@ EXPORTS = [
     "mre_set_trace", "mre_osc_set_target", "mre_osc_configure", "mre_gripper_set",
     "mre_run_controller", "mre_get_sites", "mre_get_status", "mre_get_solver_stats",
     "mre_profile_enable", "mre_profile_read", "mre_set_env_id_offset", "mre_set_env_order",
-    "mre_set_fallback", "mre_get_fallback_stats",
+    "mre_set_fallback", "mre_get_fallback_stats", "mre_osc_configure_env", "mre_set_env_ids",
 ]
 
 
@@ -110,10 +110,12 @@ def lib() -> C.CDLL:
     L.mre_get_status.argtypes = [vp, fp]
     L.mre_get_solver_stats.argtypes = [vp, fp]
     L.mre_set_env_id_offset.argtypes = [vp, C.c_longlong]
+    L.mre_set_env_ids.argtypes = [vp, C.POINTER(C.c_longlong)]
     L.mre_set_env_order.argtypes = [vp, fp]
     L.mre_profile_enable.argtypes = [vp, ci]
     L.mre_profile_read.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(ci)]
     L.mre_set_fallback.argtypes = [vp, ci]
+    L.mre_osc_configure_env.argtypes = [vp, fp, fp, fp]
     L.mre_get_fallback_stats.argtypes = [vp, C.POINTER(C.c_longlong)]
     for name in EXPORTS:
         if name not in ("mre_last_error", "mre_stream"):

@@ -93,6 +93,11 @@ class BatchedPhysics:
         assert sorted(o.tolist()) == list(range(self.num_envs)), "order must be a permutation"
         check(_lib.lib().mre_set_env_order(self._h, _ptr(o)), "mre_set_env_order")
 
+    def set_env_ids(self, ids) -> None:
+        """Explicit global env ids (RNG keys of prop placement); envs may share an id = a scene."""
+        a = np.ascontiguousarray(ids, np.int64).reshape(self.num_envs)
+        check(_lib.lib().mre_set_env_ids(self._h, a.ctypes.data_as(C.POINTER(C.c_longlong))), "mre_set_env_ids")
+
     def set_env_id_offset(self, offset: int) -> None:
         check(_lib.lib().mre_set_env_id_offset(self._h, int(offset)), "mre_set_env_id_offset")
 
@@ -183,6 +188,18 @@ class BatchedPhysics:
         t = None if thresholds is None else np.ascontiguousarray(thresholds, np.float32)
         check(_lib.lib().mre_osc_configure(self._h, _ptr(g), _ptr(q), _ptr(t), int(pinv_always)),
               "mre_osc_configure")
+
+    def osc_configure_env(self, gains=None, null_q=None, thresholds=None) -> None:
+        """One controller parameter set per env: gains [N, 6] (kp, kd of position / orientation /
+        nullspace), null_q [N, 7], thresholds [N, 2]; None keeps the shared set's values."""
+        def prep(x, w):
+            if x is None:
+                return None
+            x = np.ascontiguousarray(x, np.float32)
+            assert x.shape == (self.num_envs, w), (x.shape, w)
+            return x
+        g, q, t = prep(gains, 6), prep(null_q, 7), prep(thresholds, 2)
+        check(_lib.lib().mre_osc_configure_env(self._h, _ptr(g), _ptr(q), _ptr(t)), "mre_osc_configure_env")
 
     def osc_set_target(self, position=None, quat=None, velocity=None, angular_velocity=None,
                        mask=None) -> None:

@@ -72,12 +72,15 @@ class BatchedRearrangementEnv:
     """num_envs independent RearrangementEnv instances stepped in lockstep on one GPU."""
 
     def __init__(self, cfg: Optional[Cfg] = None, num_envs: int = 1, viewer=None, device: int = 0,
-                 seed: Optional[int] = None, env_id_offset: int = 0):
+                 seed: Optional[int] = None, env_id_offset: int = 0, env_ids=None):
         self._cfg = cfg if cfg is not None else DEFAULT_CONFIG
         cfg = self._cfg
         self.num_envs = int(num_envs)
         self.has_viewer = False  # no viewer on a headless GPU batch (tasks/rearrangement.py:64-70)
-        self.env_ids = np.arange(env_id_offset, env_id_offset + self.num_envs)
+        # global env ids key every random draw; explicit ids may repeat (envs sharing a scene)
+        self.env_ids = (np.arange(env_id_offset, env_id_offset + self.num_envs) if env_ids is None
+                        else np.asarray(env_ids, np.int64).reshape(self.num_envs))
+        self._explicit_ids = env_ids is not None
         self.seed = int(cfg.task.initializers.seed if seed is None else seed)
         ac = cfg.robots.arm.actuator_config
         lim = [float(ac[ac.joint_actuator_mapping[f"joint{i + 1}"]].ctrlrange.split()[1]) for i in range(7)]
@@ -154,7 +157,10 @@ class BatchedRearrangementEnv:
         (tasks/rearrangement.py:297-337)."""
         ws = self._cfg.task.initializers.workspace
         self._physics.reset()
-        self._physics.set_env_id_offset(int(self.env_ids[0]))
+        if self._explicit_ids:
+            self._physics.set_env_ids(self.env_ids)
+        else:
+            self._physics.set_env_id_offset(int(self.env_ids[0]))
         # settle with the robot frozen: >= 0.3 s, <= 2 s, until max|qvel| of the cubes < 1e-3
         steps, done = 300, False
         try:

@@ -313,3 +313,41 @@ def test_scripted_pick_phases_match_oracle(compiled_model, oracle_model):
     print("cube lifted: gpu", lifted_gpu.astype(int), "cpu", lifted_cpu.astype(int), "fallback", phys.fallback_stats())
     assert (lifted_gpu == lifted_cpu).sum() >= N - 1
     phys.close()
+
+
+def test_per_env_osc_gains_match_oracle(compiled_model, oracle_model):
+    """mre_osc_configure_env: every env runs its own gain set (a CMA-ES population as one batch,
+    automated_controller_tuning/rearrangement_controller_tuning.py:164-168).  8 envs, 8 different
+    gain sets, 200 ticks towards one target; each env must follow the oracle configured with ITS
+    gains, and envs with different gains must actually move differently."""
+    from oracle import oracle as O
+    N, ticks = 8, 200
+    phys, envs, nprops, ids = _osc_setup(compiled_model, oracle_model, N, seed=13)
+    gains = np.array([[350, 20, 500, 100, 200, 30], [200, 30, 500, 100, 200, 30], [350, 37, 500, 100, 200, 30],
+                      [500, 45, 300, 60, 100, 20], [150, 25, 800, 120, 200, 30], [350, 20, 500, 100, 50, 10],
+                      [100, 20, 200, 40, 20, 5], [600, 50, 600, 110, 300, 40]], np.float32)
+    sx = envs[0].arr("site_xpos")[:3].copy()
+    tgt = sx + np.array([0.05, -0.08, -0.15])
+    from mujoco_robot_environments_amd.model.compile import m2q
+    quat = m2q(envs[0].arr("site_xmat")[:9].reshape(3, 3))
+    phys.osc_configure_env(gains=gains)
+    phys.osc_set_target(position=tgt, quat=quat, velocity=np.zeros(3), angular_velocity=np.zeros(3))
+    phys.gripper_set(np.zeros(N, np.uint8))
+    phys.run_controller(ticks // 2, 5)
+    mid = phys.qpos()[:, :7].copy()
+    phys.run_controller(ticks // 2, 5)
+    gq = phys.qpos()
+    err = np.zeros(N)
+    for i, e in enumerate(envs):
+        g = gains[i]
+        p = O.make_osc(dict(kp_pos=g[0], kd_pos=g[1], kp_ori=g[2], kd_ori=g[3], kp_null=g[4], kd_null=g[5]))
+        p.target_pos[:] = tgt; p.target_quat[:] = quat
+        e.run_controller(p, 0.0, ticks, 5)
+        err[i] = np.abs(gq[i, :7] - e.arr("qpos")[:7]).max()
+    print("per-env gains: arm err", err)
+    assert err.max() < QPOS_TOL
+    assert np.abs(mid[0] - mid[6]).max() > 1e-2  # stiff vs soft gains are at different places mid-way
+    # back to ONE shared set: all envs with identical state history would now get identical gains
+    phys.osc_configure(gains=[350, 20, 500, 100, 200, 30], null_q=[0, -0.785, 0, -2.356, 0, 1.571, 0.785],
+                       thresholds=[5e-3, 68e-3])
+    phys.close()
