@@ -136,6 +136,20 @@ int mre_get_solver_stats(mre_env*, int32_t* stats);
  * env, so callers may put envs with many constraint rows first (see mre_get_solver_stats). */
 int mre_set_env_order(mre_env*, const int32_t* order);
 
+/* Batched overhead camera (replaces the mujoco.Renderer passes of
+ * tasks/rearrangement.py:254-280, 460-478, 500-530): one ray per pixel against the scene's ground
+ * plane, table, cubes and robot box hulls, for the CURRENT state of every env (mask: NULL = all).
+ *   cam_pos[3], cam_mat[9]  camera frame -> world (row-major; MuJoCo cameras look along -z, y up)
+ *   rgb   device u8  [N][H][W][3] or NULL     (flat-shaded approximation of MuJoCo's lighting)
+ *   depth device f32 [N][H][W]    or NULL     (distance along the optical axis [m]; 100 = nothing hit)
+ *   seg   device u8  [N][H][W]    or NULL     (geom index: 0 ground, 1 table, 2..11 robot hulls,
+ *                                              12 + p cube p; 255 = nothing hit)
+ * width must be a multiple of 4.  Enqueued on the handle's stream.  Colours: cube albedo per env
+ * [N][4][3] u8 and static geom albedo [16][3] floats (NULL keeps the current / default grey). */
+int mre_set_render_colours(mre_env*, const uint8_t* prop_rgb, const float* geom_rgb);
+int mre_render(mre_env*, const float* cam_pos, const float* cam_mat, float fovy_deg, int height, int width,
+               uint8_t* rgb, float* depth, uint8_t* seg, const uint8_t* mask);
+
 /* Constraint capacities.  The library holds the step kernel in two capacity sets
  * (csrc/mre_dev.h): compact (32 contacts / 112 rows / 50 robot rows / 8 cube-cube contacts, 8
  * workgroups per CU) and large (48 / 160 / 100 / 16, 5 per CU).  By default every launch runs each

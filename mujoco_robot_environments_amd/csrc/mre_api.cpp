@@ -19,6 +19,7 @@ using namespace mre;
 extern "C" void mre_launch_step(const StepArgs* args, hipStream_t stream);
 extern "C" void mre_launch_settle(const StepArgs* args, hipStream_t stream);
 extern "C" void mre_launch_step_large(const StepArgs* args, hipStream_t stream);
+extern "C" void mre_launch_render(const RenderArgs* args, int row_groups, hipStream_t stream);
 extern "C" void mre_launch_prepare(const uint8_t* user_mask, const uint8_t* large, int N, uint8_t* mask_compact,
                                    uint8_t* mask_large, int* launch_info, const float* qpos, float* sv_qpos,
                                    const float* qvel, float* sv_qvel, const float* qacc_ws, float* sv_qacc_ws,
@@ -63,7 +64,10 @@ struct mre_env {
   int* stats = nullptr;
   OscConfig osc;
   OscConfig* d_osc = nullptr;
-  OscConfig* d_osc_env = nullptr;  // [N] per-env controller parameters (mre_osc_configure_env) or null
+  OscConfig* d_osc_env = nullptr;
+  float* geoms = nullptr;        // [N][NG][16] geom poses for the renderer (allocated on first use)
+  uint8_t* prop_rgb = nullptr;   // [N][NPROP][3]
+  float geom_rgb[NG][3];  // [N] per-env controller parameters (mre_osc_configure_env) or null
   float* trace = nullptr;
   int trace_nenv = 0, trace_max = 0, trace_pos = 0;
   long long env_id_offset = 0;
@@ -484,6 +488,7 @@ extern "C" int mre_destroy(mre_env* e) {
   if (e->stream2) (void)hipStreamSynchronize(e->stream2);
   void* ptrs[] = {e->dM, e->qpos, e->qvel, e->qacc_ws, e->ctrl, e->nprops, e->prop_size, e->osc_target,
                   e->grip_closed, e->converged, e->mask, e->sites, e->status, e->stats, e->d_osc, e->d_osc_env, e->order,
+                  e->geoms, e->prop_rgb,
                   e->d_large, e->mask_c, e->mask_l, e->mask_r, e->sv_qpos, e->sv_qvel, e->sv_qacc_ws, e->sv_ctrl,
                   e->sv_status, e->launch_info, e->auto_order};
   for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -545,6 +550,76 @@ extern "C" int mre_reset(mre_env* e, const uint8_t* mask) {
     HIPCHK(hipMemcpyAsync(e->d_large, e->h_large.data(), (size_t)e->N, hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
   }
+  return MRE_OK;
+}
+
+// ---- batched overhead camera (csrc/mre_render.hip)
+static void fill_args(mre_env* e, StepArgs& a);
+static bool is_device_ptr(const void* p) {
+  hipPointerAttribute_t at;
+  if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return at.type == hipMemoryTypeDevice;
+}
+
+extern "C" int mre_set_render_colours(mre_env* e, const uint8_t* prop_rgb, const float* geom_rgb) {
+  if (!e) return fail(MRE_ERR_ARG, "null handle");
+  const size_t N = (size_t)e->N;
+  if (!e->prop_rgb) {
+    HIPCHK(hipMalloc(&e->prop_rgb, N * NPROP * 3));
+    HIPCHK(hipMemset(e->prop_rgb, 128, N * NPROP * 3));
+    for (int g = 0; g < NG; g++) for (int k = 0; k < 3; k++) e->geom_rgb[g][k] = 0.5f;
+  }
+  if (prop_rgb) { int rc = copy_in(e, e->prop_rgb, prop_rgb, N * NPROP * 3); if (rc) return rc; }
+  if (geom_rgb) memcpy(e->geom_rgb, geom_rgb, sizeof(e->geom_rgb));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return MRE_OK;
+}
+
+extern "C" int mre_render(mre_env* e, const float* cam_pos, const float* cam_mat, float fovy_deg, int height, int width,
+                          uint8_t* rgb, float* depth, uint8_t* seg, const uint8_t* mask) {
+  if (!e || !cam_pos || !cam_mat) return fail(MRE_ERR_ARG, "mre_render: null argument");
+  if (height <= 0 || width <= 0 || (width & 3) != 0 || width / 4 > 320 || !(fovy_deg > 0.f && fovy_deg < 180.f))
+    return fail(MRE_ERR_ARG, "mre_render: width must be a multiple of 4 (<= 1280), 0 < fovy < 180");
+  if ((rgb && !is_device_ptr(rgb)) || (depth && !is_device_ptr(depth)) || (seg && !is_device_ptr(seg)))
+    return fail(MRE_ERR_ARG, "mre_render: image buffers must be device pointers");
+  if (depth && ((uintptr_t)depth & 15)) return fail(MRE_ERR_ARG, "mre_render: depth must be 16-byte aligned");
+  if ((rgb && ((uintptr_t)rgb & 3)) || (seg && ((uintptr_t)seg & 3)))
+    return fail(MRE_ERR_ARG, "mre_render: rgb / seg must be 4-byte aligned");
+  int rc = MRE_OK;
+  if (!e->prop_rgb) { rc = mre_set_render_colours(e, nullptr, nullptr); if (rc) return rc; }
+  const size_t N = (size_t)e->N;
+  if (!e->geoms) HIPCHK(hipMalloc(&e->geoms, N * NG * 16 * 4));
+  const uint8_t* dmask;
+  rc = stage_mask(e, mask, &dmask);
+  if (rc) return rc;
+  // geometry of the current state: a zero-step launch of the step kernel (kinematics + export)
+  StepArgs a;
+  fill_args(e, a);
+  a.nsteps = 0; a.trace = nullptr; a.env_order = nullptr; a.env_mask = dmask; a.geoms = e->geoms;
+  mre_launch_step(&a, e->stream);
+  HIPCHK(hipGetLastError());
+  RenderArgs r;
+  memset(&r, 0, sizeof(r));
+  r.N = e->N; r.height = height; r.width = width;
+  r.geoms = e->geoms; r.nprops = e->nprops; r.prop_rgb = e->prop_rgb;
+  memcpy(r.geom_rgb, e->geom_rgb, sizeof(r.geom_rgb));
+  for (int k = 0; k < 3; k++) r.cam_pos[k] = cam_pos[k];
+  for (int k = 0; k < 9; k++) r.cam_mat[k] = cam_mat[k];
+  r.fy = 0.5f * (float)height / tanf(0.5f * fovy_deg * 3.14159265358979323846f / 180.f);
+  // arena.xml:18 (positional light) and MuJoCo's default headlight (ambient 0.1, diffuse 0.4)
+  r.light_pos[0] = 0.7f; r.light_pos[1] = 0.f; r.light_pos[2] = 1.6f;
+  r.ambient = 0.1f; r.head_diffuse = 0.4f; r.light_diffuse = 0.7f;
+  // arena.xml:5-6: checker .2 .3 .4 / .1 .2 .3, texrepeat 5 per metre of a 2 x 2 checker
+  const float c0[3] = {0.2f, 0.3f, 0.4f}, c1[3] = {0.1f, 0.2f, 0.3f};
+  for (int k = 0; k < 3; k++) { r.checker[0][k] = c0[k]; r.checker[1][k] = c1[k]; }
+  r.checker_size = 0.1f;
+  r.zfar = 100.f;
+  r.rgb = rgb; r.depth = depth; r.seg = seg; r.env_mask = dmask;
+  const int rows_per_iter = 320 / (width / 4);
+  int row_groups = (height + rows_per_iter - 1) / rows_per_iter;
+  if (row_groups > 60) row_groups = 60;
+  mre_launch_render(&r, row_groups, e->stream);
+  HIPCHK(hipGetLastError());
   return MRE_OK;
 }
 

@@ -143,9 +143,30 @@ struct StepArgs {
   int trace_nenv, trace_max, trace_base;
   const uint8_t* env_mask;   // [N] or null: envs with 0 are skipped by this launch
   const int* env_order;      // [N] or null: workgroup b steps env env_order[b] (heavy-first dispatch)
+  float* geoms;              // [N][NG][16] or null: world pose of every geom for the renderer
+                             //  (pos3, rotation 9 row-major geom->world, half sizes 3, type)
   int* launch_info;          // [N][4] or null: {overflowed in this launch, max ncon | max schedule
                              //  length << 16, max nefc, max robot rows | max cube-cube contacts << 16}
                              //  over the launch's steps
+};
+
+// Camera + shading parameters of mre_render (csrc/mre_render.hip)
+struct RenderArgs {
+  int N, height, width;
+  const float* geoms;        // [N][NG][16] from the step kernel's geometry export
+  const int* nprops;         // [N]
+  const uint8_t* prop_rgb;   // [N][NPROP][3] cube albedo
+  float geom_rgb[NG][3];     // albedo of the static geoms (cube entries unused)
+  float cam_pos[3], cam_mat[9];  // camera frame -> world, row-major (MuJoCo: looks along -z, y up)
+  float fy;                  // focal length in pixels: 0.5 * height / tan(fovy / 2)
+  float light_pos[3];        // positional scene light (arena.xml)
+  float ambient, head_diffuse, light_diffuse;
+  float checker[2][3], checker_size;  // ground plane (geom type 0) checker colours / square size [m]
+  float zfar;                // depth written where nothing is hit
+  uint8_t* rgb;              // [N][H][W][3] or null
+  float* depth;              // [N][H][W] or null
+  uint8_t* seg;              // [N][H][W] geom index, 255 = background, or null
+  const uint8_t* env_mask;   // [N] or null
 };
 
 }  // namespace mre

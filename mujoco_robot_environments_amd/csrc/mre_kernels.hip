@@ -713,6 +713,17 @@ MRE_DEV void step_body(const StepArgs& a, Sm& s) {
       if (!arm_converged && a.status != nullptr) a.status[env] |= 1u;
     }
   }
+  if (a.geoms != nullptr && l < NG) {
+    float p[3], R[9], size[3], rb;
+    geom_pose(M, s, l, p, R, size, &rb);
+    float* o = a.geoms + ((size_t)env * NG + l) * 16;
+    const int pid = M->geom_propid[l];
+    const bool active = pid < 0 || pid < s.nprops;
+    for (int k = 0; k < 3; k++) o[k] = p[k];
+    for (int k = 0; k < 9; k++) o[3 + k] = R[k];
+    for (int k = 0; k < 3; k++) o[12 + k] = size[k];
+    o[15] = active ? (float)M->geom_type[l] : -1.f;  // -1: cube slot not in use
+  }
   if (a.sites != nullptr) {
     float* o = a.sites + (size_t)env * 16;
     if (l < 3) o[l] = s.site_xpos[M->tcp_site][l];

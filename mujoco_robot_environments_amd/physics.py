@@ -247,6 +247,30 @@ class BatchedPhysics:
         return st
 
     # ---------------------------------------------------------- measurement
+    # ------------------------------------------------------------------ camera
+    def set_render_colours(self, prop_rgb=None, geom_rgb=None) -> None:
+        """prop_rgb [N, 4, 3] uint8 cube albedo; geom_rgb [16, 3] float albedo of the static geoms."""
+        p = None if prop_rgb is None else np.ascontiguousarray(prop_rgb, np.uint8).reshape(self.num_envs, MRE_MAX_PROPS, 3)
+        g = None if geom_rgb is None else np.ascontiguousarray(geom_rgb, np.float32).reshape(16, 3)
+        check(_lib.lib().mre_set_render_colours(self._h, _ptr(p), _ptr(g)), "mre_set_render_colours")
+
+    def render(self, cam_pos, cam_mat, fovy: float, height: int, width: int, rgb: bool = True, depth: bool = True,
+               seg: bool = True, mask=None):
+        """Overhead camera images of the current state of every env (mre_render) as CUDA tensors:
+        rgb uint8 [N, H, W, 3], depth float32 [N, H, W], seg uint8 [N, H, W] (255 = background);
+        entries not asked for are None."""
+        n = self.num_envs
+        t_rgb = torch.empty((n, height, width, 3), dtype=torch.uint8, device=self.device) if rgb else None
+        t_depth = torch.empty((n, height, width), dtype=torch.float32, device=self.device) if depth else None
+        t_seg = torch.empty((n, height, width), dtype=torch.uint8, device=self.device) if seg else None
+        cp = np.ascontiguousarray(cam_pos, np.float32).reshape(3)
+        cm = np.ascontiguousarray(cam_mat, np.float32).reshape(9)
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        check(_lib.lib().mre_render(self._h, _ptr(cp), _ptr(cm), float(fovy), int(height), int(width),
+                                    _ptr(t_rgb), _ptr(t_depth), _ptr(t_seg), _ptr(m)), "mre_render")
+        self.sync()
+        return t_rgb, t_depth, t_seg
+
     def set_fallback(self, enabled: bool = True) -> None:
         """Capacity fallback (include/mre.h): on by default; off pins every env to the compact kernel."""
         check(_lib.lib().mre_set_fallback(self._h, int(enabled)), "mre_set_fallback")

@@ -1,0 +1,95 @@
+"""CPU oracle of the batched overhead camera (csrc/mre_render.hip) -- TEST INFRASTRUCTURE ONLY.
+
+Independent restatement in numpy fp64: world-space ray casting of every pixel against every geom
+(no screen rectangles, no per-geom frames shared with the kernel), geom poses from the model's own
+forward kinematics (model/compile.py), the same documented shading formula.  The reference renders
+with mujoco.Renderer (tasks/rearrangement.py:254-280, 460-478), which is absent here, so image
+parity with the reference is UNPINNED; depth and segmentation are determined by geometry alone
+(pinhole camera of tasks/rearrangement.py:480-494) and are what the parity tests lean on."""
+from __future__ import annotations
+
+import numpy as np
+
+from mujoco_robot_environments_amd.model import compile as MC
+
+LIGHT_POS = np.array([0.7, 0.0, 1.6])          # arena.xml:18
+AMBIENT, HEAD_DIFFUSE, LIGHT_DIFFUSE = 0.1, 0.4, 0.7
+CHECKER = np.array([[0.2, 0.3, 0.4], [0.1, 0.2, 0.3]])
+CHECKER_SIZE = 0.1
+ZFAR = 100.0
+NEAR = 0.01
+
+
+def geom_poses(A, qpos, nprops, half_sizes):
+    """World pose of the 16 geoms: (pos [16,3], mat [16,3,3] geom->world, size [16,3], type [16])."""
+    xpos, xquat = MC.forward_kinematics(A, np.asarray(qpos, np.float64))
+    ng = len(A["geom_type"])
+    pos = np.zeros((ng, 3)); mat = np.zeros((ng, 3, 3)); size = np.zeros((ng, 3)); typ = np.zeros(ng, int)
+    for g in range(ng):
+        b = int(A["geom_bodyid"][g])
+        pos[g] = xpos[b] + MC.qrot(xquat[b], A["geom_pos"][g])
+        mat[g] = MC.q2m(MC.qmul(xquat[b], A["geom_quat"][g]))
+        pid = int(A["geom_propid"][g])
+        size[g] = half_sizes[pid] if pid >= 0 else A["geom_size"][g]
+        typ[g] = -1 if (pid >= 0 and pid >= nprops) else int(A["geom_type"][g])
+    return pos, mat, size, typ
+
+
+def render(A, qpos, nprops, half_sizes, prop_rgb, geom_rgb, cam_pos, cam_mat, fovy, height, width):
+    """-> rgb uint8 [H,W,3], depth float64 [H,W], seg int [H,W] (255 background)."""
+    pos, mat, size, typ = geom_poses(A, qpos, nprops, half_sizes)
+    cam_pos = np.asarray(cam_pos, np.float64); Rc = np.asarray(cam_mat, np.float64).reshape(3, 3)
+    f = 0.5 * height / np.tan(np.deg2rad(fovy) / 2)
+    cx, cy = 0.5 * (width - 1), 0.5 * (height - 1)
+    u, v = np.meshgrid(np.arange(width), np.arange(height))
+    dc = np.stack([(u - cx) / f, -(v - cy) / f, -np.ones_like(u, float)], axis=-1)   # camera frame
+    dw = dc @ Rc.T                                                                    # world frame
+    best = np.full((height, width), ZFAR); seg = np.full((height, width), 255, int)
+    normal = np.zeros((height, width, 3))
+    for g in range(len(typ)):
+        if typ[g] < 0:
+            continue
+        R = mat[g]
+        o = (cam_pos - pos[g]) @ R          # camera in geom frame
+        d = dw @ R                          # rays in geom frame
+        with np.errstate(divide="ignore", invalid="ignore"):
+            if typ[g] == 0:
+                t = np.where(d[..., 2] < 0, -o[2] / d[..., 2], np.inf)
+                n_loc = np.zeros_like(d); n_loc[..., 2] = 1.0
+            else:
+                t1 = (-size[g] - o) / d; t2 = (size[g] - o) / d
+                tmin = np.minimum(t1, t2); tmax = np.maximum(t1, t2)
+                tn = tmin.max(axis=-1); tf = tmax.min(axis=-1)
+                t = np.where((tn <= tf) & (tn >= NEAR), tn, np.inf)
+                ax = tmin.argmax(axis=-1)
+                n_loc = np.zeros_like(d)
+                np.put_along_axis(n_loc, ax[..., None], -np.sign(np.take_along_axis(d, ax[..., None], -1)), -1)
+        hit = (t > NEAR) & (t < best)
+        best = np.where(hit, t, best); seg = np.where(hit, g, seg)
+        normal = np.where(hit[..., None], n_loc @ R.T, normal)
+    # shading
+    rgb = np.zeros((height, width, 3))
+    rgb[:] = [0.4, 0.6, 0.8]
+    hitm = seg != 255
+    p = cam_pos + best[..., None] * dw
+    dn = dw / np.linalg.norm(dw, axis=-1, keepdims=True)
+    cosv = np.abs((normal * dn).sum(-1))
+    lv = LIGHT_POS - p
+    lv /= np.linalg.norm(lv, axis=-1, keepdims=True)
+    cl = np.maximum(0.0, (normal * lv).sum(-1))
+    inten = AMBIENT + HEAD_DIFFUSE * cosv + LIGHT_DIFFUSE * cl
+    alb = np.zeros((height, width, 3))
+    ng = len(typ)
+    for g in range(ng):
+        m = seg == g
+        if not m.any():
+            continue
+        pid = g - (ng - 4)
+        if typ[g] == 0:
+            loc = (p[m] - pos[g]) @ mat[g]
+            par = (np.floor(loc[:, 0] / CHECKER_SIZE) + np.floor(loc[:, 1] / CHECKER_SIZE)).astype(int) & 1
+            alb[m] = CHECKER[par]
+        else:
+            alb[m] = (np.asarray(prop_rgb[pid], float) / 255.0) if pid >= 0 else geom_rgb[g]
+    rgb[hitm] = np.minimum(1.0, alb[hitm] * inten[hitm][:, None])
+    return (rgb * 255.0 + 0.5).astype(np.uint8), best, seg

@@ -1,0 +1,61 @@
+"""CPU known-answer tests of the camera oracle (oracle/render_oracle.py) that the GPU renderer is
+checked against: pinhole geometry of tasks/rearrangement.py:480-548 (intrinsics / extrinsics /
+world_2_pixel) and analytic depths of the scene (overhead camera at z = 1.3 looking straight down)."""
+import numpy as np
+import pytest
+
+from mujoco_robot_environments_amd.model import compile as MC
+from oracle import render_oracle as RO
+
+CAM_POS = np.array([0.7, 0.0, 1.3])
+CAM_QUAT = np.array([0.707, 0.0, 0.0, -0.707])
+H, W, FOVY = 120, 160, 61.0
+
+
+@pytest.fixture(scope="module")
+def scene():
+    A = MC.compile_scene()
+    q = np.array(A["qpos0"], float)[:43].copy()
+    q[:7] = A["home_qpos"]
+    cubes = [(0.6, 0.1, 0.4155), (0.8, -0.2, 0.4155)]
+    for p, c in enumerate(cubes):
+        q[15 + 7 * p: 22 + 7 * p] = [*c, 1, 0, 0, 0]
+    Rc = MC.q2m(CAM_QUAT / np.linalg.norm(CAM_QUAT))
+    half = np.full((4, 3), 0.0155)
+    prop_rgb = np.array([[0, 255, 0], [0, 0, 255], [255, 0, 0], [255, 255, 0]], np.uint8)
+    geom_rgb = np.full((16, 3), 0.5)
+    rgb, depth, seg = RO.render(A, q, 2, half, prop_rgb, geom_rgb, CAM_POS, Rc, FOVY, H, W)
+    return A, q, Rc, rgb, depth, seg, cubes
+
+
+def _pixel(Rc, xyz):
+    f = 0.5 * H / np.tan(np.deg2rad(FOVY) / 2)
+    c = Rc.T @ (np.asarray(xyz) - CAM_POS)
+    return (W - 1) / 2 + f * c[0] / -c[2], (H - 1) / 2 - f * c[1] / -c[2]
+
+
+def test_table_depth_and_segmentation(scene):
+    A, q, Rc, rgb, depth, seg, cubes = scene
+    u, v = _pixel(Rc, [0.9, 0.3, 0.4])  # a free spot of the table top
+    assert seg[int(round(v)), int(round(u))] == 1
+    assert abs(depth[int(round(v)), int(round(u))] - 0.9) < 1e-9  # camera z 1.3 - table top 0.4
+
+
+def test_cubes_are_seen_where_the_pinhole_model_puts_them(scene):
+    A, q, Rc, rgb, depth, seg, cubes = scene
+    for p, c in enumerate(cubes):
+        u, v = _pixel(Rc, c)
+        r, col = int(round(v)), int(round(u))
+        assert seg[r, col] == 12 + p
+        assert abs(depth[r, col] - (1.3 - (c[2] + 0.0155))) < 1e-9  # top face
+        # the cube's colour dominates its pixel (green / blue albedo, lit from above)
+        assert rgb[r, col].argmax() == (1 if p == 0 else 2)
+    assert not (seg == 14).any() and not (seg == 15).any()  # cube slots 2, 3 are not in use
+
+
+def test_every_pixel_is_hit_and_ground_is_deeper_than_table(scene):
+    A, q, Rc, rgb, depth, seg, cubes = scene
+    assert (seg != 255).all()           # looking down: ground plane everywhere behind
+    if (seg == 0).any():
+        assert np.allclose(depth[seg == 0], 1.3)
+    assert depth[seg == 1].max() < 0.9 + 1e-9
