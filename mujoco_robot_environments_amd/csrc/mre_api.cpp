@@ -596,6 +596,17 @@ extern "C" int mre_render(mre_env* e, const float* cam_pos, const float* cam_mat
   StepArgs a;
   fill_args(e, a);
   a.nsteps = 0; a.trace = nullptr; a.env_order = nullptr; a.env_mask = dmask; a.geoms = e->geoms;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (e->profiling) {  // same event bracket as launch_step: tools/bench_render.py times the camera with it
+    if (e->events_used == e->events.size()) {
+      hipEvent_t x, y;
+      HIPCHK(hipEventCreate(&x)); HIPCHK(hipEventCreate(&y));
+      e->events.emplace_back(x, y);
+    }
+    e0 = e->events[e->events_used].first; e1 = e->events[e->events_used].second;
+    e->events_used++;
+    HIPCHK(hipEventRecord(e0, e->stream));
+  }
   mre_launch_step(&a, e->stream);
   HIPCHK(hipGetLastError());
   RenderArgs r;
@@ -620,6 +631,7 @@ extern "C" int mre_render(mre_env* e, const float* cam_pos, const float* cam_mat
   if (row_groups > 60) row_groups = 60;
   mre_launch_render(&r, row_groups, e->stream);
   HIPCHK(hipGetLastError());
+  if (e1) HIPCHK(hipEventRecord(e1, e->stream));
   return MRE_OK;
 }
 

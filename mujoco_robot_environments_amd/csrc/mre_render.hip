@@ -28,7 +28,7 @@ struct GeomView {
   float o[3];      // camera position in the geom frame
   float G[9];      // geom-frame ray direction = G * (x, y, -1), row-major
   float size[3];
-  float Rw[9];     // geom -> world rotation (normals)
+  float Lg[3];     // scene light position minus camera position, in the geom frame
   float rgb[3];
   int type;        // 0 plane, > 0 box, -1 unused
   int x0, x1, y0, y1;  // inclusive screen rectangle
@@ -41,6 +41,7 @@ __global__ __launch_bounds__(RENDER_THREADS) void k_render(RenderArgs a) {
   if (env >= a.N) return;
   if (a.env_mask != nullptr && a.env_mask[env] == 0) return;
   const float cx = 0.5f * (a.width - 1), cy = 0.5f * (a.height - 1), f = a.fy, inv_f = 1.0f / a.fy;
+  const float inv_checker = 1.0f / a.checker_size;
   // ---- per-geom view data (thread = geom) and projected corners (thread = geom * 8 + corner)
   if (t < NG) {
     rect[t][0] = a.width; rect[t][1] = -1; rect[t][2] = a.height; rect[t][3] = -1;
@@ -54,7 +55,11 @@ __global__ __launch_bounds__(RENDER_THREADS) void k_render(RenderArgs a) {
         v.G[3 * i + j] = g[3 + i] * a.cam_mat[j] + g[6 + i] * a.cam_mat[3 + j] + g[9 + i] * a.cam_mat[6 + j];
       v.size[i] = g[12 + i];
     }
-    for (int k = 0; k < 9; k++) v.Rw[k] = g[3 + k];
+    {
+      float lr[3];
+      for (int k = 0; k < 3; k++) lr[k] = a.light_pos[k] - a.cam_pos[k];
+      for (int i = 0; i < 3; i++) v.Lg[i] = g[3 + i] * lr[0] + g[6 + i] * lr[1] + g[9 + i] * lr[2];
+    }
     v.type = (int)g[15];
     const int pid = t - (NG - NPROP);  // cubes are the last NPROP geoms
     for (int k = 0; k < 3; k++)
@@ -99,38 +104,61 @@ __global__ __launch_bounds__(RENDER_THREADS) void k_render(RenderArgs a) {
     int best_g[4], best_ax[4];
 #pragma unroll
     for (int p = 0; p < 4; p++) { best_t[p] = a.zfar; best_g[p] = 255; best_ax[p] = 0; cosv[p] = 0.f; }
-    for (int g = 0; g < NG; g++) {
+    // geoms whose screen rectangle reaches this iteration's rows (wave-uniform bit mask: every
+    // wave evaluates the 16 tests in its first 16 lanes), then only those are visited
+    const int wl = t & 63;
+    const int gq = wl < NG ? wl : 0;
+    const bool rows_hit = wl < NG && gv[gq].type >= 0 && gv[gq].y0 <= row0 + rows_per_iter - 1 && gv[gq].y1 >= row0;
+    unsigned long long todo = __ballot(rows_hit);
+    while (todo != 0ull) {
+      const int g = __builtin_ctzll(todo);
+      todo &= todo - 1ull;
       const GeomView& v = gv[g];
-      if (v.type < 0 || row < v.y0 || row > v.y1 || u0 + 3 < v.x0 || u0 > v.x1) continue;
+      if (row < v.y0 || row > v.y1 || u0 + 3 < v.x0 || u0 > v.x1) continue;
+      // ray direction in the geom frame is affine in the pixel column: d = G[:,0] x + e
+      const float e0 = v.G[1] * y - v.G[2], e1 = v.G[4] * y - v.G[5], e2 = v.G[7] * y - v.G[8];
 #pragma unroll
       for (int p = 0; p < 4; p++) {
         const float x = (u0 + p - cx) * inv_f;
-        const float d0 = v.G[0] * x + v.G[1] * y - v.G[2];
-        const float d1 = v.G[3] * x + v.G[4] * y - v.G[5];
-        const float d2 = v.G[6] * x + v.G[7] * y - v.G[8];
+        const float d0 = v.G[0] * x + e0, d1 = v.G[3] * x + e1, d2 = v.G[6] * x + e2;
         float th, cs;
         int ax;
         if (v.type == 0) {  // plane z = 0 of the geom frame, visible from above
           if (!(d2 < 0.f)) continue;
-          th = -v.o[2] / d2;
-          ax = 2; cs = -d2;
+          th = -v.o[2] * __builtin_amdgcn_rcpf(d2);
+          ax = 2; cs = d2;
         } else {
-          const float i0 = 1.0f / d0, i1 = 1.0f / d1, i2 = 1.0f / d2;
-          const float a0 = (-v.size[0] - v.o[0]) * i0, b0 = (v.size[0] - v.o[0]) * i0;
-          const float a1 = (-v.size[1] - v.o[1]) * i1, b1 = (v.size[1] - v.o[1]) * i1;
-          const float a2 = (-v.size[2] - v.o[2]) * i2, b2 = (v.size[2] - v.o[2]) * i2;
-          const float n0 = fminf(a0, b0), n1 = fminf(a1, b1), n2 = fminf(a2, b2);
-          const float tn = fmaxf(fmaxf(n0, n1), n2);
-          const float tf = fminf(fminf(fmaxf(a0, b0), fmaxf(a1, b1)), fmaxf(a2, b2));
-          if (!(tn <= tf) || tn < RENDER_NEAR) continue;
-          th = tn;
-          ax = (n0 >= n1 && n0 >= n2) ? 0 : (n1 >= n2 ? 1 : 2);
-          cs = fabsf(ax == 0 ? d0 : (ax == 1 ? d1 : d2));
+          // the ray enters a box through a face the camera is in front of: for each axis whose slab
+          // the camera is outside of (wave-uniform per geom) intersect that one face plane and keep
+          // the hit if it lies within the face.  (Seen from above the table is ONE such axis.)
+          const float dd3[3] = {d0, d1, d2};
+          bool found = false;
+          th = 0.f; ax = 0; cs = 0.f;
+#pragma unroll
+          for (int k = 0; k < 3; k++) {
+            if (fabsf(v.o[k]) <= v.size[k]) continue;
+            const float face = v.o[k] > 0.f ? v.size[k] : -v.size[k];
+            const float tk = (face - v.o[k]) * __builtin_amdgcn_rcpf(dd3[k]);
+            const int k1 = (k + 1) % 3, k2 = (k + 2) % 3;
+            const float p1 = v.o[k1] + tk * dd3[k1], p2 = v.o[k2] + tk * dd3[k2];
+            const bool ok = tk > RENDER_NEAR && fabsf(p1) <= v.size[k1] && fabsf(p2) <= v.size[k2];
+            if (ok && !found) { found = true; th = tk; ax = k; cs = dd3[k]; }
+          }
+          if (!found) continue;
         }
         if (th > RENDER_NEAR && th < best_t[p]) { best_t[p] = th; best_g[p] = g; best_ax[p] = ax; cosv[p] = cs; }
       }
     }
-    // ---- shade the winning surface and store
+    // ---- shade the winning surface and store.  With n the entry face's normal (geom axis ax, turned
+    // towards the camera) and ds the ray direction's component along that axis (kept from the hit):
+    //   cos(view)  = |ds| / |d|
+    //   n.(L - hit) = sgn * (Lg[ax] - t ds),   |L - hit|^2 = |L-c|^2 - 2 t (L-c).d + t^2 |d|^2
+    float lc[3], l2 = 0.f;
+    for (int j = 0; j < 3; j++) {
+      lc[j] = 0.f;
+      for (int r = 0; r < 3; r++) lc[j] += a.cam_mat[3 * r + j] * (a.light_pos[r] - a.cam_pos[r]);
+      l2 += (a.light_pos[j] - a.cam_pos[j]) * (a.light_pos[j] - a.cam_pos[j]);
+    }
     uint32_t rgbw[3] = {0u, 0u, 0u};
     uint32_t segw = 0u;
 #pragma unroll
@@ -139,23 +167,18 @@ __global__ __launch_bounds__(RENDER_THREADS) void k_render(RenderArgs a) {
       if (best_g[p] != 255) {
         const GeomView& v = gv[best_g[p]];
         const float x = (u0 + p - cx) * inv_f;
-        const float inv_len = rsqrtf(x * x + y * y + 1.0f);
-        // world ray direction and hit point, world normal of the entry face (towards the camera)
-        float dw[3], hit[3], nw[3], lv[3];
-        for (int i = 0; i < 3; i++) dw[i] = a.cam_mat[3 * i] * x + a.cam_mat[3 * i + 1] * y - a.cam_mat[3 * i + 2];
-        for (int i = 0; i < 3; i++) hit[i] = a.cam_pos[i] + best_t[p] * dw[i];
-        for (int i = 0; i < 3; i++) nw[i] = v.Rw[3 * i + best_ax[p]];
-        const float facing = nw[0] * dw[0] + nw[1] * dw[1] + nw[2] * dw[2];
-        const float sgn = facing > 0.f ? -1.f : 1.f;
-        for (int i = 0; i < 3; i++) lv[i] = a.light_pos[i] - hit[i];
-        const float ll = rsqrtf(lv[0] * lv[0] + lv[1] * lv[1] + lv[2] * lv[2]);
-        const float cl = fmaxf(0.f, sgn * (nw[0] * lv[0] + nw[1] * lv[1] + nw[2] * lv[2]) * ll);
-        const float inten = a.ambient + a.head_diffuse * (cosv[p] * inv_len) + a.light_diffuse * cl;
+        const float dd = x * x + y * y + 1.0f, th = best_t[p], ds = cosv[p];
+        const float cview = fabsf(ds) * rsqrtf(dd);
+        const float sgn = ds > 0.f ? -1.f : 1.f;
+        const float ldd = lc[0] * x + lc[1] * y - lc[2];
+        const float lv2 = l2 - 2.f * th * ldd + th * th * dd;
+        const float cl = fmaxf(0.f, sgn * (v.Lg[best_ax[p]] - th * ds)) * rsqrtf(lv2);
+        const float inten = a.ambient + a.head_diffuse * cview + a.light_diffuse * cl;
         float alb[3] = {v.rgb[0], v.rgb[1], v.rgb[2]};
         if (v.type == 0) {  // ground checker in the plane's own xy
-          const float px = v.o[0] + best_t[p] * (v.G[0] * x + v.G[1] * y - v.G[2]);
-          const float py = v.o[1] + best_t[p] * (v.G[3] * x + v.G[4] * y - v.G[5]);
-          const int par = ((int)floorf(px / a.checker_size) + (int)floorf(py / a.checker_size)) & 1;
+          const float px = v.o[0] + th * (v.G[0] * x + v.G[1] * y - v.G[2]);
+          const float py = v.o[1] + th * (v.G[3] * x + v.G[4] * y - v.G[5]);
+          const int par = ((int)floorf(px * inv_checker) + (int)floorf(py * inv_checker)) & 1;
           for (int i = 0; i < 3; i++) alb[i] = a.checker[par][i];
         }
         for (int i = 0; i < 3; i++) col[i] = fminf(1.f, alb[i] * inten);
