@@ -56,6 +56,11 @@ PRE_PICK_HEIGHT = 0.9   # :364,408
 PROP_GEOM_ID0 = 12      # geom ids of prop_0..3 in the compiled scene
 
 PropsLabels = collections.namedtuple("PropsLabels", ["shape", "colour", "texture"])
+# environment/props.py:13-20
+COLOURS = {"red": (1.0, 0.0, 0.0), "green": (0.0, 1.0, 0.0), "blue": (0.0, 0.0, 1.0),
+           "yellow": (1.0, 1.0, 0.0), "cyan": (0.0, 1.0, 1.0), "magenta": (1.0, 0.0, 1.0)}
+COLOUR_NOISE = 0.1      # environment/props.py:274,290
+OVERHEAD = "overhead_camera/overhead_camera"
 
 
 def mat2quat(mat3x3) -> np.ndarray:
@@ -72,7 +77,7 @@ class BatchedRearrangementEnv:
     """num_envs independent RearrangementEnv instances stepped in lockstep on one GPU."""
 
     def __init__(self, cfg: Optional[Cfg] = None, num_envs: int = 1, viewer=None, device: int = 0,
-                 seed: Optional[int] = None, env_id_offset: int = 0, env_ids=None):
+                 seed: Optional[int] = None, env_id_offset: int = 0, env_ids=None, render: bool = False):
         self._cfg = cfg if cfg is not None else DEFAULT_CONFIG
         cfg = self._cfg
         self.num_envs = int(num_envs)
@@ -114,6 +119,20 @@ class BatchedRearrangementEnv:
                                                            mat=_compile.q2m(q), fovy=float(cam.fovy))
             if cam.name == "overhead_camera":
                 self.overhead_camera_height, self.overhead_camera_width = int(cam.height), int(cam.width)
+        # ---- overhead camera images (mre_render): cube albedo = colour + noise (props.py:288-291),
+        # table grey (tasks/rearrangement.py:91), robot hulls dark
+        self.render_observations = bool(render)
+        un = rng.uniform(self.seed ^ 0xC0FFEE, self.env_ids, [0], 12)[0].reshape(self.num_envs, 4, 3)
+        self.prop_rgb = np.zeros((self.num_envs, 4, 3), np.uint8)
+        self.prop_rgba = np.ones((self.num_envs, 4, 4))
+        for i in range(self.num_envs):
+            for p, c in enumerate(self.prop_colours[i]):
+                rgbf = np.clip(np.asarray(COLOURS.get(c, (0.5, 0.5, 0.5))) + COLOUR_NOISE * (2 * un[i, p] - 1), 0.0, 1.0)
+                self.prop_rgba[i, p, :3] = rgbf
+                self.prop_rgb[i, p] = np.round(rgbf * 255)
+        geom_rgb = np.full((16, 3), 0.25, np.float32)
+        geom_rgb[1] = 0.5
+        self._physics.set_render_colours(self.prop_rgb, geom_rgb)
         self._reset_count = 0
         self._place_count = 0
         self._place_counts = np.zeros(self.num_envs, np.int64)  # prop_place calls per env (RNG key)
@@ -138,13 +157,43 @@ class BatchedRearrangementEnv:
         depth = np.broadcast_to(np.zeros((1, 1, 1), np.float32), (n, h, w))
         return {"overhead_camera/rgb": rgb, "overhead_camera/depth": depth}
 
+    def render(self, rgb: bool = True, depth: bool = True, seg: bool = True, camera: str = OVERHEAD):
+        """Overhead camera images of every env's current state as CUDA tensors (rgb uint8 [N,H,W,3],
+        depth float32 [N,H,W], seg uint8 [N,H,W]: 12 + p = cube p, 1 table, 2..11 robot, 255 nothing):
+        the batched form of the reference's renderer / depth_renderer / seg_renderer passes
+        (tasks/rearrangement.py:254-280, 460-478)."""
+        cam = self._cameras[camera]
+        return self._physics.render(cam["pos"], cam["mat"], cam["fovy"], self.overhead_camera_height,
+                                    self.overhead_camera_width, rgb=rgb, depth=depth, seg=seg)
+
+    def prop_bboxes(self, seg=None) -> np.ndarray:
+        """PASCAL-VOC boxes [N, 4 cubes, (xmin, ymin, xmax, ymax)] of the VISIBLE pixels of every cube
+        in the segmentation image (get_bbox, tasks/rearrangement.py:254-268); -1 where a cube is not
+        in view or not in use."""
+        import torch
+        if seg is None:
+            seg = self.render(rgb=False, depth=False)[2]
+        n, h, w = seg.shape
+        out = torch.full((n, 4, 4), -1, dtype=torch.int64, device=seg.device)
+        for p in range(4):
+            m = seg == (PROP_GEOM_ID0 + p)
+            cols, rows = m.any(dim=1), m.any(dim=2)
+            vis = cols.any(dim=1)
+            box = torch.stack([cols.int().argmax(dim=1), rows.int().argmax(dim=1),
+                               w - 1 - cols.flip(1).int().argmax(dim=1), h - 1 - rows.flip(1).int().argmax(dim=1)], dim=1)
+            out[:, p] = torch.where(vis[:, None], box, out[:, p])
+        return out.cpu().numpy()
+
     def _compute_observation(self):
-        return self._zeros_obs()
+        if not self.render_observations:
+            return self._zeros_obs()
+        rgb, depth, _ = self.render(seg=False)
+        return {"overhead_camera/rgb": rgb, "overhead_camera/depth": depth}
 
     def observation_spec(self):
         h, w = self.overhead_camera_height, self.overhead_camera_width
         return {"overhead_camera/depth": _Array(shape=(h, w), dtype=np.float32),
-                "overhead_camera/rgb": _Array(shape=(h, w, 3), dtype=np.float32)}
+                "overhead_camera/rgb": _Array(shape=(h, w, 3), dtype=np.float32)}  # (sic: :448; images are uint8)
 
     def action_spec(self) -> Dict[str, _Array]:
         return {"pose": _Array(shape=(7,), dtype=np.float64),
@@ -272,15 +321,25 @@ class BatchedRearrangementEnv:
         out = np.round(img).astype(np.int32)
         return out[0] if np.asarray(coords).ndim == 1 else out
 
-    def pixel_2_world(self, camera_name, coords):
-        """tasks/rearrangement.py:505-531 with the depth taken from the table plane
-        (rendering is stubbed): intersect the pixel ray with z = table top."""
+    def pixel_2_world(self, camera_name, coords, env: int = 0):
+        """tasks/rearrangement.py:505-531: the pixel's rendered depth pushed back through the pinhole
+        model (env selects the image of a batch).  Without rendering the depth is that of the table
+        plane: the pixel ray intersected with z = table top."""
         K = self._get_camera_intrinsics(camera_name, self.overhead_camera_height, self.overhead_camera_width)
         E = self._get_camera_extrinsics(camera_name)
-        ray_c = np.linalg.inv(K) @ np.concatenate([np.asarray(coords, np.float64), np.ones(1)])
+        coords = np.asarray(coords, np.float64)
+        ray_c = np.linalg.inv(K) @ np.concatenate([coords, np.ones(1)])
         cam = self._cameras[camera_name]
-        d_w = cam["mat"] @ (-ray_c)  # camera looks along -z; scale by depth below
-        depth = (TABLE_TOP_Z - cam["pos"][2]) / d_w[2]
+        if self.render_observations:
+            rc = np.round(coords).astype(np.int32)  # coords_rounded (:509)
+            mask = np.zeros(self.num_envs, np.uint8)
+            mask[env] = 1
+            _, dimg, _ = self._physics.render(cam["pos"], cam["mat"], cam["fovy"], self.overhead_camera_height,
+                                              self.overhead_camera_width, rgb=False, seg=False, mask=mask)
+            depth = float(dimg[env, rc[1], rc[0]])
+        else:
+            d_w = cam["mat"] @ (-ray_c)  # camera looks along -z
+            depth = (TABLE_TOP_Z - cam["pos"][2]) / d_w[2]
         camc = np.concatenate([ray_c * (-depth), np.ones(1)])
         w = np.linalg.inv(E) @ camc
         return w[:3] / w[3]
@@ -299,10 +358,14 @@ class BatchedRearrangementEnv:
                                "qx": quat[0], "qy": quat[1], "qz": quat[2], "qw": quat[3]}}
 
     # ------------------------------------------------------------ demo logic
-    def props_info_env(self, i: int, prop_pose: Optional[np.ndarray] = None) -> dict:
-        """props_info of env i (tasks/rearrangement.py:227-295); keys are geom ids."""
+    def props_info_env(self, i: int, prop_pose: Optional[np.ndarray] = None, bboxes: Optional[np.ndarray] = None) -> dict:
+        """props_info of env i (tasks/rearrangement.py:227-295); keys are geom ids.  With rendering
+        enabled the bounding boxes come from the segmentation image like the reference's (visible
+        pixels, empty array when out of view); otherwise from the projected cube corners."""
         if prop_pose is None:
             prop_pose = self._physics.sites()[2]
+        if bboxes is None and self.render_observations:
+            bboxes = self.prop_bboxes()
         info = {}
         for p in range(int(self.nprops[i])):
             pos = prop_pose[i, p, :3].astype(np.float64)
@@ -312,10 +375,12 @@ class BatchedRearrangementEnv:
             corners = np.array([[sx, sy, sz] for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)]) * half
             px = self.world_2_pixel("overhead_camera/overhead_camera", pos + corners @ mat.T)
             bbox = np.array([px[:, 0].min(), px[:, 1].min(), px[:, 0].max(), px[:, 1].max()])
+            if bboxes is not None:
+                bbox = bboxes[i, p] if bboxes[i, p, 0] >= 0 else np.array([])
             info[PROP_GEOM_ID0 + p] = {
                 "prop_name": f"prop_{p}", "position": pos,
                 "orientation": R.from_matrix(mat).as_quat(),  # scipy (x,y,z,w) like the reference
-                "rgba": None, "bbox": bbox,
+                "rgba": self.prop_rgba[i, p].copy(), "bbox": bbox,
                 "labels": PropsLabels("cube", self.prop_colours[i][p], "plain")}
         return info
 
@@ -402,12 +467,12 @@ class RearrangementEnv(BatchedRearrangementEnv):
     """Batch of one with the reference's shapes and error behaviour
     (signature: tasks/rearrangement.py:54-58)."""
 
-    def __init__(self, viewer=None, cfg: Optional[Cfg] = None, device: int = 0):
-        super().__init__(cfg=cfg, num_envs=1, viewer=viewer, device=device)
+    def __init__(self, viewer=None, cfg: Optional[Cfg] = None, device: int = 0, render: bool = True):
+        super().__init__(cfg=cfg, num_envs=1, viewer=viewer, device=device, render=render)
 
     def _compute_observation(self):
-        o = self._zeros_obs()
-        return {k: v[0] for k, v in o.items()}
+        o = super()._compute_observation()
+        return {k: (v[0].cpu().numpy() if hasattr(v, "cpu") else v[0]) for k, v in o.items()}
 
     def _phase(self, name, duration):
         conv = super()._phase(name, duration)
