@@ -427,18 +427,18 @@ static int create_buffers(mre_env* e, int num_envs, int device_id) {
   HIPCHK(hipMalloc(&e->sv_qacc_ws, N * NVP * 4)); HIPCHK(hipMalloc(&e->sv_ctrl, N * NU * 4));
   HIPCHK(hipMalloc(&e->sv_status, N * 4)); HIPCHK(hipMalloc(&e->launch_info, N * 16));
   HIPCHK(hipHostMalloc((void**)&e->h_launch_info, N * 16, hipHostMallocDefault));
-  HIPCHK(hipMemset(e->d_large, 0, N));
+  HIPCHK(hipMemsetAsync(e->d_large, 0, N, e->stream));
   e->h_large.assign(N, 0); e->h_rerun.assign(N, 0);
   if (const char* fb = getenv("MRE_NO_FALLBACK")) e->fallback = atoi(fb) == 0;  // profiling knob only
   if (const char* fl = getenv("MRE_FORCE_LARGE")) {  // profiling knob only: start every env on the large kernel
     if (atoi(fl) != 0) {
       e->h_large.assign(N, 1); e->n_large = num_envs;
-      HIPCHK(hipMemset(e->d_large, 1, N));
+      HIPCHK(hipMemsetAsync(e->d_large, 1, N, e->stream));
     }
   }
-  HIPCHK(hipMemset(e->status, 0, N * 4)); HIPCHK(hipMemset(e->stats, 0, N * 16));
-  HIPCHK(hipMemset(e->grip_closed, 0, N)); HIPCHK(hipMemset(e->osc_target, 0, N * 64));
-  HIPCHK(hipMemset(e->sites, 0, N * 64));
+  HIPCHK(hipMemsetAsync(e->status, 0, N * 4, e->stream)); HIPCHK(hipMemsetAsync(e->stats, 0, N * 16, e->stream));
+  HIPCHK(hipMemsetAsync(e->grip_closed, 0, N, e->stream)); HIPCHK(hipMemsetAsync(e->osc_target, 0, N * 64, e->stream));
+  HIPCHK(hipMemsetAsync(e->sites, 0, N * 64, e->stream));
   // defaults: 4 cubes of half size 0.0155
   std::vector<int> np(N, NPROP);
   std::vector<float> ps(N * NPROP * 3, 0.0155f);
@@ -449,6 +449,9 @@ static int create_buffers(mre_env* e, int num_envs, int device_id) {
                      5e-3f, 68e-3f, 0};
   HIPCHK(hipMalloc(&e->d_osc, sizeof(OscConfig)));
   HIPCHK(hipMemcpy(e->d_osc, &e->osc, sizeof(OscConfig), hipMemcpyHostToDevice));
+  // (device memsets above are enqueued on the handle's stream: a hipMemset on the null stream is
+  // asynchronous and is NOT ordered against a non-blocking stream)
+  HIPCHK(hipStreamSynchronize(e->stream));
   int rc = mre_reset(e, nullptr);
   if (rc != MRE_OK) return rc;
   return mre_sync(e);
@@ -566,7 +569,7 @@ extern "C" int mre_set_render_colours(mre_env* e, const uint8_t* prop_rgb, const
   const size_t N = (size_t)e->N;
   if (!e->prop_rgb) {
     HIPCHK(hipMalloc(&e->prop_rgb, N * NPROP * 3));
-    HIPCHK(hipMemset(e->prop_rgb, 128, N * NPROP * 3));
+    HIPCHK(hipMemsetAsync(e->prop_rgb, 128, N * NPROP * 3, e->stream));
     for (int g = 0; g < NG; g++) for (int k = 0; k < 3; k++) e->geom_rgb[g][k] = 0.5f;
   }
   if (prop_rgb) { int rc = copy_in(e, e->prop_rgb, prop_rgb, N * NPROP * 3); if (rc) return rc; }
