@@ -343,7 +343,7 @@ MRE_DEV void factor_regs_rows(float (&A)[NMR], lds_float_p dinv) {
   if constexpr (K > 0) factor_regs_rows<K - 1>(A, dinv);
 }
 // src: the matrix (qM, or M - h dF/dv already formed in LD); LD / dinv: factor and 1/D (all LDS)
-MRE_PHASE_FN void factor_robot_regs(const float* src_, float* LD_, float* dinv_) {
+MRE_DEV void factor_robot_regs(const float* src_, float* LD_, float* dinv_) {
   lds_cfloat_p src = (lds_cfloat_p)src_;
   lds_float_p LD = (lds_float_p)LD_, dinv = (lds_float_p)dinv_;
   asm volatile("" : "+v"(src), "+v"(LD), "+v"(dinv));
@@ -533,7 +533,9 @@ MRE_DEV bool smooth_forces(const DevModel* M, Sm& s, int l) {
 }
 
 // ------------------------------------------- mj_implicit (implicitfast) + advance
-MRE_PHASE_FN void integrate(const DevModel* M, Sm& s, int l, bool grip_clamped, unsigned flags) {
+// part 1: MH and the right-hand side; the kernel body then factors MH (factor_robot_regs, inlined
+// there: a kernel has no callee-saved registers to spill) and calls part 2
+MRE_PHASE_FN void integrate_setup(const DevModel* M, Sm& s, int l, bool grip_clamped) {
   const float h = M->timestep;
   if (l < NVP) s.qacc_ws[l] = (l < NV) ? s.qacc[l] : 0.f;
   // MH = M - h*dF/dv restricted to M's pattern (diagonal terms only here)
@@ -551,8 +553,11 @@ MRE_PHASE_FN void integrate(const DevModel* M, Sm& s, int l, bool grip_clamped, 
   }
   if (l < NRV) s.scratch[l] = s.qfrc_smooth[l] + s.qfrc_con[l];
   __syncthreads();
-  factor_robot_regs(s.qLD, s.qLD, s.qLDinv);
-  solve_robot_par(M, s.qLD, s.qLDinv, s.scratch, 0, 1, l);
+}
+
+// part 2 (after the solve of MH x = f, also run from the kernel body): advance velocities and positions
+MRE_PHASE_FN void integrate(const DevModel* M, Sm& s, int l, unsigned flags) {
+  const float h = M->timestep;
   const bool freeze = (flags & F_FREEZE_ROBOT) != 0;
   if (l < NV) {
     const int b = M->dof_body[l];
@@ -666,6 +671,8 @@ MRE_DEV void step_body(const StepArgs& a, Sm& s) {
       collide(M, s, l);
       MRE_STAMP(2);
       assemble_constraints(M, s, l);
+      solve_robot_rows(s, l);
+      assemble_blocks(M, s, l);
       MRE_STAMP(3);
       hw_ncon = max(hw_ncon, s.ncon); hw_nefc = max(hw_nefc, s.nefc); hw_nsched = max(hw_nsched, s.nsched);
       hw_nrrow = max(hw_nrrow, s.nrrow); hw_npp = max(hw_npp, s.npp);
@@ -697,7 +704,10 @@ MRE_DEV void step_body(const StepArgs& a, Sm& s) {
       __syncthreads();
     }
 
-    integrate(M, s, l, clamped, a.flags);
+    integrate_setup(M, s, l, clamped);
+    factor_robot_regs(s.qLD, s.qLD, s.qLDinv);
+    solve_robot_par(M, s.qLD, s.qLDinv, s.scratch, 0, 1, l);
+    integrate(M, s, l, a.flags);
     if (a.trace != nullptr && env < a.trace_nenv && (a.trace_base + step) < a.trace_max) {
       if (l < NQP)
         a.trace[((size_t)(a.trace_base + step) * a.trace_nenv + env) * NQP + l] = s.qpos[l];

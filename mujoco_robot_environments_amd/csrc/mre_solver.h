@@ -371,8 +371,13 @@ MRE_PHASE_FN void assemble_constraints(const DevModel* M, Sm& s, int l) {
     if (i >= 7 + nl && (i - 7 - nl) % 3 == 0) s.blkrec[8 + (i - 7 - nl) / 3][15] = M->pair_friction[s.con_pair[(i - 7 - nl) / 3]][0];
   }
   __syncthreads();
-  // ---- Br = M^-1 Jr'
-  solve_robot_rows(s, l);
+}
+
+// second half of the assembly, after the kernel body has run solve_robot_rows (Br = M^-1 Jr'); the
+// phases do not nest calls, so none of them needs a callee-saved register (= scratch) to keep
+// state across one
+MRE_PHASE_FN void assemble_blocks(const DevModel* M, Sm& s, int l) {
+  const int nefc = s.nefc, nl = s.nl;
   // ---- diagonal blocks of A = J M^-1 J' + R.  Contacts: 3x3 block of the contact's rows.
   // Scalar rows (equality / limit, robot-only) are grouped in consecutive triples whose
   // 3x3 block lets one solver step apply the three sequential scalar updates exactly.
