@@ -124,3 +124,20 @@ def test_run_controller_tick_count_follows_fp64_clock():
                 t += 0.001
             ticks += 1
         assert r.ticks_for(dur) == ticks and abs(ticks - dur / 0.005) <= 1
+
+
+def test_prop_bboxes_from_a_segmentation_image_on_cpu():
+    """get_bbox of the reference (tasks/rearrangement.py:254-268) vectorised over the batch: PASCAL
+    VOC corners of the visible pixels of each cube id, -1 where the id is absent."""
+    import torch
+    from mujoco_robot_environments_amd.tasks.rearrangement import BatchedRearrangementEnv, PROP_GEOM_ID0
+    seg = torch.full((2, 48, 64), 1, dtype=torch.uint8)
+    seg[0, 10:15, 20:31] = PROP_GEOM_ID0          # cube 0: rows 10..14, cols 20..30
+    seg[0, 40:42, 3:5] = PROP_GEOM_ID0 + 2        # cube 2
+    seg[1, 0:1, 63:64] = PROP_GEOM_ID0 + 3        # a single pixel in the corner
+    boxes = BatchedRearrangementEnv.prop_bboxes(None, seg)
+    assert boxes.shape == (2, 4, 4)
+    assert boxes[0, 0].tolist() == [20, 10, 30, 14]
+    assert boxes[0, 2].tolist() == [3, 40, 4, 41]
+    assert boxes[1, 3].tolist() == [63, 0, 63, 0]
+    assert (boxes[0, 1] == -1).all() and (boxes[0, 3] == -1).all() and (boxes[1, :3] == -1).all()
