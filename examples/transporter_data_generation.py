@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """BASELINE.json configs[4]: the reference's data-generation loop
 (mujoco_robot_environments/transporter_network_data_generation.py:97-143) driving thousands of
-RearrangementEnv instances on one MI355X.  Rendering and envlogger/TFDS writing are stubbed
-(out of scope): observations are zero images of the reference shapes and
-the "dataset" is the list of (pick, place) actions with their pixel coordinates.
+RearrangementEnv instances on one MI355X.  envlogger/TFDS writing is stubbed (out of scope,
+SURVEY.md section 8f): the "dataset" is the list of (pick, place) actions with their pixel coordinates; observations are zero images of the
+reference shapes, or the batched overhead camera's images with --render.
 
     python examples/transporter_data_generation.py --num-envs 8192 --max-steps 2
 """
@@ -24,10 +24,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--num-envs", type=int, default=8192)
     ap.add_argument("--max-steps", type=int, default=None, help="pick/place pairs per episode (config: dataset.max_steps)")
+    ap.add_argument("--render", action="store_true", help="overhead-camera observations (depth + RGB, CUDA tensors) instead of zero images")
     args = ap.parse_args()
     cfg = colour_separator_task_config()
     max_steps = args.max_steps or cfg.dataset.max_steps
-    env = BatchedRearrangementEnv(cfg=cfg, num_envs=args.num_envs)
+    env = BatchedRearrangementEnv(cfg=cfg, num_envs=args.num_envs, render=args.render)
     cam = "overhead_camera/overhead_camera"
     t0 = time.time()
     _, _, _, obs = env.reset()
@@ -43,6 +44,10 @@ def main():
         _, _, _, obs = env.step(pick_action)
         _, _, _, obs = env.step(place_action)
         episodes.append((pick_action, place_action))
+        if args.render and step == 0:
+            d = obs["overhead_camera/depth"]
+            print(f"observation: rgb {tuple(obs['overhead_camera/rgb'].shape)} depth {tuple(d.shape)} "
+                  f"(min {float(d.min()):.3f} m, max {float(d.max()):.3f} m) on {d.device}")
         nsim = 2 * 9000
         print(f"pair {step}: {in_progress.sum()} envs in progress, all phases converged in "
               f"{int(env.last_converged.sum())}/{args.num_envs} envs, "
