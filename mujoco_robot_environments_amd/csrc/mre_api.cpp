@@ -631,7 +631,9 @@ extern "C" int mre_render(mre_env* e, const float* cam_pos, const float* cam_mat
   r.rgb = rgb; r.depth = depth; r.seg = seg; r.env_mask = dmask;
   const int rows_per_iter = 320 / (width / 4);
   int row_groups = (height + rows_per_iter - 1) / rows_per_iter;
-  if (row_groups > 60) row_groups = 60;
+  int cap = 8;  // 8 row groups per env: the per-workgroup geom set-up is amortised over 30 row pairs
+  if (const char* rg = getenv("MRE_RENDER_ROW_GROUPS")) cap = atoi(rg);  // tuning knob
+  if (row_groups > cap) row_groups = cap;
   mre_launch_render(&r, row_groups, e->stream);
   HIPCHK(hipGetLastError());
   if (e1) HIPCHK(hipEventRecord(e1, e->stream));
