@@ -129,7 +129,12 @@ static int launch_step(mre_env* e, const StepArgs& a, bool settle = false) {
                        e->stream);
     StepArgs ac = a;
     ac.env_mask = e->mask_c; ac.launch_info = e->launch_info;
-    if (e->n_large > 0) {
+    // (recounted from the flags every launch: an env flagged large is masked out of the compact
+    // kernel, so the large kernel MUST run whenever a flag is set)
+    e->n_large = 0;
+    for (size_t i = 0; i < N; i++) e->n_large += e->h_large[i];
+    const bool run_large = e->n_large > 0;
+    if (run_large) {
       HIPCHK(hipEventRecord(e->ev_fork, e->stream));
       HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_fork, 0));
       StepArgs al = a;
@@ -140,7 +145,7 @@ static int launch_step(mre_env* e, const StepArgs& a, bool settle = false) {
     }
     if (settle) mre_launch_settle(&ac, e->stream); else mre_launch_step(&ac, e->stream);
     HIPCHK(hipGetLastError());
-    if (e->n_large > 0) HIPCHK(hipStreamWaitEvent(e->stream, e->ev_join, 0));
+    if (run_large) HIPCHK(hipStreamWaitEvent(e->stream, e->ev_join, 0));
     HIPCHK(hipMemcpyAsync(e->h_launch_info, e->launch_info, N * 16, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     int nrerun = 0;
