@@ -192,3 +192,61 @@ def test_capacity_emulation_cuts_the_contact_list(oracle_model):
     e.set_caps(0, 0, 0, 0)
     e.forward()
     assert e.nefc == 7 + 3 * 16 and not e.overflow
+
+
+def test_osc_torque_matches_an_independent_numpy_evaluation_of_the_law(compiled_model, oracle_model):
+    """The OSC law restated at tasks/rearrangement_mjx.py:59-135 (gains from osc.yaml:5-15),
+    evaluated in numpy from INDEPENDENT ingredients: the site Jacobian by central differences of the
+    model's own forward kinematics (model/compile.py, not the oracle's), the mass matrix by the
+    sum_b J_b' I_b J_b formula, and the oracle's bias force; the oracle's torque must agree.  Covers
+    both the regular branch (inverse of J M^-1 J') and pinv(rcond=1e-2), away from the home pose and
+    with joint velocities."""
+    from oracle import oracle as O
+    A, _ = compiled_model
+    rng = np.random.default_rng(4)
+    for trial in range(3):
+        e = _env(oracle_model, 0)
+        q = e.arr("qpos")
+        q[:7] = np.array(HOME) + rng.uniform(-0.3, 0.3, 7)
+        e.arr("qvel")[:7] = rng.uniform(-0.5, 0.5, 7)
+        e.forward()
+        st = int(A["eef_site"][0])
+        sb = int(A["site_bodyid"][st])
+
+        def site_pose(qq):
+            xpos, xquat = MC.forward_kinematics(A, qq)
+            return xpos[sb] + MC.qrot(xquat[sb], A["site_pos"][st]), MC.q2m(MC.qmul(xquat[sb], A["site_quat"][st]))
+
+        q0 = np.array(q[:43])
+        p0, R0 = site_pose(q0)
+        J = np.zeros((6, 7))
+        h = 1e-6
+        for a in range(7):
+            qp, qm = q0.copy(), q0.copy()
+            qp[a] += h; qm[a] -= h
+            pp, Rp = site_pose(qp); pm, Rm = site_pose(qm)
+            J[:3, a] = (pp - pm) / (2 * h)
+            W = (Rp - Rm) / (2 * h) @ R0.T          # skew(omega)
+            J[3:, a] = [W[2, 1], W[0, 2], W[1, 0]]
+        M = MC.dense_mass_matrix(A, q0)[:7, :7]
+        qd = np.array(e.arr("qvel")[:7])
+        p = O.make_osc()
+        p.target_pos[:] = p0 + [0.04, -0.03, 0.05]
+        yaw = 0.2
+        tq = MC.qmul(np.array([np.cos(yaw / 2), 0, 0, np.sin(yaw / 2)]), MC.m2q(R0))
+        p.target_quat[:] = tq
+        for pinv_always in (0, 1):
+            p.pinv_always = pinv_always
+            Minv = np.linalg.inv(M)
+            Li = J @ Minv @ J.T
+            Lam = np.linalg.pinv(Li, rcond=1e-2) if (pinv_always or abs(np.linalg.det(Li)) < 1e-2) else np.linalg.inv(Li)
+            qc = MC.m2q(R0); qc = np.array([qc[0], -qc[1], -qc[2], -qc[3]])
+            qe = MC.qmul(tq, qc)
+            eo = np.sign(qe[0]) * qe[1:]
+            F = np.concatenate([350.0 * (np.array(p.target_pos) - p0) + 20.0 * (0 - J[:3] @ qd),
+                                500.0 * eo + 100.0 * (0 - J[3:] @ qd)])
+            tn = 200.0 * (np.array([0, -0.785, 0, -2.356, 0, 1.571, 0.785]) - q0[:7]) + 30.0 * (0 - qd)
+            Jbar = Minv @ J.T @ Lam
+            tau = J.T @ Lam @ F + (np.eye(7) - J.T @ Jbar.T) @ tn + np.array(e.arr("qfrc_bias")[:7])
+            got = e.osc(p)
+            assert np.abs(got - tau).max() < 2e-4 * max(1.0, np.abs(tau).max()), (trial, pinv_always, got, tau)
