@@ -250,3 +250,35 @@ def test_osc_torque_matches_an_independent_numpy_evaluation_of_the_law(compiled_
             tau = J.T @ Lam @ F + (np.eye(7) - J.T @ Jbar.T) @ tn + np.array(e.arr("qfrc_bias")[:7])
             got = e.osc(p)
             assert np.abs(got - tau).max() < 2e-4 * max(1.0, np.abs(tau).max()), (trial, pinv_always, got, tau)
+
+
+@pytest.mark.parametrize("gx, slides", [(4.0, False), (14.0, True)])
+def test_elliptic_friction_cone_stick_and_slide_under_tilted_gravity(gx, slides):
+    """Coulomb friction of the cube-table pair (mu = 1: max of the two geoms' sliding friction at equal
+    priority): with gravity tilted to (gx, 0, -9.8) a resting cube must stick while gx < mu g and slide
+    beyond, with a friction force that never exceeds the cone (acceleration >= gx - mu g) and reaches
+    most of it (PGS stops at its 100-sweep cap short of the cone boundary: measured mu_eff = 0.90).
+    The robot is frozen; the soft friction rows allow a small creep in the stick case."""
+    from oracle import oracle as O
+    from mujoco_robot_environments_amd.model import spec as MS
+    A = MC.compile_scene(MS.default_scene(dict(gravity=[gx, 0.0, -9.8])))
+    m = O.Model(MC.to_blob(A))
+    e = O.Env(m, nprops=1)
+    q = e.arr("qpos")
+    q[:7] = HOME
+    q[15:22] = [0.5, 0.0, 0.4155, 1, 0, 0, 0]
+    e.freeze_robot(True)
+    e.forward()
+    e.step(50)                       # let the normal force build up
+    x0, v0 = float(q[15]), float(e.arr("qvel")[15])
+    T = 200
+    e.step(T)
+    x1 = float(q[15])
+    t = T * 1e-3
+    if not slides:
+        assert abs(x1 - x0) < 2e-3, x1 - x0          # sticks (creep of the soft friction rows only)
+    else:
+        a_measured = 2.0 * (x1 - x0 - v0 * t) / (t * t)
+        mu_eff = (gx - a_measured) / 9.8
+        assert 0.85 < mu_eff <= 1.0 + 1e-6, (a_measured, mu_eff)
+    assert abs(q[17] - 0.4155) < 1e-3                # stays on the table
