@@ -66,6 +66,9 @@ struct mre_env {
   OscConfig* d_osc = nullptr;
   OscConfig* d_osc_env = nullptr;
   float* geoms = nullptr;        // [N][NG][16] geom poses for the renderer (allocated on first use)
+  // cached image of the static geoms (ground, table) for the last camera: depth | rgb | seg
+  float* bg_depth = nullptr; uint8_t* bg_rgb = nullptr; uint8_t* bg_seg = nullptr;
+  float bg_key[16] = {0}; int bg_h = 0, bg_w = 0; bool bg_valid = false;
   uint8_t* prop_rgb = nullptr;   // [N][NPROP][3]
   float geom_rgb[NG][3];  // [N] per-env controller parameters (mre_osc_configure_env) or null
   float* trace = nullptr;
@@ -496,7 +499,7 @@ extern "C" int mre_destroy(mre_env* e) {
   if (e->stream2) (void)hipStreamSynchronize(e->stream2);
   void* ptrs[] = {e->dM, e->qpos, e->qvel, e->qacc_ws, e->ctrl, e->nprops, e->prop_size, e->osc_target,
                   e->grip_closed, e->converged, e->mask, e->sites, e->status, e->stats, e->d_osc, e->d_osc_env, e->order,
-                  e->geoms, e->prop_rgb,
+                  e->geoms, e->prop_rgb, e->bg_depth, e->bg_rgb, e->bg_seg,
                   e->d_large, e->mask_c, e->mask_l, e->mask_r, e->sv_qpos, e->sv_qvel, e->sv_qacc_ws, e->sv_ctrl,
                   e->sv_status, e->launch_info, e->auto_order};
   for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -578,7 +581,7 @@ extern "C" int mre_set_render_colours(mre_env* e, const uint8_t* prop_rgb, const
     for (int g = 0; g < NG; g++) for (int k = 0; k < 3; k++) e->geom_rgb[g][k] = 0.5f;
   }
   if (prop_rgb) { int rc = copy_in(e, e->prop_rgb, prop_rgb, N * NPROP * 3); if (rc) return rc; }
-  if (geom_rgb) memcpy(e->geom_rgb, geom_rgb, sizeof(e->geom_rgb));
+  if (geom_rgb) { memcpy(e->geom_rgb, geom_rgb, sizeof(e->geom_rgb)); e->bg_valid = false; }
   HIPCHK(hipStreamSynchronize(e->stream));
   return MRE_OK;
 }
@@ -639,6 +642,44 @@ extern "C" int mre_render(mre_env* e, const float* cam_pos, const float* cam_mat
   int cap = 8;  // 8 row groups per env: the per-workgroup geom set-up is amortised over 30 row pairs
   if (const char* rg = getenv("MRE_RENDER_ROW_GROUPS")) cap = atoi(rg);  // tuning knob
   if (row_groups > cap) row_groups = cap;
+  // The static geoms (ground plane, table: geoms 0 and 1, fixed to the world) look the same in every
+  // env and every frame of a camera: their image is rendered once per camera and every frame then
+  // starts from it and composites the moving geoms (robot hulls, cubes) on top.
+  constexpr int N_STATIC = 2;
+  bool use_bg = true;
+  if (const char* nb = getenv("MRE_RENDER_NO_BACKGROUND")) use_bg = atoi(nb) == 0;  // diagnostic
+  if (use_bg) {
+    float key[16] = {cam_pos[0], cam_pos[1], cam_pos[2], cam_mat[0], cam_mat[1], cam_mat[2], cam_mat[3], cam_mat[4],
+                     cam_mat[5], cam_mat[6], cam_mat[7], cam_mat[8], fovy_deg, 0.f, 0.f, 0.f};
+    if (!e->bg_valid || e->bg_h != height || e->bg_w != width || memcmp(key, e->bg_key, sizeof(key)) != 0) {
+      if (e->bg_h != height || e->bg_w != width) {
+        for (void* p : {(void*)e->bg_depth, (void*)e->bg_rgb, (void*)e->bg_seg}) if (p) (void)hipFree(p);
+        e->bg_depth = nullptr; e->bg_rgb = nullptr; e->bg_seg = nullptr;
+        const size_t px = (size_t)height * width;
+        HIPCHK(hipMalloc(&e->bg_depth, px * 4)); HIPCHK(hipMalloc(&e->bg_rgb, px * 3)); HIPCHK(hipMalloc(&e->bg_seg, px));
+        e->bg_h = height; e->bg_w = width;
+      }
+      // the static geoms' poses do not depend on the env: cast them for env 0 (exported above even
+      // when env 0 is masked out? no -- so export it unmasked once)
+      if (dmask) {
+        StepArgs a0 = a;
+        a0.env_mask = nullptr;
+        mre_launch_step(&a0, e->stream);
+        HIPCHK(hipGetLastError());
+      }
+      RenderArgs b = r;
+      b.N = 1; b.env_mask = nullptr; b.g0 = 0; b.g1 = N_STATIC;
+      b.rgb = e->bg_rgb; b.depth = e->bg_depth; b.seg = e->bg_seg;
+      mre_launch_render(&b, row_groups, e->stream);
+      HIPCHK(hipGetLastError());
+      memcpy(e->bg_key, key, sizeof(key));
+      e->bg_valid = true;
+    }
+    r.g0 = N_STATIC; r.g1 = NG;
+    r.bg_depth = e->bg_depth; r.bg_rgb = e->bg_rgb; r.bg_seg = e->bg_seg;
+  } else {
+    r.g0 = 0; r.g1 = NG;
+  }
   mre_launch_render(&r, row_groups, e->stream);
   HIPCHK(hipGetLastError());
   if (e1) HIPCHK(hipEventRecord(e1, e->stream));

@@ -167,6 +167,12 @@ struct RenderArgs {
   float* depth;              // [N][H][W] or null
   uint8_t* seg;              // [N][H][W] geom index, 255 = background, or null
   const uint8_t* env_mask;   // [N] or null
+  // geoms [g0, g1) are cast; with a background (the image of the static geoms for this camera,
+  // rendered once) every pixel starts from it and only the moving geoms are composited on top
+  int g0, g1;
+  const float* bg_depth;     // [H][W] or null
+  const uint8_t* bg_rgb;     // [H][W][3]
+  const uint8_t* bg_seg;     // [H][W]
 };
 
 }  // namespace mre
