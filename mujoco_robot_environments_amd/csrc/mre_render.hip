@@ -9,7 +9,14 @@
 // so that depth leaves as one 16-byte store per lane, colour as three dwords and ids as one dword; a
 // workgroup of 320 threads covers two image rows per iteration.  Per workgroup the 16 geoms are turned
 // into (camera origin, ray basis) in their own frames plus a screen-space bounding rectangle, so a
-// pixel group only intersects the geoms whose rectangle it touches (typically ground + table + <= 1).
+// pixel group only intersects the geoms whose rectangle it touches.
+//
+// Ground plane and table are fixed to the world: their image is the same for every env and frame of a
+// camera.  mre_render (mre_api.cpp) renders it once (geoms [0, 2), N = 1) and keeps it; a frame then
+// starts every pixel from that background -- 2.4 MB shared by all workgroups, served from L2 /
+// Infinity Cache -- and casts only the moving geoms [2, 16), whose rectangles cover a few percent of
+// the image, so most 4-pixel groups are a copy (1.97 ms per 4096-env frame = 0.64 of HBM peak,
+// against 3.7 ms when every pixel casts all geoms).
 //
 // Shading is a documented approximation of MuJoCo's fixed-function lighting (no specular, no shadows,
 // no textures except the ground checker): albedo * (ambient + headlight diffuse * cos(view) + scene
