@@ -156,10 +156,11 @@ int mre_render(mre_env*, const float* cam_pos, const float* cam_mat, float fovy_
  * env on the compact kernel, re-runs from the saved pre-launch state on the large kernel the envs
  * that overflowed it, and keeps them there until their contact set has shrunk again -- results
  * never depend on the compact capacities, and MRE_ST_CONTACT_OVERFLOW reports an overflow of the
- * LARGE ones only.  mre_set_fallback(0) pins all envs to the compact kernel (status then reports
- * compact overflows; profiling and capacity tests).  Stats: out4 = {envs currently on the large
+ * LARGE ones only.  mre_set_fallback(mode): 1 = the above (default); 0 pins all envs to the compact
+ * kernel (status then reports compact overflows; profiling and capacity tests); 2 pins all envs to
+ * the large kernel (the run the fallback must reproduce bit for bit).  Stats: out4 = {envs currently on the large
  * kernel, env launches re-run so far, promotions, demotions}. */
-int mre_set_fallback(mre_env*, int enabled);
+int mre_set_fallback(mre_env*, int mode);
 int mre_get_fallback_stats(mre_env*, long long* out4);
 
 /* measurement support for bench.py: when enabled every step-kernel launch is

@@ -85,6 +85,7 @@ struct mre_env {
   size_t events_used = 0;
   // ---- capacity fallback (see launch_step): per-env kernel choice, pre-launch state copies
   bool fallback = true;
+  bool large_only = false;  // mre_set_fallback(2): every env on the large kernel (reference run for the fallback)
   hipStream_t stream2 = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   uint8_t *d_large = nullptr, *mask_c = nullptr, *mask_l = nullptr, *mask_r = nullptr;
@@ -159,7 +160,7 @@ static int launch_step(mre_env* e, const StepArgs& a, bool settle = false) {
       if (li[0] < 0) continue;
       if (!e->h_large[i]) {
         if (li[0] > 0) { e->h_rerun[i] = 1; e->h_large[i] = 1; nrerun++; changed = true; e->n_large++; e->n_promotions++; }
-      } else if (li[0] == 0 && 4 * (li[1] & 0xFFFF) <= 3 * NCON_MAX && 4 * li[2] <= 3 * NEFC_MAX &&
+      } else if (!e->large_only && li[0] == 0 && 4 * (li[1] & 0xFFFF) <= 3 * NCON_MAX && 4 * li[2] <= 3 * NEFC_MAX &&
                  4 * (li[3] & 0xFFFF) <= 3 * NRROW_MAX && 4 * (li[3] >> 16) <= 3 * NPP_MAX) {
         e->h_large[i] = 0; changed = true; e->n_large--; e->n_demotions++;
       }
@@ -556,7 +557,7 @@ extern "C" int mre_reset(mre_env* e, const uint8_t* mask) {
   // a reset env starts on the compact kernel again
   bool changed = false;
   for (int i = 0; i < e->N; i++)
-    if (e->h_large[i] && (!mask || mask[i])) { e->h_large[i] = 0; e->n_large--; changed = true; }
+    if (!e->large_only && e->h_large[i] && (!mask || mask[i])) { e->h_large[i] = 0; e->n_large--; changed = true; }
   if (changed) {
     HIPCHK(hipMemcpyAsync(e->d_large, e->h_large.data(), (size_t)e->N, hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -686,9 +687,16 @@ extern "C" int mre_render(mre_env* e, const float* cam_pos, const float* cam_mat
   return MRE_OK;
 }
 
-extern "C" int mre_set_fallback(mre_env* e, int enabled) {
+extern "C" int mre_set_fallback(mre_env* e, int mode) {
   if (!e) return fail(MRE_ERR_ARG, "null handle");
-  e->fallback = enabled != 0;
+  if (mode < 0 || mode > 2) return fail(MRE_ERR_ARG, "mre_set_fallback: mode is 0 (compact only), 1 (fallback) or 2 (large only)");
+  e->fallback = mode != 0;
+  e->large_only = mode == 2;
+  HIPCHK(hipStreamSynchronize(e->stream));
+  if (mode != 1) {
+    e->h_large.assign((size_t)e->N, mode == 2 ? 1 : 0);
+    HIPCHK(hipMemcpy(e->d_large, e->h_large.data(), (size_t)e->N, hipMemcpyHostToDevice));
+  }
   return MRE_OK;
 }
 

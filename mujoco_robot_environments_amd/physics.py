@@ -271,9 +271,10 @@ class BatchedPhysics:
         self.sync()
         return t_rgb, t_depth, t_seg
 
-    def set_fallback(self, enabled: bool = True) -> None:
-        """Capacity fallback (include/mre.h): on by default; off pins every env to the compact kernel."""
-        check(_lib.lib().mre_set_fallback(self._h, int(enabled)), "mre_set_fallback")
+    def set_fallback(self, mode=True) -> None:
+        """Capacity fallback (include/mre.h): True / 1 = on (default), False / 0 = compact kernel only,
+        2 = large kernel only."""
+        check(_lib.lib().mre_set_fallback(self._h, int(mode)), "mre_set_fallback")
 
     def fallback_stats(self) -> dict:
         out = (C.c_longlong * 4)()
