@@ -4,7 +4,15 @@ sys.path.insert(0, '.')
 from mujoco_robot_environments_amd.tasks.rearrangement import BatchedRearrangementEnv, colour_separator_task_config
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 npairs = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-env = BatchedRearrangementEnv(cfg=colour_separator_task_config(), num_envs=N)
+cfg = colour_separator_task_config()
+if len(sys.argv) > 3:   # optional OSC gain override: kp_pos kd_pos [kp_ori kd_ori kp_null kd_null]
+    g = cfg.robots.arm.controller_config.controller_params.gains
+    vals = [float(v) for v in sys.argv[3:]]
+    g.position.kp, g.position.kd = vals[0], vals[1]
+    if len(vals) >= 6:
+        g.orientation.kp, g.orientation.kd, g.nullspace.kp, g.nullspace.kd = vals[2:6]
+    print("OSC gains:", g)
+env = BatchedRearrangementEnv(cfg=cfg, num_envs=N)
 env.reset()
 np.set_printoptions(precision=4, suppress=True, linewidth=200)
 for pair in range(npairs):
