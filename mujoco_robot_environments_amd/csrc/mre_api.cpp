@@ -111,6 +111,7 @@ struct mre_env {
 //      capacities -- and demotes large envs whose high-water marks fell below 3/4 of them.
 // Only an overflow of the LARGE capacities is reported (MRE_ST_CONTACT_OVERFLOW).
 static int launch_step(mre_env* e, const StepArgs& a, bool settle = false) {
+  HIPCHK(hipSetDevice(e->device));  // the HIP current device is per thread; callers may have moved it
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (e->profiling) {
     if (e->events_used == e->events.size()) {
@@ -518,15 +519,18 @@ extern "C" int mre_num_envs(const mre_env* e) { return e ? e->N : 0; }
 extern "C" void* mre_stream(mre_env* e) { return e ? (void*)e->stream : nullptr; }
 extern "C" int mre_sync(mre_env* e) {
   if (!e) return fail(MRE_ERR_ARG, "null handle");
+  HIPCHK(hipSetDevice(e->device));
   HIPCHK(hipStreamSynchronize(e->stream));
   return MRE_OK;
 }
 
 static int copy_in(mre_env* e, void* dst, const void* src, size_t n) {
+  HIPCHK(hipSetDevice(e->device));
   HIPCHK(hipMemcpyAsync(dst, src, n, hipMemcpyDefault, e->stream));
   return MRE_OK;
 }
 static int copy_out(mre_env* e, void* dst, const void* src, size_t n) {
+  HIPCHK(hipSetDevice(e->device));
   HIPCHK(hipMemcpyAsync(dst, src, n, hipMemcpyDefault, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
   return MRE_OK;
@@ -549,6 +553,7 @@ extern "C" int mre_set_props(mre_env* e, const int32_t* nprops, const float* pro
 
 extern "C" int mre_reset(mre_env* e, const uint8_t* mask) {
   if (!e) return fail(MRE_ERR_ARG, "null handle");
+  HIPCHK(hipSetDevice(e->device));
   const uint8_t* dmask;
   int rc = stage_mask(e, mask, &dmask);
   if (rc) return rc;
@@ -590,6 +595,7 @@ extern "C" int mre_set_render_colours(mre_env* e, const uint8_t* prop_rgb, const
 extern "C" int mre_render(mre_env* e, const float* cam_pos, const float* cam_mat, float fovy_deg, int height, int width,
                           uint8_t* rgb, float* depth, uint8_t* seg, const uint8_t* mask) {
   if (!e || !cam_pos || !cam_mat) return fail(MRE_ERR_ARG, "mre_render: null argument");
+  HIPCHK(hipSetDevice(e->device));
   if (height <= 0 || width <= 0 || (width & 3) != 0 || width / 4 > 320 || !(fovy_deg > 0.f && fovy_deg < 180.f))
     return fail(MRE_ERR_ARG, "mre_render: width must be a multiple of 4 (<= 1280), 0 < fovy < 180");
   if ((rgb && !is_device_ptr(rgb)) || (depth && !is_device_ptr(depth)) || (seg && !is_device_ptr(seg)))
@@ -833,6 +839,7 @@ extern "C" int mre_gripper_set(mre_env* e, const uint8_t* closed) {
 
 extern "C" int mre_get_sites(mre_env* e, float* tcp_pos, float* eef_pose, float* prop_pose) {
   if (!e) return fail(MRE_ERR_ARG, "null handle");
+  HIPCHK(hipSetDevice(e->device));
   // refresh site poses for the current state (0 physics steps = kinematics only)
   StepArgs a;
   fill_args(e, a);
