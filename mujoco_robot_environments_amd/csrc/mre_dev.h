@@ -42,11 +42,11 @@ static_assert(robot_dof_madr(NRV) == NMR, "robot mass-matrix size");
 // mre_api.cpp runs every env on the compact kernel and re-runs, from the saved pre-launch state, the
 // envs that report an overflow on the large kernel, so results never depend on the compact caps.
 #ifdef MRE_LARGE_CAPS
-constexpr int NCON_MAX = 48;   // active contacts kept per env
-constexpr int NEFC_MAX = 160;  // constraint rows per env (7 equality + limits + 3 per contact)
-constexpr int NRROW_MAX = 100; // rows with a robot part (7 equality + limits + 3 per robot contact)
+constexpr int NCON_MAX = 44;   // active contacts kept per env
+constexpr int NEFC_MAX = 148;  // constraint rows per env (7 equality + limits + 3 per contact)
+constexpr int NRROW_MAX = 83;  // rows with a robot part (7 equality + limits + 3 per robot contact)
 constexpr int NPP_MAX = 16;    // cube-cube contacts (rows with two prop parts)
-constexpr int MAXBLK = 56;     // <= 8 scalar-row triples + NCON_MAX contact blocks (also bounds the schedule length)
+constexpr int MAXBLK = 52;     // <= 8 scalar-row triples + NCON_MAX contact blocks (also bounds the schedule length)
 #else
 constexpr int NCON_MAX = 32;
 constexpr int NEFC_MAX = 112;

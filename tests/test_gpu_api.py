@@ -127,7 +127,7 @@ def test_capacity_fallback_reruns_overflowing_envs_on_the_large_kernel(compiled_
         envs.append(e)
     assert envs[0].overflow and not envs[1].overflow
     for e in envs:
-        e.set_caps(48, 160, 100, 16)
+        e.set_caps(44, 148, 83, 16)
         e.forward()
         for _ in range(nsteps):
             e.step(1)

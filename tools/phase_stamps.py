@@ -16,7 +16,7 @@ if sys.argv[1] == "build":
         base = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
         objs = []
         for name, src, flags in (("k", "mre_kernels.hip", [f"-DMRE_PHASE_STAMPS={k}"]),
-                                 ("kl", "mre_kernels.hip", ["-DMRE_LARGE_CAPS"]), ("r", "mre_render.hip", []),
+                                 ("kl", "mre_kernels.hip", ["-DMRE_LARGE_CAPS", f"-DMRE_PHASE_STAMPS={k}"]), ("r", "mre_render.hip", []),
                                  ("api", "mre_api.cpp", [])):
             objs.append(os.path.join(DIAG, f"{name}{k}.o"))
             subprocess.check_call(base + flags + ["-c", os.path.join(CSRC, src), "-o", objs[-1]])
