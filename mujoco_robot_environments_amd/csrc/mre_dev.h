@@ -38,7 +38,7 @@ static_assert(robot_dof_madr(NRV) == NMR, "robot mass-matrix size");
 
 // Per-env constraint capacities (LDS is sized for them).  The library carries the step kernel in
 // two capacity sets: the compact one keeps a workgroup at 20 KB of LDS (8 workgroups per CU) and
-// covers cubes resting / sliding on the table; the large one (5 per CU) covers grasps and piles.
+// covers cubes resting / sliding on the table; the large one (6 per CU) covers grasps and piles.
 // mre_api.cpp runs every env on the compact kernel and re-runs, from the saved pre-launch state, the
 // envs that report an overflow on the large kernel, so results never depend on the compact caps.
 #ifdef MRE_LARGE_CAPS
