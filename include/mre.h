@@ -151,7 +151,7 @@ int mre_render(mre_env*, const float* cam_pos, const float* cam_mat, float fovy_
                uint8_t* rgb, float* depth, uint8_t* seg, const uint8_t* mask);
 
 /* Constraint capacities.  The library holds the step kernel in two capacity sets
- * (csrc/mre_dev.h): compact (32 contacts / 112 rows / 50 robot rows / 8 cube-cube contacts, 8
+ * (csrc/mre_dev.h): compact (32 contacts / 112 rows / 62 robot rows / 8 cube-cube contacts, 8
  * workgroups per CU) and large (44 / 148 / 83 / 16, 6 per CU).  By default every launch runs each
  * env on the compact kernel, re-runs from the saved pre-launch state on the large kernel the envs
  * that overflowed it, and keeps them there until their contact set has shrunk again -- results

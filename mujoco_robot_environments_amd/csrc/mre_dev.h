@@ -50,7 +50,7 @@ constexpr int MAXBLK = 52;     // <= 8 scalar-row triples + NCON_MAX contact blo
 #else
 constexpr int NCON_MAX = 32;
 constexpr int NEFC_MAX = 112;
-constexpr int NRROW_MAX = 50;
+constexpr int NRROW_MAX = 62;
 constexpr int NPP_MAX = 8;
 constexpr int MAXBLK = 40;
 #endif

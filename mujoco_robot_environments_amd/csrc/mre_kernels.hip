@@ -37,27 +37,26 @@ struct alignas(8) Blk {
   uint8_t bslot : 4;        // slot of the second cube's Jacobian part (cube-cube contacts)
 };
 
-// bytes the solver's operand table needs on top of the body-frame arrays (mre_solver.h)
+// bytes the solver's operand table needs on top of the body-frame region (mre_solver.h)
 constexpr int TAB_BYTES = 8 * (MAXBLK * 5 + 1) + 4 * 48;
-constexpr int R1_MIN = TAB_BYTES - 4 * (NB * 16) > 0 ? TAB_BYTES - 4 * (NB * 16) : 4;
+constexpr int FRAME_BYTES = (int)sizeof(OscSm) > 4 * (NB * 16) ? (int)sizeof(OscSm) : 4 * (NB * 16);
+constexpr int R1_MIN = TAB_BYTES - FRAME_BYTES > 0 ? TAB_BYTES - FRAME_BYTES : 4;
 
 struct Sm {
   // state
   float qpos[NQP], qvel[NVP], qacc_ws[NVP], ctrl[NU];
   // generalized vectors
   float qfrc_smooth[NVP], qacc_smooth[NVP], qacc[NVP], qfrc_bias[NVP], qfrc_con[NVP];
-  // body frames
-  float xpos[NB][3], xquat[NB][4], xmat[NB][9];
   // LDS regions reused along the step (lifetimes: S1a kinematics..factor, S1b velocity stage,
   // S1c collision + assembly, tick-boundary controller, S2 solve + integrate)
-  union {  // R1: spatial inertias (S1a/S1b) | OSC scratch (tick boundary)
-    struct { float cinert[NB][10], crb[NRB][10]; };
+  union {  // body frames (S1a..S1c) | OSC scratch (tick boundary: nothing reads the frames between the
+           // assembly and the next position stage) | head of the solver's operand table (S2)
+    struct { float xpos[NB][3], xquat[NB][4], xmat[NB][9]; };
     OscSm osc;
-    char tab_room[R1_MIN];  // (solve) tail of the operand table
   };
+  char tab_room[R1_MIN];  // R1: (S2) tail of the operand table
   float cdof[NRV][6];  // robot dofs only; cube cdofs are implicit (prop_cdof)
-  union {  // R2: velocity-stage temporaries (S1b) | contact geometry (S1c) | jar + forces (S2)
-    struct { float cdof_dot[NV][6], cvel[NB][6], cfrc[NB][6]; };
+  union {  // R2: contact geometry (S1c) | jar + forces (S2)
     struct { float con_pos[NCON_MAX][3], con_frame[NCON_MAX][9], con_dist[NCON_MAX]; };
     struct { float jar[NEFC_MAX], frc[NEFC_MAX]; };
   };
@@ -76,9 +75,17 @@ struct Sm {
   uint16_t lim_info[NRV + 1];
   // ---- contiguous block [JpA .. sched]: written only after collision; hosts the per-lane
   // clip buffers of the narrow phase (mre_solver.h: collide)
-  float JpA[3 * NCON_MAX][6];            // prop part A of every contact row
+  // Its head doubles as the home of what only S1a / S1b need (dead before the collision):
+  union {
+    float JpA[3 * NCON_MAX][6];          // prop part A of every contact row
+    struct { float cinert[NB][10], crb[NRB][10]; };  // spatial inertias (S1a/S1b)
+  };
   float JpB[3 * NPP_MAX][6];             // prop part B (cube-cube contacts only)
-  float Jr[NRROW_MAX][NRV], Br[NRROW_MAX][NRV];
+  union {
+    float Jr[NRROW_MAX][NRV];
+    struct { float cdof_dot[NV][6], cvel[NB][6], cfrc[NB][6]; };  // velocity-stage temporaries (S1b)
+  };
+  float Br[NRROW_MAX][NRV];
   // one 64-byte record per constraint block (scalar-row triple g -> record g, contact c -> record
   // 8 + c): [0:3] regulariser R of its rows, [3:6] aref (S1) -> efc_b (S2), [6:9] 1/A_ii,
   // [9:15] symmetric 3x3 block of A (00,01,02,11,12,22), [15] friction coefficient

@@ -123,7 +123,7 @@ class Env:
     def no_constraints(self, flag: bool):
         lib().mro_set_no_constraints(self.ptr, int(flag))
 
-    def set_caps(self, ncon_cap: int = 32, nefc_cap: int = 112, nrrow_cap: int = 50, npp_cap: int = 8):
+    def set_caps(self, ncon_cap: int = 32, nefc_cap: int = 112, nrrow_cap: int = 62, npp_cap: int = 8):
         """Emulate the device capacities (csrc/mre_dev.h: NCON_MAX, NEFC_MAX, NRROW_MAX, NPP_MAX)."""
         lib().mro_set_caps(self.ptr, int(ncon_cap), int(nefc_cap), int(nrrow_cap), int(npp_cap))
 

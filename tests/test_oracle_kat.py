@@ -183,10 +183,10 @@ def test_capacity_emulation_cuts_the_contact_list(oracle_model):
     init_oracle_env(e, 4, z_extra=-1e-4)
     e.forward()
     assert e.nefc == 7 + 3 * 16 and not e.overflow
-    e.set_caps(ncon_cap=10, nefc_cap=112, nrrow_cap=50, npp_cap=8)
+    e.set_caps(ncon_cap=10, nefc_cap=112, nrrow_cap=62, npp_cap=8)
     e.forward()
     assert e.nefc == 7 + 3 * 10 and e.overflow
-    e.set_caps(ncon_cap=32, nefc_cap=7 + 3 * 5 + 2, nrrow_cap=50, npp_cap=8)
+    e.set_caps(ncon_cap=32, nefc_cap=7 + 3 * 5 + 2, nrrow_cap=62, npp_cap=8)
     e.forward()
     assert e.nefc == 7 + 3 * 5 and e.overflow
     e.set_caps(0, 0, 0, 0)
