@@ -24,11 +24,11 @@ extern "C" void mre_launch_prepare(const uint8_t* user_mask, const uint8_t* larg
                                    uint8_t* mask_large, int* launch_info, const float* qpos, float* sv_qpos,
                                    const float* qvel, float* sv_qvel, const float* qacc_ws, float* sv_qacc_ws,
                                    const float* ctrl, float* sv_ctrl, const uint32_t* status, uint32_t* sv_status,
-                                   hipStream_t stream);
+                                   const uint8_t* converged, uint8_t* sv_converged, hipStream_t stream);
 extern "C" void mre_launch_restore_rows(const uint8_t* sel, int N, float* qpos, const float* sv_qpos, float* qvel,
                                         const float* sv_qvel, float* qacc_ws, const float* sv_qacc_ws, float* ctrl,
                                         const float* sv_ctrl, uint32_t* status, const uint32_t* sv_status,
-                                        hipStream_t stream);
+                                        uint8_t* converged, const uint8_t* sv_converged, hipStream_t stream);
 extern "C" void mre_launch_reset(const DevModel* M, int N, float* qpos, float* qvel, float* qacc_ws,
                                  float* ctrl, uint32_t* status, const uint8_t* mask,
                                  hipStream_t stream);
@@ -85,12 +85,14 @@ struct mre_env {
   size_t events_used = 0;
   // ---- capacity fallback (see launch_step): per-env kernel choice, pre-launch state copies
   bool fallback = true;
-  bool large_only = false;  // mre_set_fallback(2): every env on the large kernel (reference run for the fallback)
+  bool large_only = false;
+  bool compact_only = false;  // mre_set_fallback(0)  // mre_set_fallback(2): every env on the large kernel (reference run for the fallback)
   hipStream_t stream2 = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   uint8_t *d_large = nullptr, *mask_c = nullptr, *mask_l = nullptr, *mask_r = nullptr;
   float *sv_qpos = nullptr, *sv_qvel = nullptr, *sv_qacc_ws = nullptr, *sv_ctrl = nullptr;
   uint32_t* sv_status = nullptr;
+  uint8_t* sv_converged = nullptr;
   int* launch_info = nullptr;    // device [N][4]
   int* h_launch_info = nullptr;  // pinned host mirror
   std::vector<uint8_t> h_large, h_rerun;
@@ -108,7 +110,8 @@ struct mre_env {
 //   3. reads back per-env launch info (overflow flag + high-water marks of the launch),
 //   4. restores the envs that overflowed on the compact kernel to their saved rows, marks them
 //      large and runs them again on the large kernel -- so no result ever depends on the compact
-//      capacities -- and demotes large envs whose high-water marks fell below 3/4 of them.
+//      capacities; it also moves envs whose high-water marks came within 1/8 of a compact capacity
+//      (no re-run needed at a launch boundary) and demotes large envs that fell below 5/8.
 // Only an overflow of the LARGE capacities is reported (MRE_ST_CONTACT_OVERFLOW).
 static int launch_step(mre_env* e, const StepArgs& a, bool settle = false) {
   HIPCHK(hipSetDevice(e->device));  // the HIP current device is per thread; callers may have moved it
@@ -131,7 +134,7 @@ static int launch_step(mre_env* e, const StepArgs& a, bool settle = false) {
     const size_t N = (size_t)e->N;
     mre_launch_prepare(a.env_mask, e->d_large, e->N, e->mask_c, e->mask_l, e->launch_info, e->qpos, e->sv_qpos,
                        e->qvel, e->sv_qvel, e->qacc_ws, e->sv_qacc_ws, e->ctrl, e->sv_ctrl, e->status, e->sv_status,
-                       e->stream);
+                       e->converged, e->sv_converged, e->stream);
     StepArgs ac = a;
     ac.env_mask = e->mask_c; ac.launch_info = e->launch_info;
     // (recounted from the flags every launch: an env flagged large is masked out of the compact
@@ -159,11 +162,20 @@ static int launch_step(mre_env* e, const StepArgs& a, bool settle = false) {
       const int* li = e->h_launch_info + 4 * i;
       e->h_rerun[i] = 0;
       if (li[0] < 0) continue;
+      const int hw_ncon = li[1] & 0xFFFF, hw_nefc = li[2], hw_nrrow = li[3] & 0xFFFF, hw_npp = li[3] >> 16;
       if (!e->h_large[i]) {
-        if (li[0] > 0) { e->h_rerun[i] = 1; e->h_large[i] = 1; nrerun++; changed = true; e->n_large++; e->n_promotions++; }
-      } else if (!e->large_only && li[0] == 0 && 4 * (li[1] & 0xFFFF) <= 3 * NCON_MAX && 4 * li[2] <= 3 * NEFC_MAX &&
-                 4 * (li[3] & 0xFFFF) <= 3 * NRROW_MAX && 4 * (li[3] >> 16) <= 3 * NPP_MAX) {
-        e->h_large[i] = 0; changed = true; e->n_large--; e->n_demotions++;
+        if (li[0] > 0) {  // overflowed the compact kernel: re-run this launch on the large one
+          e->h_rerun[i] = 1; e->h_large[i] = 1; nrerun++; changed = true; e->n_large++; e->n_promotions++;
+        } else if (!e->compact_only && (8 * hw_ncon > 7 * NCON_MAX || 8 * hw_nefc > 7 * NEFC_MAX ||
+                                        8 * hw_nrrow > 7 * NRROW_MAX || 8 * hw_npp > 7 * NPP_MAX)) {
+          // within 1/8 of a compact capacity: move over BEFORE it overflows -- a promotion at a launch
+          // boundary costs nothing, an overflow costs a re-run of the whole launch (a scripted phase
+          // is one launch of 2000 steps)
+          e->h_large[i] = 1; changed = true; e->n_large++; e->n_promotions++;
+        }
+      } else if (!e->large_only && li[0] == 0 && 8 * hw_ncon <= 5 * NCON_MAX && 8 * hw_nefc <= 5 * NEFC_MAX &&
+                 8 * hw_nrrow <= 5 * NRROW_MAX && 8 * hw_npp <= 5 * NPP_MAX) {
+        e->h_large[i] = 0; changed = true; e->n_large--; e->n_demotions++;  // back below 5/8: demote
       }
     }
     // Dispatch order for the next launch: a launch ends with its slowest wavefront, and an env's
@@ -197,7 +209,7 @@ static int launch_step(mre_env* e, const StepArgs& a, bool settle = false) {
     if (nrerun > 0) {
       HIPCHK(hipMemcpyAsync(e->mask_r, e->h_rerun.data(), N, hipMemcpyHostToDevice, e->stream));
       mre_launch_restore_rows(e->mask_r, e->N, e->qpos, e->sv_qpos, e->qvel, e->sv_qvel, e->qacc_ws, e->sv_qacc_ws,
-                              e->ctrl, e->sv_ctrl, e->status, e->sv_status, e->stream);
+                              e->ctrl, e->sv_ctrl, e->status, e->sv_status, e->converged, e->sv_converged, e->stream);
       StepArgs ar = a;
       ar.env_mask = e->mask_r; ar.launch_info = nullptr;
       mre_launch_step_large(&ar, e->stream);
@@ -436,6 +448,7 @@ static int create_buffers(mre_env* e, int num_envs, int device_id) {
   HIPCHK(hipMalloc(&e->sv_qpos, N * NQP * 4)); HIPCHK(hipMalloc(&e->sv_qvel, N * NVP * 4));
   HIPCHK(hipMalloc(&e->sv_qacc_ws, N * NVP * 4)); HIPCHK(hipMalloc(&e->sv_ctrl, N * NU * 4));
   HIPCHK(hipMalloc(&e->sv_status, N * 4)); HIPCHK(hipMalloc(&e->launch_info, N * 16));
+  HIPCHK(hipMalloc(&e->sv_converged, N));
   HIPCHK(hipHostMalloc((void**)&e->h_launch_info, N * 16, hipHostMallocDefault));
   HIPCHK(hipMemsetAsync(e->d_large, 0, N, e->stream));
   e->h_large.assign(N, 0); e->h_rerun.assign(N, 0);
@@ -503,7 +516,7 @@ extern "C" int mre_destroy(mre_env* e) {
                   e->grip_closed, e->converged, e->mask, e->sites, e->status, e->stats, e->d_osc, e->d_osc_env, e->order,
                   e->geoms, e->prop_rgb, e->bg_depth, e->bg_rgb, e->bg_seg,
                   e->d_large, e->mask_c, e->mask_l, e->mask_r, e->sv_qpos, e->sv_qvel, e->sv_qacc_ws, e->sv_ctrl,
-                  e->sv_status, e->launch_info, e->auto_order};
+                  e->sv_status, e->launch_info, e->auto_order, e->sv_converged};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (e->h_launch_info) (void)hipHostFree(e->h_launch_info);
   if (e->h_auto_order) (void)hipHostFree(e->h_auto_order);
@@ -698,6 +711,7 @@ extern "C" int mre_set_fallback(mre_env* e, int mode) {
   if (mode < 0 || mode > 2) return fail(MRE_ERR_ARG, "mre_set_fallback: mode is 0 (compact only), 1 (fallback) or 2 (large only)");
   e->fallback = mode != 0;
   e->large_only = mode == 2;
+  e->compact_only = mode == 0;
   HIPCHK(hipStreamSynchronize(e->stream));
   if (mode != 1) {
     e->h_large.assign((size_t)e->N, mode == 2 ? 1 : 0);
@@ -914,13 +928,32 @@ extern "C" int mre_osc_set_target(mre_env* e, const float* pos, const float* qua
 
 extern "C" int mre_run_controller(mre_env* e, int nticks, int control_steps, uint8_t* converged_out) {
   if (!e || nticks < 0 || control_steps < 1) return fail(MRE_ERR_ARG, "mre_run_controller: bad argument");
-  StepArgs a;
-  fill_args(e, a);
-  a.nsteps = nticks * control_steps; a.control_steps = control_steps; a.mode = CTRL_OSC;
-  a.converged = e->converged;
-  int rc = launch_step(e, a);
-  if (rc) return rc;
-  if (e->trace) e->trace_pos += a.nsteps;
+  // One scripted phase is 400 ticks (2000 steps).  With the capacity fallback an overflow costs a
+  // re-run of the launch it happened in, so the call is cut into launches of RUN_CHUNK ticks: the
+  // state round-trips through HBM exactly, the converged flag carries over (F_CONV_CONTINUE) and
+  // NOT_CONVERGED is judged by the last launch only (F_CONV_OPEN on the others) -- bit-identical to
+  // one launch (tests/test_gpu_api.py), and a re-run repeats at most one chunk.
+  int chunk = nticks;
+  if (e->fallback && !e->large_only) {
+    chunk = 50;
+    if (const char* c = getenv("MRE_RUN_CHUNK")) { const int v = atoi(c); chunk = v > 0 ? v : nticks; }  // tuning knob
+  }
+  if (chunk <= 0 || chunk > nticks) chunk = nticks;
+  if (nticks > 0 && e->converged) HIPCHK(hipMemsetAsync(e->converged, 0, (size_t)e->N, e->stream));
+  int t0 = 0;
+  do {
+    const int n = (nticks - t0 < chunk) ? nticks - t0 : chunk;
+    StepArgs a;
+    fill_args(e, a);
+    a.nsteps = n * control_steps; a.control_steps = control_steps; a.mode = CTRL_OSC;
+    a.converged = e->converged;
+    if (t0 > 0) a.flags |= F_CONV_CONTINUE;
+    if (t0 + n < nticks) a.flags |= F_CONV_OPEN;
+    int rc = launch_step(e, a);
+    if (rc) return rc;
+    if (e->trace) e->trace_pos += a.nsteps;
+    t0 += n;
+  } while (t0 < nticks);
   if (converged_out) return copy_out(e, converged_out, e->converged, (size_t)e->N);
   return MRE_OK;
 }

@@ -114,7 +114,9 @@ struct OscConfig {
   int pinv_always;
 };
 
-enum StepFlags : unsigned { F_NO_CONSTRAINTS = 1u, F_FREEZE_ROBOT = 2u };
+// F_CONV_CONTINUE: this launch continues a run_controller call cut into several launches (the
+// converged flag carries over); F_CONV_OPEN: more launches follow (NOT_CONVERGED is not judged yet)
+enum StepFlags : unsigned { F_NO_CONSTRAINTS = 1u, F_FREEZE_ROBOT = 2u, F_CONV_CONTINUE = 4u, F_CONV_OPEN = 8u };
 enum CtrlMode : int { CTRL_HELD = 0, CTRL_SEQ = 1, CTRL_OSC = 2 };
 
 struct StepArgs {

@@ -647,7 +647,7 @@ MRE_DEV void step_body(const StepArgs& a, Sm& s) {
   unsigned long long stamp_acc[4] = {0, 0, 0, 0};
   unsigned long long stamp_t = __builtin_amdgcn_s_memtime();
 #endif
-  bool arm_converged = false;
+  bool arm_converged = (a.flags & F_CONV_CONTINUE) != 0 && a.converged != nullptr && a.converged[env] != 0;
   float grip_cmd = 0.f;
   const OscConfig* oscp = a.osc + (size_t)env * a.osc_stride;  // per-env gains when tuning a population
   int hw_ncon = 0, hw_nefc = 0, hw_nrrow = 0, hw_npp = 0, hw_nsched = 0;  // high-water marks of this launch
@@ -727,7 +727,7 @@ MRE_DEV void step_body(const StepArgs& a, Sm& s) {
     if (osc_converged(M, s, oscp, s.osc_tgt)) arm_converged = true;
     if (l == 0) {
       if (a.converged != nullptr) a.converged[env] = arm_converged ? 1 : 0;
-      if (!arm_converged && a.status != nullptr) a.status[env] |= 1u;
+      if (!arm_converged && a.status != nullptr && (a.flags & F_CONV_OPEN) == 0) a.status[env] |= 1u;
     }
   }
   if (a.geoms != nullptr && l < NG) {
@@ -830,7 +830,8 @@ __global__ __launch_bounds__(64) void k_prepare(const uint8_t* user_mask, const 
                                                 uint8_t* mask_compact, uint8_t* mask_large, int* launch_info,
                                                 const float* qpos, float* sv_qpos, const float* qvel, float* sv_qvel,
                                                 const float* qacc_ws, float* sv_qacc_ws, const float* ctrl,
-                                                float* sv_ctrl, const uint32_t* status, uint32_t* sv_status) {
+                                                float* sv_ctrl, const uint32_t* status, uint32_t* sv_status,
+                                                const uint8_t* converged, uint8_t* sv_converged) {
   const int env = blockIdx.x, l = threadIdx.x;
   if (env >= N) return;
   if (l < NQP) sv_qpos[(size_t)env * NQP + l] = qpos[(size_t)env * NQP + l];
@@ -842,6 +843,7 @@ __global__ __launch_bounds__(64) void k_prepare(const uint8_t* user_mask, const 
   if (l < 4) launch_info[(size_t)env * 4 + l] = -1;
   if (l == 0) {
     sv_status[env] = status[env];
+    sv_converged[env] = converged[env];
     const bool on = user_mask == nullptr || user_mask[env] != 0;
     mask_compact[env] = on && !large[env];
     mask_large[env] = on && large[env];
@@ -852,7 +854,8 @@ __global__ __launch_bounds__(64) void k_prepare(const uint8_t* user_mask, const 
 __global__ __launch_bounds__(64) void k_restore_rows(const uint8_t* sel, int N, float* qpos, const float* sv_qpos,
                                                      float* qvel, const float* sv_qvel, float* qacc_ws,
                                                      const float* sv_qacc_ws, float* ctrl, const float* sv_ctrl,
-                                                     uint32_t* status, const uint32_t* sv_status) {
+                                                     uint32_t* status, const uint32_t* sv_status, uint8_t* converged,
+                                                     const uint8_t* sv_converged) {
   const int env = blockIdx.x, l = threadIdx.x;
   if (env >= N || sel[env] == 0) return;
   if (l < NQP) qpos[(size_t)env * NQP + l] = sv_qpos[(size_t)env * NQP + l];
@@ -861,7 +864,7 @@ __global__ __launch_bounds__(64) void k_restore_rows(const uint8_t* sel, int N, 
     qacc_ws[(size_t)env * NVP + l] = sv_qacc_ws[(size_t)env * NVP + l];
   }
   if (l < NU) ctrl[(size_t)env * NU + l] = sv_ctrl[(size_t)env * NU + l];
-  if (l == 0) status[env] = sv_status[env];
+  if (l == 0) { status[env] = sv_status[env]; converged[env] = sv_converged[env]; }
 }
 
 }  // namespace mre
@@ -870,17 +873,18 @@ extern "C" void mre_launch_prepare(const uint8_t* user_mask, const uint8_t* larg
                                    uint8_t* mask_large, int* launch_info, const float* qpos, float* sv_qpos,
                                    const float* qvel, float* sv_qvel, const float* qacc_ws, float* sv_qacc_ws,
                                    const float* ctrl, float* sv_ctrl, const uint32_t* status, uint32_t* sv_status,
-                                   hipStream_t stream) {
+                                   const uint8_t* converged, uint8_t* sv_converged, hipStream_t stream) {
   hipLaunchKernelGGL(mre::k_prepare, dim3(N), dim3(64), 0, stream, user_mask, large, N, mask_compact, mask_large,
-                     launch_info, qpos, sv_qpos, qvel, sv_qvel, qacc_ws, sv_qacc_ws, ctrl, sv_ctrl, status, sv_status);
+                     launch_info, qpos, sv_qpos, qvel, sv_qvel, qacc_ws, sv_qacc_ws, ctrl, sv_ctrl, status, sv_status,
+                     converged, sv_converged);
 }
 
 extern "C" void mre_launch_restore_rows(const uint8_t* sel, int N, float* qpos, const float* sv_qpos, float* qvel,
                                         const float* sv_qvel, float* qacc_ws, const float* sv_qacc_ws, float* ctrl,
                                         const float* sv_ctrl, uint32_t* status, const uint32_t* sv_status,
-                                        hipStream_t stream) {
+                                        uint8_t* converged, const uint8_t* sv_converged, hipStream_t stream) {
   hipLaunchKernelGGL(mre::k_restore_rows, dim3(N), dim3(64), 0, stream, sel, N, qpos, sv_qpos, qvel, sv_qvel,
-                     qacc_ws, sv_qacc_ws, ctrl, sv_ctrl, status, sv_status);
+                     qacc_ws, sv_qacc_ws, ctrl, sv_ctrl, status, sv_status, converged, sv_converged);
 }
 
 extern "C" void mre_launch_reset(const mre::DevModel* M, int N, float* qpos, float* qvel, float* qacc_ws,

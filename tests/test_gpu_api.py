@@ -228,3 +228,33 @@ def test_fallback_reproduces_the_large_kernel_bit_for_bit(compiled_model):
     assert out[2][3]["promotions"] == 0 and out[2][3]["reruns"] == 0
     assert np.array_equal(out[1][0], out[2][0]) and np.array_equal(out[1][1], out[2][1])
     assert np.array_equal(out[1][2], out[2][2])
+
+
+def test_run_controller_in_chunks_equals_one_launch(compiled_model, monkeypatch):
+    """mre_run_controller cuts a phase into launches of 50 ticks (so that a capacity re-run repeats at
+    most one chunk).  State, converged flags and status must be bit-identical to a single launch,
+    including a target that is never reached (NOT_CONVERGED judged once, by the last launch) and one
+    reached early (flag carried over the cuts)."""
+    from mujoco_robot_environments_amd.model.compile import m2q
+    A, _ = compiled_model
+    N = 4
+    out = {}
+    for chunk in ("0", "50", "7"):
+        monkeypatch.setenv("MRE_RUN_CHUNK", chunk)
+        phys = _phys(N, A)
+        tcp, eef, _ = phys.sites()
+        tgt = eef[:, :3].astype(np.float64).copy()
+        tgt[0] += [0.05, 0.05, -0.10]     # reached well within the window
+        tgt[1] += [0.0, 0.0, 0.0]         # already there
+        tgt[2] += [0.9, 0.0, 0.9]         # out of reach: never converges
+        tgt[3] += [-0.02, 0.08, -0.05]
+        phys.osc_set_target(position=tgt, quat=eef[:, 3:7], velocity=np.zeros(3), angular_velocity=np.zeros(3))
+        phys.gripper_set(np.array([0, 1, 0, 1], np.uint8))
+        conv = phys.run_controller(230, 5)
+        out[chunk] = (phys.qpos().copy(), phys.qvel().copy(), conv.copy(), phys.status().copy())
+        phys.close()
+    assert out["0"][2].tolist() == [True, True, False, True]
+    assert (out["0"][3] & 1).tolist() == [0, 0, 1, 0]
+    for chunk in ("50", "7"):
+        for k in range(4):
+            assert np.array_equal(out["0"][k], out[chunk][k]), (chunk, k)
