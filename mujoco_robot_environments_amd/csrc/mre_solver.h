@@ -10,9 +10,13 @@
 // (diag(m,m,m,Ixx,Iyy,Izz)), so M^-1 J' needs storage for the robot part only.
 //
 // PGS is run matrix-free: lanes own dofs and carry a = M^-1 J' f and w = J' f in
-// registers; a row update is one wave-wide dot product (DPP reduction) plus a
-// rank-1 update.  Iterates are identical (in exact arithmetic) to MuJoCo's PGS
-// on the explicit A = J M^-1 J' + R that the CPU oracle builds.
+// registers.  Rows are grouped in blocks (a contact's three rows, or three consecutive
+// scalar rows) and the blocks of a sweep are scheduled over "islands" (the robot's 16
+// lanes, 8 lanes per cube): blocks touching disjoint islands run in the same step, blocks
+// sharing an island keep MuJoCo's order, so the iterates are identical (in exact
+// arithmetic) to MuJoCo's sequential PGS on the explicit A = J M^-1 J' + R that the CPU
+// oracle builds.  A step is three island dot products (DPP), the block update, and a
+// rank-3 update of a and w.
 #pragma once
 
 namespace mre {
