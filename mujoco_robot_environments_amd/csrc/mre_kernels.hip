@@ -10,9 +10,14 @@
 // the head of step k+1 (same state, same result).
 //
 // Lane mappings: lane = body for tree quantities, lane = dof for generalized
-// vectors, lane = mass-matrix entry for CRB, lane = (i,j) pair for the sparse
-// L'DL elimination step, lane = collision pair for the narrow phase,
-// lane = constraint row for assembly.
+// vectors, lane = mass-matrix entry for CRB, lane = collision pair for the narrow
+// phase, lane = constraint row for assembly, lanes = dofs grouped in islands for
+// the PGS sweeps (mre_solver.h); the robot's L'DL factorisation and solves are
+// unrolled at compile time over its dof tree (ROBOT_DOF_PARENT, mre_dev.h).
+// Phases are noinline functions called from the kernel body only (no nested
+// calls, no callee-saved registers, no scratch).  This file is compiled twice:
+// plain (compact constraint capacities, entry points k_step / k_settle) and with
+// -DMRE_LARGE_CAPS (k_step_large), see mre_dev.h.
 #include <hip/hip_runtime.h>
 
 #include "mre_dev.h"
