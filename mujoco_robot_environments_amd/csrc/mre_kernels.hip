@@ -103,6 +103,14 @@ struct Sm {
   int nblk, nsched;
 };
 
+// Residency is the budget the whole layout is built around: 160 KB of LDS per CU, allocated in
+// 512-byte granules -- 8 workgroups per CU for the compact capacities, 6 for the large ones.
+#ifdef MRE_LARGE_CAPS
+static_assert(sizeof(Sm) <= 27136, "large-capacity Sm must fit 6 workgroups per CU");
+#else
+static_assert(sizeof(Sm) <= 20480, "compact Sm must fit 8 workgroups per CU");
+#endif
+
 struct BodyRegs {
   float anchor[3], axis[3], xipos[3], ximat[9];
 };
