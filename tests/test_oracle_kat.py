@@ -282,3 +282,59 @@ def test_elliptic_friction_cone_stick_and_slide_under_tilted_gravity(gx, slides)
         mu_eff = (gx - a_measured) / 9.8
         assert 0.85 < mu_eff <= 1.0 + 1e-6, (a_measured, mu_eff)
     assert abs(q[17] - 0.4155) < 5e-3                # stays on the table (a sliding cube pitches a little)
+
+
+def test_boxbox_agrees_with_an_independent_separating_axis_computation():
+    """Random box pairs: an independent numpy separating-axis test (15 axes) gives the signed gap along
+    the axis of least overlap.  The collider must report contacts exactly when the boxes are closer
+    than the margin, its deepest contact distance must equal that gap, every contact must lie within
+    the margin of both boxes, and the normal must be a unit vector pointing from box 1 to box 2."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(12)
+
+    def rot():
+        q = rng.standard_normal(4); q /= np.linalg.norm(q)
+        return MC.q2m(q)
+
+    def sat_gap(p1, R1, s1, p2, R2, s2):
+        axes = [R1[:, i] for i in range(3)] + [R2[:, i] for i in range(3)]
+        for i in range(3):
+            for j in range(3):
+                c = np.cross(R1[:, i], R2[:, j])
+                if np.linalg.norm(c) > 1e-8:
+                    axes.append(c / np.linalg.norm(c))
+        d = p2 - p1
+        best = -np.inf
+        for a in axes:
+            r1 = sum(s1[i] * abs(a @ R1[:, i]) for i in range(3))
+            r2 = sum(s2[i] * abs(a @ R2[:, i]) for i in range(3))
+            best = max(best, abs(a @ d) - r1 - r2)   # > 0: separated by this much along a
+        return best
+
+    def dist_to_box(x, p, R, s):
+        loc = R.T @ (x - p)
+        return np.linalg.norm(np.maximum(np.abs(loc) - s, 0.0))
+
+    margin = 0.02
+    checked = hits = 0
+    for _ in range(2000):
+        s1, s2 = rng.uniform(0.05, 0.3, 3), rng.uniform(0.05, 0.3, 3)
+        R1, R2 = rot(), rot()
+        p1 = np.zeros(3)
+        p2 = rng.standard_normal(3)
+        p2 *= rng.uniform(0.1, 0.6) / np.linalg.norm(p2)
+        gap = sat_gap(p1, R1, s1, p2, R2, s2)
+        if gap < -0.02 or abs(gap - margin) < 1e-4:
+            continue        # deep interpenetration / knife-edge cases are not what the env produces
+        n, nrm, pos, dist = O.boxbox(p1, R1, s1, p2, R2, s2, margin)
+        checked += 1
+        if gap > margin:
+            assert n == 0, (gap, n)
+            continue
+        assert n >= 1, gap
+        hits += 1
+        assert abs(np.linalg.norm(nrm) - 1) < 1e-9 and nrm @ (p2 - p1) > 0
+        assert abs(dist.min() - gap) < 2e-6, (dist.min(), gap)
+        for x, dd in zip(pos, dist):
+            assert dist_to_box(x, p1, R1, s1) < margin + 1e-6 and dist_to_box(x, p2, R2, s2) < margin + 1e-6
+    assert checked > 400 and hits > 100, (checked, hits)
