@@ -344,3 +344,43 @@ def test_boxbox_agrees_with_an_independent_separating_axis_computation():
         for x, dd in zip(pos, dist):
             assert dist_to_box(x, p1, R1, s1) < margin + 1e-6 and dist_to_box(x, p2, R2, s2) < margin + 1e-6
     assert checked > 400 and hits > 100, (checked, hits)
+
+
+def test_mechanical_energy_balance_of_the_falling_arm(compiled_model, oracle_model):
+    """Work-energy theorem over 0.15 s of the arm falling from a bent pose with zero controls (no
+    cubes, no joint limit reached): kinetic energy from the oracle's own mass matrix, potential energy
+    from an INDEPENDENT forward kinematics (model/compile.py: m g z of every body's centre of mass),
+    dissipation = integral of sum_i d_i qdot_i^2 (joint damping) -- the balance closes to about a
+    percent of the energy converted (first-order integrator, soft gripper constraints)."""
+    A, _ = compiled_model
+    e = _env(oracle_model, 0)
+    q = e.arr("qpos")
+    q[:7] = [0.3, -0.2, 0.4, -1.8, 0.3, 1.9, 0.5]
+    e.forward()
+    g = 9.8
+    damp = np.asarray(A["dof_damping"], float)[:39]
+
+    def energy():
+        M = _dense_M(A, e)
+        qd = np.array(e.arr("qvel")[:39])
+        xpos, xquat = MC.forward_kinematics(A, np.array(q[:43]))
+        pe = 0.0
+        for b in range(1, 16):  # robot bodies
+            com = xpos[b] + MC.qrot(xquat[b], A["body_ipos"][b])
+            pe += float(A["body_mass"][b]) * g * com[2]
+        return 0.5 * qd @ M @ qd, pe, float(damp @ (qd * qd))
+
+    ke0, pe0, p0 = energy()
+    diss, p_prev = 0.0, p0
+    h = 1e-3
+    for _ in range(150):
+        e.step(1)
+        _, _, p = energy()
+        diss += 0.5 * (p + p_prev) * h
+        p_prev = p
+        assert np.all(np.abs(q[:7]) < 2.85)   # stays inside the joint ranges used here
+    ke1, pe1, _ = energy()
+    converted = pe0 - pe1
+    assert converted > 0.5, converted         # the arm did fall (J)
+    residual = (ke1 + pe1 + diss) - (ke0 + pe0)
+    assert abs(residual) < 0.03 * converted, (residual, converted, ke1, diss)
