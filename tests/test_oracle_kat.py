@@ -384,3 +384,47 @@ def test_mechanical_energy_balance_of_the_falling_arm(compiled_model, oracle_mod
     assert converted > 0.5, converted         # the arm did fall (J)
     residual = (ke1 + pe1 + diss) - (ke0 + pe0)
     assert abs(residual) < 0.03 * converted, (residual, converted, ke1, diss)
+
+
+def test_cube_cube_collision_conserves_momentum_in_free_fall(compiled_model, oracle_model):
+    """Two cubes collide in mid-air (one thrown down onto the other, off-centre so that they also spin):
+    contact forces are internal, so total linear momentum changes by gravity's impulse only and the
+    angular momentum about the pair's centre of mass is conserved -- Newton's third law through the
+    contact Jacobians (both prop parts of a row), friction cone included."""
+    A, _ = compiled_model
+    e = _env(oracle_model, 2)
+    q, v = e.arr("qpos"), e.arr("qvel")
+    s = 0.0155
+    q[15:22] = [0.5, 0.0, 0.80, 1, 0, 0, 0]
+    q[22:29] = [0.5 + 0.012, 0.006, 0.80 + 2 * s + 0.02, np.cos(0.2), 0, 0, np.sin(0.2)]
+    v[15 + 6 + 2] = -1.0   # cube 1 linear z velocity
+    e.freeze_robot(True)
+    e.forward()
+    m = 0.1
+    I = m / 3.0 * (s * s + s * s)   # solid cube about its centre: m (2 s)^2 / 6
+
+    def momenta():
+        xpos, xquat = MC.forward_kinematics(A, np.array(q[:43]))
+        P = np.zeros(3); L = np.zeros(3); com = np.zeros(3)
+        bodies = [16, 17]
+        for k, b in enumerate(bodies):
+            com += xpos[b] / 2
+        for k, b in enumerate(bodies):
+            lin = np.array(v[15 + 6 * k: 18 + 6 * k])
+            w_local = np.array(v[18 + 6 * k: 21 + 6 * k])       # free-joint angular velocity is body-local
+            w = MC.q2m(xquat[b]) @ w_local
+            P += m * lin
+            L += np.cross(xpos[b] - com, m * lin) + I * w
+        return P, L
+
+    P0, L0 = momenta()
+    hit = False
+    for k in range(60):
+        e.step(1)
+        hit = hit or e.ncon > 0 and (e.contacts()[:, 12] < 0).any()
+    P1, L1 = momenta()
+    assert hit and q[17] > 0.7 and q[24] > 0.7            # collided, still far above the table
+    expected = P0 + np.array([0, 0, -2 * m * 9.8 * 0.060])
+    assert np.abs(P1 - expected).max() < 2e-4, (P1, expected)
+    assert abs(v[15 + 2] - (-9.8 * 0.06)) > 0.05            # cube 0 was really pushed
+    assert np.abs(L1 - L0).max() < 2e-5, (L1, L0)
