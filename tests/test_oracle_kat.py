@@ -428,3 +428,24 @@ def test_cube_cube_collision_conserves_momentum_in_free_fall(compiled_model, ora
     assert np.abs(P1 - expected).max() < 2e-4, (P1, expected)
     assert abs(v[15 + 2] - (-9.8 * 0.06)) > 0.05            # cube 0 was really pushed
     assert np.abs(L1 - L0).max() < 2e-5, (L1, L0)
+
+
+def test_joint_limit_row_balances_a_torque_pushing_into_the_limit(compiled_model, oracle_model):
+    """Joint 6 of the arm (range -0.0175 .. 3.7525) is pushed towards its lower limit by 4 N m on top
+    of gravity compensation.  It must come to rest within a few milliradians of the limit (soft
+    constraint), with the limit row's force cancelling the push, and no other arm joint moving."""
+    e = _env(oracle_model, 0)
+    q = e.arr("qpos")
+    q[:7] = HOME
+    q[5] = 0.05
+    e.forward()
+    for _ in range(1500):
+        ctrl = e.arr("ctrl")
+        ctrl[:7] = e.arr("qfrc_bias")[:7]
+        ctrl[5] -= 4.0
+        e.step(1)
+    assert -0.0175 - 6e-3 < q[5] < -0.0175 + 1e-3, q[5]       # resting slightly inside the soft limit
+    assert abs(e.arr("qvel")[5]) < 1e-4 and np.abs(e.arr("qvel")[:7]).max() < 5e-3   # (lagged gravity compensation drifts)
+    assert abs(e.arr("qfrc_constraint")[5] - 4.0) < 0.05, e.arr("qfrc_constraint")[:7]
+    others = [0, 1, 2, 3, 4, 6]
+    assert np.abs(np.array(q[:7])[others] - np.array(HOME)[others]).max() < 2e-2
