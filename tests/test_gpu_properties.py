@@ -74,3 +74,53 @@ def test_sharding_over_ranks_does_not_change_results(full_batch):
     b = _run(np.arange(N // 2, N))
     assert np.array_equal(full_batch[0], np.concatenate([a[0], b[0]]))
     assert np.array_equal(full_batch[1], np.concatenate([a[1], b[1]]))
+
+
+def test_gpu_cube_collision_conserves_momentum(compiled_model):
+    """The oracle's momentum KAT (tests/test_oracle_kat.py) on the product path itself, in fp32: two
+    cubes collide in mid-air in 64 envs with different offsets; per env, total linear momentum changes
+    by gravity's impulse only and angular momentum about the pair's centre of mass is conserved."""
+    from mujoco_robot_environments_amd.model import compile as MC
+    from mujoco_robot_environments_amd.physics import BatchedPhysics
+    from mujoco_robot_environments_amd import rng
+    A, _ = compiled_model
+    n = 64
+    phys = BatchedPhysics(n, model=A)
+    s = 0.0155
+    phys.set_props(np.full(n, 2, np.int32), np.full((n, 4, 3), s, np.float32))
+    phys.reset()
+    u = rng.uniform(5, np.arange(n), [0], 4)[0]
+    qp = phys.qpos().copy()
+    qv = np.zeros((n, 39), np.float32)
+    for i in range(n):
+        yaw = 0.6 * u[i, 2]
+        qp[i, 15:22] = [0.5, 0.0, 0.80, 1, 0, 0, 0]
+        qp[i, 22:29] = [0.5 + 0.02 * (u[i, 0] - 0.5), 0.02 * (u[i, 1] - 0.5), 0.80 + 2 * s + 0.02, np.cos(yaw / 2), 0, 0, np.sin(yaw / 2)]
+        qv[i, 15 + 6 + 2] = -1.0 - 0.5 * u[i, 3]
+    phys.set_state(qp, qv)
+    m, I = 0.1, 0.1 / 3.0 * 2 * s * s
+
+    def momenta(qpos, qvel):
+        P = np.zeros((n, 3)); L = np.zeros((n, 3))
+        for i in range(n):
+            x = [qpos[i, 15:18].astype(float), qpos[i, 22:25].astype(float)]
+            com = 0.5 * (x[0] + x[1])
+            for k in range(2):
+                lin = qvel[i, 15 + 6 * k: 18 + 6 * k].astype(float)
+                R = MC.q2m(qpos[i, 18 + 7 * k: 22 + 7 * k].astype(float))
+                w = R @ qvel[i, 18 + 6 * k: 21 + 6 * k].astype(float)
+                P[i] += m * lin
+                L[i] += np.cross(x[k] - com, m * lin) + I * w
+        return P, L
+
+    P0, L0 = momenta(qp, qv)
+    phys.step(60, flags=2)   # robot frozen
+    q1, v1 = phys.qpos(), phys.qvel()
+    P1, L1 = momenta(q1, v1)
+    assert (q1[:, 17] > 0.7).all() and (q1[:, 24] > 0.7).all()
+    pushed = np.abs(v1[:, 17] - (-9.8 * 0.06)) > 0.05
+    assert pushed.mean() > 0.9                      # (nearly) every pair did collide
+    expected = P0 + np.array([0, 0, -2 * m * 9.8 * 0.060])
+    assert np.abs(P1 - expected).max() < 5e-4, np.abs(P1 - expected).max()
+    assert np.abs(L1 - L0).max() < 5e-5, np.abs(L1 - L0).max()
+    phys.close()
