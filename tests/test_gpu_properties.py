@@ -124,3 +124,49 @@ def test_gpu_cube_collision_conserves_momentum(compiled_model):
     assert np.abs(P1 - expected).max() < 5e-4, np.abs(P1 - expected).max()
     assert np.abs(L1 - L0).max() < 5e-5, np.abs(L1 - L0).max()
     phys.close()
+
+
+def test_gpu_arm_energy_balance(compiled_model):
+    """Work-energy theorem on the product path, judged by physics alone: 16 arms fall from different bent
+    poses with zero controls; kinetic energy from an INDEPENDENT mass matrix (sum_b J_b' I_b J_b in
+    numpy), potential energy from the numpy forward kinematics, dissipation = integral of the joint
+    damping power sampled every 5 steps.  The balance closes within 3 % of the energy converted."""
+    from mujoco_robot_environments_amd.model import compile as MC
+    from mujoco_robot_environments_amd.physics import BatchedPhysics
+    from mujoco_robot_environments_amd import rng
+    A, _ = compiled_model
+    n = 16
+    phys = BatchedPhysics(n, model=A)
+    phys.set_props(np.zeros(n, np.int32), np.full((n, 4, 3), 0.0155, np.float32))
+    phys.reset()
+    u = rng.uniform(9, np.arange(n), [0], 7)[0]
+    qp = phys.qpos().copy()
+    base = np.array([0.3, -0.2, 0.4, -1.8, 0.3, 1.9, 0.5])
+    for i in range(n):
+        qp[i, :7] = base + 0.3 * (u[i] - 0.5)
+    phys.set_state(qp, np.zeros((n, 39), np.float32))
+    damp = np.asarray(A["dof_damping"], float)[:39]
+
+    def energies(qpos, qvel):
+        out = np.zeros((n, 3))
+        for i in range(n):
+            q = qpos[i, :43].astype(float); qd = qvel[i, :39].astype(float)
+            M = MC.dense_mass_matrix(A, q)
+            xpos, xquat = MC.forward_kinematics(A, q)
+            pe = sum(float(A["body_mass"][b]) * 9.8 * (xpos[b] + MC.qrot(xquat[b], A["body_ipos"][b]))[2] for b in range(1, 16))
+            out[i] = [0.5 * qd[:15] @ M[:15, :15] @ qd[:15], pe, damp[:15] @ (qd[:15] ** 2)]
+        return out
+
+    e0 = energies(phys.qpos(), phys.qvel())
+    diss = np.zeros(n); prev = e0[:, 2]
+    for _ in range(30):
+        phys.step(5)
+        e = energies(phys.qpos(), phys.qvel())
+        diss += 0.5 * (e[:, 2] + prev) * 5e-3
+        prev = e[:, 2]
+    assert (np.abs(phys.qpos()[:, :7]) < 2.85).all()
+    converted = e0[:, 1] - e[:, 1]
+    assert (converted > 0.3).all(), converted
+    residual = (e[:, 0] + e[:, 1] + diss) - (e0[:, 0] + e0[:, 1])
+    assert (np.abs(residual) < 0.03 * converted).all(), (residual, converted)
+    phys.close()
