@@ -39,6 +39,15 @@ def algorithmic_bytes_per_env_step(nprops: np.ndarray) -> float:
     return float(np.mean(4.0 * (2 * (15 + 7 * n) + 4 * (15 + 6 * n) + 8)))
 
 
+def baseline_metric():
+    """BASELINE.json's metric string (the repo root travels with the bench)."""
+    try:
+        with open(os.path.join(ROOT, "BASELINE.json")) as f:
+            return json.load(f)["metric"]
+    except Exception:
+        return "env steps/sec (whole node), RearrangementEnv batch=4096 at 1/2/4/8 MI355X"
+
+
 def pmc_summary():
     """Latest committed PMC pass (profiles/*_pmc_summary.json: separate rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE / SQ_* runs of this same bench command); the counters cannot be read from inside
@@ -217,7 +226,7 @@ def main():
     avg_launch_s = (kern_ms / max(launches, 1)) * 1e-3
     achieved = bytes_per_launch / avg_launch_s / 1e9
     res = {
-        "metric": "env steps/sec (whole node), RearrangementEnv batch=4096 per GPU",
+        "metric": baseline_metric(),
         "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
