@@ -26,9 +26,13 @@ def main():
     ap.add_argument("--max-steps", type=int, default=None, help="pick/place pairs per episode (config: dataset.max_steps)")
     ap.add_argument("--gains", type=float, nargs=6, default=None, metavar=("KP_POS", "KD_POS", "KP_ORI", "KD_ORI", "KP_NULL", "KD_NULL"),
                     help="OSC gains instead of osc.yaml's (e.g. the tuned 221.2 59.5 543.0 169.6 81.6 36.2)")
+    ap.add_argument("--tuned-gains", action="store_true", help="config.apply_tuned_osc_gains (CMA-ES result for this arm model)")
     ap.add_argument("--render", action="store_true", help="overhead-camera observations (depth + RGB, CUDA tensors) instead of zero images")
     args = ap.parse_args()
     cfg = colour_separator_task_config()
+    if args.tuned_gains:
+        from mujoco_robot_environments_amd.config import apply_tuned_osc_gains
+        apply_tuned_osc_gains(cfg)
     if args.gains:
         g = cfg.robots.arm.controller_config.controller_params.gains
         g.position.kp, g.position.kd, g.orientation.kp, g.orientation.kd, g.nullspace.kp, g.nullspace.kd = args.gains

@@ -186,3 +186,17 @@ def colour_separator_task_config() -> Cfg:
     """transporter_network_data_generation.py:26-33 COLOR_SEPERATOR_TASK_CONFIG."""
     return compose("rearrangement", ["+name=colour_splitter", "task=rearrangement_w_targets",
                                      "arena/props=colour_splitter"])
+
+
+# OSC gains found by the batched CMA-ES run of examples/controller_tuning.py (256 candidates x 16
+# scenes, 5 generations, profiles/r01k_controller_tuning_256x16.log): fitness 2.6 against 523 for
+# osc.yaml's gains on this repo's (unverified) arm model, whose joint torques osc.yaml's gains saturate.
+TUNED_OSC_GAINS = {"position": (525.4, 215.2), "orientation": (766.6, 158.6), "nullspace": (22.6, 7.2)}
+
+
+def apply_tuned_osc_gains(cfg: Cfg) -> Cfg:
+    """Opt-in replacement of controller_params.gains by TUNED_OSC_GAINS (returns cfg)."""
+    g = cfg.robots.arm.controller_config.controller_params.gains
+    for k, (kp, kd) in TUNED_OSC_GAINS.items():
+        g[k].kp, g[k].kd = kp, kd
+    return cfg

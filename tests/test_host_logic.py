@@ -141,3 +141,16 @@ def test_prop_bboxes_from_a_segmentation_image_on_cpu():
     assert boxes[0, 2].tolist() == [3, 40, 4, 41]
     assert boxes[1, 3].tolist() == [63, 0, 63, 0]
     assert (boxes[0, 1] == -1).all() and (boxes[0, 3] == -1).all() and (boxes[1, :3] == -1).all()
+
+
+def test_tuned_gain_helper_only_touches_the_gains():
+    from mujoco_robot_environments_amd.config import (colour_separator_task_config, apply_tuned_osc_gains,
+                                                       TUNED_OSC_GAINS)
+    a, b = colour_separator_task_config(), apply_tuned_osc_gains(colour_separator_task_config())
+    ga = a.robots.arm.controller_config.controller_params
+    gb = b.robots.arm.controller_config.controller_params
+    assert ga.gains.position.kp == 350.0 and ga.gains.position.kd == 20.0      # osc.yaml:6-8 untouched by default
+    for k, (kp, kd) in TUNED_OSC_GAINS.items():
+        assert gb.gains[k].kp == kp and gb.gains[k].kd == kd
+    assert list(ga.nullspace.joint_config) == list(gb.nullspace.joint_config)
+    assert ga.convergence.position_threshold == gb.convergence.position_threshold
