@@ -161,6 +161,16 @@ int mre_render(mre_env*, const float* cam_pos, const float* cam_mat, float fovy_
  * the large kernel (the run the fallback must reproduce bit for bit).  Stats: out4 = {envs currently on the large
  * kernel, env launches re-run so far, promotions, demotions}. */
 int mre_set_fallback(mre_env*, int mode);
+
+/* Constraint solver (mjOption.solver; MuJoCo's enum values).  The model blob's `opt_solver`
+ * selects it at mre_create; the reference leaves MuJoCo's default, Newton
+ * (tasks/rearrangement.py:77-80 sets timestep / gravity / nconmax / njmax only), BASELINE.json's
+ * north_star prescribes PGS.  Both are built; mre_set_solver switches a live handle (the state,
+ * warm start included, carries over). mre_get_solver returns the current value. */
+#define MRE_SOLVER_PGS 0
+#define MRE_SOLVER_NEWTON 2
+int mre_set_solver(mre_env*, int solver);
+int mre_get_solver(mre_env*);
 int mre_get_fallback_stats(mre_env*, long long* out4);
 
 /* measurement support for bench.py: when enabled every step-kernel launch is

@@ -19,6 +19,9 @@ using namespace mre;
 extern "C" void mre_launch_step(const StepArgs* args, hipStream_t stream);
 extern "C" void mre_launch_settle(const StepArgs* args, hipStream_t stream);
 extern "C" void mre_launch_step_large(const StepArgs* args, hipStream_t stream);
+extern "C" void mre_launch_step_newton(const StepArgs* args, hipStream_t stream);
+extern "C" void mre_launch_settle_newton(const StepArgs* args, hipStream_t stream);
+extern "C" void mre_launch_step_large_newton(const StepArgs* args, hipStream_t stream);
 extern "C" void mre_launch_render(const RenderArgs* args, int row_groups, hipStream_t stream);
 extern "C" void mre_launch_prepare(const uint8_t* user_mask, const uint8_t* large, int N, uint8_t* mask_compact,
                                    uint8_t* mask_large, int* launch_info, const float* qpos, float* sv_qpos,
@@ -100,6 +103,16 @@ struct mre_env {
   long long n_reruns = 0, n_promotions = 0, n_demotions = 0;
 };
 
+// solver-specific instantiations of the step kernel (opt_solver of the model, mre_set_solver)
+static void launch_compact(const mre_env* e, const StepArgs& a, hipStream_t st, bool settle = false) {
+  const bool newton = e->hM.solver == MRE_SOLVER_NEWTON;
+  if (settle) { if (newton) mre_launch_settle_newton(&a, st); else mre_launch_settle(&a, st); }
+  else { if (newton) mre_launch_step_newton(&a, st); else mre_launch_step(&a, st); }
+}
+static void launch_large(const mre_env* e, const StepArgs& a, hipStream_t st) {
+  if (e->hM.solver == MRE_SOLVER_NEWTON) mre_launch_step_large_newton(&a, st); else mre_launch_step_large(&a, st);
+}
+
 // Launch the step kernel, optionally bracketed by HIP events on the handle's stream.
 //
 // Capacity fallback.  The compact kernel (8 workgroups/CU) holds at most NCON_MAX / NEFC_MAX /
@@ -128,7 +141,7 @@ static int launch_step(mre_env* e, const StepArgs& a, bool settle = false) {
   }
   const bool guarded = e->fallback && a.nsteps > 0 && (a.flags & F_NO_CONSTRAINTS) == 0;
   if (!guarded) {
-    if (settle) mre_launch_settle(&a, e->stream); else mre_launch_step(&a, e->stream);
+    launch_compact(e, a, e->stream, settle);
     HIPCHK(hipGetLastError());
   } else {
     const size_t N = (size_t)e->N;
@@ -147,11 +160,11 @@ static int launch_step(mre_env* e, const StepArgs& a, bool settle = false) {
       HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_fork, 0));
       StepArgs al = a;
       al.env_mask = e->mask_l; al.launch_info = e->launch_info;
-      mre_launch_step_large(&al, e->stream2);
+      launch_large(e, al, e->stream2);
       HIPCHK(hipGetLastError());
       HIPCHK(hipEventRecord(e->ev_join, e->stream2));
     }
-    if (settle) mre_launch_settle(&ac, e->stream); else mre_launch_step(&ac, e->stream);
+    launch_compact(e, ac, e->stream, settle);
     HIPCHK(hipGetLastError());
     if (run_large) HIPCHK(hipStreamWaitEvent(e->stream, e->ev_join, 0));
     HIPCHK(hipMemcpyAsync(e->h_launch_info, e->launch_info, N * 16, hipMemcpyDeviceToHost, e->stream));
@@ -212,7 +225,7 @@ static int launch_step(mre_env* e, const StepArgs& a, bool settle = false) {
                               e->ctrl, e->sv_ctrl, e->status, e->sv_status, e->converged, e->sv_converged, e->stream);
       StepArgs ar = a;
       ar.env_mask = e->mask_r; ar.launch_info = nullptr;
-      mre_launch_step_large(&ar, e->stream);
+      launch_large(e, ar, e->stream);
       HIPCHK(hipGetLastError());
       e->n_reruns += nrerun;
     }
@@ -317,6 +330,9 @@ static int build_model(const void* blob, size_t nbytes, DevModel& m) {
   RF("grip_forcerange", m.grip_forcerange, 2);
   RF("opt_timestep", &m.timestep, 1); RF("opt_gravity", m.gravity, 3); RF("opt_impratio", &m.impratio, 1);
   RF("opt_tolerance", &m.tolerance, 1); RI("opt_iterations", &m.iterations, 1);
+  m.solver = MRE_SOLVER_PGS;  // older blobs carry no opt_solver
+  { uint32_t c, cnt; uint64_t off; if (b.find("opt_solver", &c, &cnt, &off)) RI("opt_solver", &m.solver, 1); }
+  if (m.solver != MRE_SOLVER_PGS && m.solver != MRE_SOLVER_NEWTON) return fail(MRE_ERR_MODEL, "opt_solver must be 0 (PGS) or 2 (Newton)");
   RF("home_qpos", m.home_qpos, 7);
   float M0d[NV];
   RF("M0_diag", M0d, NV);
@@ -638,7 +654,7 @@ extern "C" int mre_render(mre_env* e, const float* cam_pos, const float* cam_mat
     e->events_used++;
     HIPCHK(hipEventRecord(e0, e->stream));
   }
-  mre_launch_step(&a, e->stream);
+  launch_compact(e, a, e->stream);
   HIPCHK(hipGetLastError());
   RenderArgs r;
   memset(&r, 0, sizeof(r));
@@ -684,7 +700,7 @@ extern "C" int mre_render(mre_env* e, const float* cam_pos, const float* cam_mat
       if (dmask) {
         StepArgs a0 = a;
         a0.env_mask = nullptr;
-        mre_launch_step(&a0, e->stream);
+        launch_compact(e, a0, e->stream);
         HIPCHK(hipGetLastError());
       }
       RenderArgs b = r;
@@ -718,6 +734,22 @@ extern "C" int mre_set_fallback(mre_env* e, int mode) {
     HIPCHK(hipMemcpy(e->d_large, e->h_large.data(), (size_t)e->N, hipMemcpyHostToDevice));
   }
   return MRE_OK;
+}
+
+extern "C" int mre_set_solver(mre_env* e, int solver) {
+  if (!e) return fail(MRE_ERR_ARG, "null handle");
+  if (solver != MRE_SOLVER_PGS && solver != MRE_SOLVER_NEWTON)
+    return fail(MRE_ERR_ARG, "mre_set_solver: solver is 0 (PGS) or 2 (Newton)");
+  HIPCHK(hipSetDevice(e->device));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  e->hM.solver = solver;
+  HIPCHK(hipMemcpy(e->dM, &e->hM, sizeof(DevModel), hipMemcpyHostToDevice));
+  return MRE_OK;
+}
+
+extern "C" int mre_get_solver(mre_env* e) {
+  if (!e) return fail(MRE_ERR_ARG, "null handle");
+  return e->hM.solver;
 }
 
 extern "C" int mre_get_fallback_stats(mre_env* e, long long* out4) {
@@ -858,7 +890,7 @@ extern "C" int mre_get_sites(mre_env* e, float* tcp_pos, float* eef_pose, float*
   StepArgs a;
   fill_args(e, a);
   a.nsteps = 0; a.trace = nullptr;
-  mre_launch_step(&a, e->stream);
+  launch_compact(e, a, e->stream);
   HIPCHK(hipGetLastError());
   const size_t N = (size_t)e->N;
   std::vector<float> hs(N * 16), hq;

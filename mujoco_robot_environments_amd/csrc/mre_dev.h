@@ -102,6 +102,7 @@ struct DevModel {
   // ---- options
   float timestep, gravity[3], impratio, tolerance;
   int iterations;
+  int solver;                    // 0 = PGS, 2 = Newton (mjtSolver); selects the kernel instantiation
   float home_qpos[7];
   float park_pos[NPROP][3];      // where inactive cube slots are parked
 };

@@ -42,10 +42,11 @@ struct alignas(8) Blk {
   uint8_t bslot : 4;        // slot of the second cube's Jacobian part (cube-cube contacts)
 };
 
-// bytes the solver's operand table needs on top of the body-frame region (mre_solver.h)
+// bytes the PGS solver's operand table needs on top of the body-frame region (mre_solver.h)
 constexpr int TAB_BYTES = 8 * (MAXBLK * 5 + 1) + 4 * 48;
 constexpr int FRAME_BYTES = (int)sizeof(OscSm) > 4 * (NB * 16) ? (int)sizeof(OscSm) : 4 * (NB * 16);
 constexpr int R1_MIN = TAB_BYTES - FRAME_BYTES > 0 ? TAB_BYTES - FRAME_BYTES : 4;
+constexpr int MD_LD = 17;  // row stride of the dense robot mass matrix (Newton): odd, conflict-free columns
 
 struct Sm {
   // state
@@ -55,15 +56,25 @@ struct Sm {
   // LDS regions reused along the step (lifetimes: S1a kinematics..factor, S1b velocity stage,
   // S1c collision + assembly, tick-boundary controller, S2 solve + integrate)
   union {  // body frames (S1a..S1c) | OSC scratch (tick boundary: nothing reads the frames between the
-           // assembly and the next position stage) | head of the solver's operand table (S2)
+           // assembly and the next position stage) | S2: head of the PGS operand table, or the Newton
+           // solver's generalized vectors
     struct { float xpos[NB][3], xquat[NB][4], xmat[NB][9]; };
     OscSm osc;
+#ifdef MRE_NEWTON
+    struct { float nw_Ma[NVP], nw_grad[NVP], nw_search[NVP], nw_Mv[NVP]; };
+#endif
   };
+#ifndef MRE_NEWTON
   char tab_room[R1_MIN];  // R1: (S2) tail of the operand table
+#endif
   float cdof[NRV][6];  // robot dofs only; cube cdofs are implicit (prop_cdof)
-  union {  // R2: contact geometry (S1c) | jar + forces (S2)
+  union {  // R2: contact geometry (S1c) | jar + forces (+ J*search, Newton) (S2)
     struct { float con_pos[NCON_MAX][3], con_frame[NCON_MAX][9], con_dist[NCON_MAX]; };
+#ifdef MRE_NEWTON
+    struct { float jar[NEFC_MAX], frc[NEFC_MAX], jv[NEFC_MAX]; };
+#else
     struct { float jar[NEFC_MAX], frc[NEFC_MAX]; };
+#endif
   };
   float com_robot[3];
   float site_xpos[NSITE][3], site_xmat[1][9];  // orientation of the controller site only
@@ -78,7 +89,7 @@ struct Sm {
   int ncon, nefc, nl, nrrow, npp, overflow, solver_iters;
   uint8_t con_pair[NCON_MAX], con_rslot[NCON_MAX], con_bslot[NCON_MAX], con_b1[NCON_MAX], con_b2[NCON_MAX];
   uint16_t lim_info[NRV + 1];
-  // ---- contiguous block [JpA .. sched]: written only after collision; hosts the per-lane
+  // ---- contiguous block [JpA .. hdr]: written only after collision; hosts the per-lane
   // clip buffers of the narrow phase (mre_solver.h: collide)
   // Its head doubles as the home of what only S1a / S1b need (dead before the collision):
   union {
@@ -90,6 +101,18 @@ struct Sm {
     float Jr[NRROW_MAX][NRV];
     struct { float cdof_dot[NV][6], cvel[NB][6], cfrc[NB][6]; };  // velocity-stage temporaries (S1b)
   };
+#ifdef MRE_NEWTON
+  // ---- Newton solver (mre_newton.h)
+  float efc_R[NEFC_MAX], efc_aref[NEFC_MAX];  // regulariser and reference acceleration of every row
+  float frc_r[NRROW_MAX];                      // forces of the rows with a robot part, in slot order
+  float con_fric[NCON_MAX];                    // friction coefficient of every contact
+  float hc[NCON_MAX][6];                       // cone Hessian of contacts in the middle zone (00,01,02,11,12,22)
+  float Md[NRV][MD_LD];                        // dense robot block of the mass matrix
+  float W[NV * (NV + 1) / 2];                  // Cholesky factor, packed by columns (transposed solve)
+  uint8_t rstate[NEFC_MAX];                    // row state after the last constraint update
+  uint8_t clist[NPROP][NCON_MAX];              // contacts touching cube p (bit 7: the cube is part B)
+  uint8_t ccount[NPROP], cpl_robot, cpl_cubes; // coupling of the Hessian blocks (robot-cube p, cube p-q)
+#else
   float Br[NRROW_MAX][NRV];
   // one 64-byte record per constraint block (scalar-row triple g -> record g, contact c -> record
   // 8 + c): [0:3] regulariser R of its rows, [3:6] aref (S1) -> efc_b (S2), [6:9] 1/A_ii,
@@ -97,15 +120,16 @@ struct Sm {
   alignas(16) float blkrec[MAXBLK][16];
   // constraint blocks (scalar row or 3-row contact) and their island schedule
   Blk blk[MAXBLK];
-  uint16_t hdr[NEFC_MAX];  // per row: robot slot | propA << 8 | propB << 12
   uint8_t sched[MAXBLK][8];  // per (schedule step, island < 5): block index or SCHED_NONE
+#endif
+  uint16_t hdr[NEFC_MAX];  // per row: robot slot | propA << 8 | propB << 12
 
   int nblk, nsched;
 };
 
 // Residency is the budget the whole layout is built around: 160 KB of LDS per CU, allocated in
 // 512-byte granules -- 8 workgroups per CU for the compact capacities, 6 for the large ones.
-#ifdef MRE_LARGE_CAPS
+#if defined(MRE_LARGE_CAPS)
 static_assert(sizeof(Sm) <= 27136, "large-capacity Sm must fit 6 workgroups per CU");
 #else
 static_assert(sizeof(Sm) <= 20480, "compact Sm must fit 8 workgroups per CU");
@@ -424,6 +448,9 @@ MRE_PHASE_FN void solve_robot_par(const DevModel* M, const float* LD, const floa
 
 }  // namespace mre
 #include "mre_solver.h"
+#ifdef MRE_NEWTON
+#include "mre_newton.h"
+#endif
 #include "mre_osc.h"
 namespace mre {
 
@@ -691,8 +718,10 @@ MRE_DEV void step_body(const StepArgs& a, Sm& s) {
       collide(M, s, l);
       MRE_STAMP(2);
       assemble_constraints(M, s, l);
+#ifndef MRE_NEWTON
       solve_robot_rows(s, l);
       assemble_blocks(M, s, l);
+#endif
       MRE_STAMP(3);
       hw_ncon = max(hw_ncon, s.ncon); hw_nefc = max(hw_nefc, s.nefc); hw_nsched = max(hw_nsched, s.nsched);
       hw_nrrow = max(hw_nrrow, s.nrrow); hw_npp = max(hw_npp, s.npp);
@@ -717,7 +746,11 @@ MRE_DEV void step_body(const StepArgs& a, Sm& s) {
     const bool clamped = smooth_forces(M, s, l);
     MRE_STAMP(5);
     if (constrained) {
+#ifdef MRE_NEWTON
+      newton_solve(M, s, l);
+#else
       solve_constraints(M, s, l);
+#endif
       MRE_STAMP(6);
     } else {
       if (l < NVP) { s.qacc[l] = s.qacc_smooth[l]; s.qfrc_con[l] = 0.f; }
@@ -790,29 +823,47 @@ MRE_DEV void step_body(const StepArgs& a, Sm& s) {
   }
 }
 
+// Entry points.  This file is compiled four times (lib.py): {compact, large capacities} x {PGS,
+// Newton}; the kernel and launcher names carry the variant so that profiler summaries tell them apart.
+#ifdef MRE_NEWTON
+#define MRE_VARIANT(name) name##_newton
+#else
+#define MRE_VARIANT(name) name
+#endif
+
 #ifdef MRE_LARGE_CAPS
-// large-capacity instantiation (second translation unit, see mre_dev.h)
-__global__ __launch_bounds__(64, 2) void k_step_large(StepArgs a) {
+// large-capacity instantiation (mre_dev.h)
+__global__ __launch_bounds__(64, 2) void MRE_VARIANT(k_step_large)(StepArgs a) {
   __shared__ Sm s;
   step_body(a, s);
 }
 }  // namespace mre
 
-extern "C" void mre_launch_step_large(const mre::StepArgs* args, hipStream_t stream) {
-  hipLaunchKernelGGL(mre::k_step_large, dim3(args->N), dim3(64), 0, stream, *args);
+extern "C" void MRE_VARIANT(mre_launch_step_large)(const mre::StepArgs* args, hipStream_t stream) {
+  hipLaunchKernelGGL(mre::MRE_VARIANT(k_step_large), dim3(args->N), dim3(64), 0, stream, *args);
 }
 #else
 // control ticks: mre_step / mre_rollout / mre_run_controller
-__global__ __launch_bounds__(64, 2) void k_step(StepArgs a) {
+__global__ __launch_bounds__(64, 2) void MRE_VARIANT(k_step)(StepArgs a) {
   __shared__ Sm s;
   step_body(a, s);
 }
 
 // frozen-robot settling after prop placement (mre_place_props): same body, own name in traces
-__global__ __launch_bounds__(64, 2) void k_settle(StepArgs a) {
+__global__ __launch_bounds__(64, 2) void MRE_VARIANT(k_settle)(StepArgs a) {
   __shared__ Sm s;
   step_body(a, s);
 }
+
+#ifdef MRE_NEWTON
+}  // namespace mre
+extern "C" void mre_launch_step_newton(const mre::StepArgs* args, hipStream_t stream) {
+  hipLaunchKernelGGL(mre::k_step_newton, dim3(args->N), dim3(64), 0, stream, *args);
+}
+extern "C" void mre_launch_settle_newton(const mre::StepArgs* args, hipStream_t stream) {
+  hipLaunchKernelGGL(mre::k_settle_newton, dim3(args->N), dim3(64), 0, stream, *args);
+}
+#else
 
 // Physics.reset() + arm home pose (tasks/rearrangement.py:302-306); cubes parked
 __global__ __launch_bounds__(64) void k_reset(const DevModel* M, int N, float* qpos, float* qvel,
@@ -912,4 +963,5 @@ extern "C" void mre_launch_step(const mre::StepArgs* args, hipStream_t stream) {
 extern "C" void mre_launch_settle(const mre::StepArgs* args, hipStream_t stream) {
   hipLaunchKernelGGL(mre::k_settle, dim3(args->N), dim3(64), 0, stream, *args);
 }
+#endif  // MRE_NEWTON
 #endif  // MRE_LARGE_CAPS

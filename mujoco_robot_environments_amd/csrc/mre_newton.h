@@ -1,0 +1,526 @@
+// mre_newton.h -- MuJoCo's Newton solver (mj_solPrimal with flg_Newton) for one environment per
+// wavefront; compiled into the step kernels built with -DMRE_NEWTON.  Included by
+// mre_kernels.hip after mre_solver.h (constraint assembly, row storage).
+//
+// The reference never sets opt.solver (tasks/rearrangement.py:77-80), so its MuJoCo runs Newton:
+// primal problem in qacc,   cost(a) = 1/2 (a - a_smooth)' M (a - a_smooth) + s(J a - aref),
+// search direction -H^-1 grad with H = M + J' diag(D_active) J + sum_cone J_c' H_c J_c, exact
+// line search along it, termination on scale * improvement or scale * |grad| < tolerance.
+//
+// Lane mappings.
+//   lane = dof (0..38) for generalized vectors, for the rows of H and of its Cholesky factor.
+//   lane = contact / lane = scalar row for the constraint update and the line-search terms.
+//   H is assembled with the matrix rows in registers (lane j holds H[j][0..38]): one uniform pass
+//   over the constraint rows, every lane adds t_j * J_i[c] for the dofs c of the blocks row i
+//   touches (J_i[c] by v_readlane: the lane index is a compile-time constant).  H is block
+//   structured -- robot 15 x 15, one 6 x 6 block per cube, couplings only where a contact joins two
+//   of them -- and the factorisation H = W W' (W upper triangular, eliminated from the last dof to
+//   the first: cubes before the robot, like mj_factorM) skips absent blocks by wave-uniform
+//   branches, fill-in between blocks included.  The solve W y = g rides along the elimination; the
+//   transposed solve W' x = y needs the columns of W, which go through LDS once (packed, 3 KB).
+#pragma once
+
+namespace mre {
+
+constexpr int NW_QUAD = 0, NW_SAT = 1, NW_CONE = 4;
+constexpr int NW_LS_MAX = 20;       // line-search evaluations at most (opt.ls_iterations = 50 in fp64)
+constexpr float NW_LS_TOL = 0.01f;  // opt.ls_tolerance
+
+MRE_DEV float rdlane(float v, int lane) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+MRE_DEV int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+MRE_DEV float unif(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
+
+// J_i[dof of this lane]; h = hdr[i] (wave-uniform), lp / lk = cube and local dof of a cube lane
+MRE_DEV float nw_Jl(const Sm& s, int i, int h, int l, int lp, int lk) {
+  const int rs = h & 0xFF, pa = (h >> 8) & 0xF, pb = (h >> 12) & 0xF;
+  float j = 0.f;
+  if (l < NRV) {
+    if (rs != HDR_NONE) j = s.Jr[rs][l];
+  } else if (l < NV) {
+    if (pa == lp) j = jpA(s, i)[lk];
+    else if (pb == lp) j = jpB(s, i)[lk];
+  }
+  return j;
+}
+
+// (M v)[dof of this lane]; v in LDS
+MRE_DEV float nw_mulM(const Sm& s, int l, float mdiag, const float* v) {
+  float acc = 0.f;
+  if (l < NRV) {
+#pragma unroll
+    for (int c = 0; c < NRV; c++) acc = fmaf(s.Md[l][c], v[c], acc);
+  } else if (l < NV) {
+    acc = mdiag * v[l];
+  }
+  return acc;
+}
+
+// One elliptic contact (condim 3) of mj_constraintUpdate: zone, forces, cost, cone Hessian.
+// jar -> U = (mu j0, fr j1, fr j2), N = U0, T = |U12|; top zone N >= mu T (no force), bottom
+// zone mu N + T <= 0 (quadratic), else the middle zone with cost Dm/2 (N - mu T)^2.
+struct NwContact { float f0, f1, f2, cost; int st; };
+template <bool HESS>
+MRE_DEV NwContact nw_contact(float j0, float j1, float j2, float D0, float D1, float D2, float fr, float mu,
+                             float* hc) {
+  NwContact o;
+  const float U0 = j0 * mu, U1 = j1 * fr, U2 = j2 * fr;
+  const float N = U0, T = sqrtf(U1 * U1 + U2 * U2);
+  if (N >= mu * T || (T <= 0.f && N >= 0.f)) {
+    o.f0 = o.f1 = o.f2 = 0.f; o.cost = 0.f; o.st = NW_SAT;
+  } else if (mu * N + T <= 0.f || (T <= 0.f && N < 0.f)) {
+    o.f0 = -D0 * j0; o.f1 = -D1 * j1; o.f2 = -D2 * j2;
+    o.cost = 0.5f * (D0 * j0 * j0 + D1 * j1 * j1 + D2 * j2 * j2);
+    o.st = NW_QUAD;
+  } else {
+    const float Dm = D0 / fmaxf(mu * mu * (1.f + mu * mu), kMinVal);
+    const float NT = N - mu * T, iT = 1.0f / T;
+    o.cost = 0.5f * Dm * NT * NT;
+    o.f0 = -Dm * NT * mu;
+    o.f1 = -o.f0 * iT * U1 * fr;
+    o.f2 = -o.f0 * iT * U2 * fr;
+    o.st = NW_CONE;
+    if (HESS) {
+      // d2/djar2: in U coordinates [1, -mu U'/T; ., mu N/T^3 UU' + (mu^2 - mu N/T) I], then
+      // pre/post multiplied by diag(mu, fr, fr) and scaled by Dm
+      const float a = mu * N * iT * iT * iT, dg = mu * mu - mu * N * iT;
+      hc[0] = Dm * mu * mu;
+      hc[1] = Dm * mu * fr * (-mu * U1 * iT);
+      hc[2] = Dm * mu * fr * (-mu * U2 * iT);
+      hc[3] = Dm * fr * fr * (a * U1 * U1 + dg);
+      hc[4] = Dm * fr * fr * (a * U1 * U2);
+      hc[5] = Dm * fr * fr * (a * U2 * U2 + dg);
+    }
+  }
+  return o;
+}
+
+// mj_constraintUpdate on `jar` (LDS): lane = scalar row and lane = contact.  FULL: forces,
+// states and cone Hessians are stored; otherwise only the cost is evaluated.  Returns s(jar).
+template <bool FULL>
+MRE_DEV float nw_update(Sm& s, int l, int nscalar, int ncon, float mu_scale, const float* jar) {
+  float cost = 0.f;
+  if (l < nscalar) {
+    const float D = 1.0f / s.efc_R[l], j = jar[l];
+    const bool act = l < 7 || j < 0.f;
+    if (FULL) {
+      const float f = act ? -D * j : 0.f;
+      s.frc[l] = f; s.frc_r[l] = f;
+      s.rstate[l] = act ? NW_QUAD : NW_SAT;
+    }
+    cost = act ? 0.5f * D * j * j : 0.f;
+  }
+  if (l < ncon) {
+    const int i = nscalar + 3 * l;
+    const float D0 = 1.0f / s.efc_R[i], D1 = 1.0f / s.efc_R[i + 1], D2 = 1.0f / s.efc_R[i + 2];
+    const float fr = s.con_fric[l];
+    float hc[6];
+    const NwContact o = nw_contact<FULL>(jar[i], jar[i + 1], jar[i + 2], D0, D1, D2, fr, fr * mu_scale, hc);
+    cost += o.cost;
+    if (FULL) {
+      s.frc[i] = o.f0; s.frc[i + 1] = o.f1; s.frc[i + 2] = o.f2;
+      const int rs = s.con_rslot[l];
+      if (rs != HDR_NONE) { s.frc_r[rs] = o.f0; s.frc_r[rs + 1] = o.f1; s.frc_r[rs + 2] = o.f2; }
+      s.rstate[i] = s.rstate[i + 1] = s.rstate[i + 2] = (uint8_t)o.st;
+      if (o.st == NW_CONE) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) s.hc[l][k] = hc[k];
+      }
+    }
+  }
+  return wave_sum(cost);
+}
+
+// (J' f)[dof of this lane]: robot lanes run over the robot-row slots, cube lanes over the
+// contacts that touch their cube
+MRE_DEV float nw_JTf(const Sm& s, int l, int lp, int lk, int nscalar) {
+  float acc = 0.f;
+  if (l < NRV) {
+    const int n = s.nrrow;
+    for (int rs = 0; rs < n; rs++) acc = fmaf(s.Jr[rs][l], s.frc_r[rs], acc);
+  } else if (l < NV && lp < s.nprops) {
+    const int n = s.ccount[lp];
+    for (int t = 0; t < n; t++) {
+      const int e = s.clist[lp][t], c = e & 0x7F;
+      const float* J = (e & 0x80) ? s.JpB[3 * s.con_bslot[c]] : s.JpA[3 * c];
+      const float* f = &s.frc[nscalar + 3 * c];
+      acc = fmaf(J[lk], f[0], acc);
+      acc = fmaf(J[6 + lk], f[1], acc);
+      acc = fmaf(J[12 + lk], f[2], acc);
+    }
+  }
+  return acc;
+}
+
+// hh[c] += t * J[c] over the dofs c of the blocks the row touches (robot: has_r; cubes pa, pb)
+MRE_DEV void nw_rank1(float (&hh)[NV], float t, float J, bool has_r, int pa, int pb) {
+  if (has_r) {
+#pragma unroll
+    for (int c = 0; c < NRV; c++) hh[c] = fmaf(t, rdlane(J, c), hh[c]);
+  }
+#pragma unroll
+  for (int p = 0; p < NPROP; p++) {
+    if (pa == p || pb == p) {
+#pragma unroll
+      for (int k = 0; k < 6; k++) hh[NRV + 6 * p + k] = fmaf(t, rdlane(J, NRV + 6 * p + k), hh[NRV + 6 * p + k]);
+    }
+  }
+}
+
+// One elimination step of H = W W' (columns NV-1 .. 0) with the solve W y = g riding along.
+// Lane j holds row j; after the step hh[K] = W[j][K].  nbm = earlier blocks (bit 0 robot, bit
+// 1 + p cube p) that column K reaches, fill-in included.
+template <int K>
+MRE_DEV void nw_elim_col(float (&hh)[NV], float& g, float& y, float& dinv, int l, unsigned nbm) {
+  constexpr int blk = K < NRV ? 0 : 1 + (K - NRV) / 6;
+  constexpr int b0 = blk == 0 ? 0 : NRV + 6 * (blk - 1);
+  const float piv = rdlane(hh[K], K);
+  const float d = __builtin_amdgcn_rsqf(fmaxf(piv, 1e-20f));
+  const float u = hh[K] * d;
+  hh[K] = u;
+  const float yk = rdlane(g, K) * d;
+  g = fmaf(-u, yk, g);
+  y = (l == K) ? yk : y;
+  dinv = (l == K) ? d : dinv;
+#pragma unroll
+  for (int c = K - 1; c >= b0; c--) hh[c] = fmaf(-u, rdlane(u, c), hh[c]);
+  if constexpr (blk > 0) {
+#pragma unroll
+    for (int q = blk - 1; q >= 1; q--) {
+      if (nbm & (1u << q)) {
+#pragma unroll
+        for (int k = 5; k >= 0; k--) {
+          const int c = NRV + 6 * (q - 1) + k;
+          hh[c] = fmaf(-u, rdlane(u, c), hh[c]);
+        }
+      }
+    }
+    if (nbm & 1u) {
+#pragma unroll
+      for (int c = NRV - 1; c >= 0; c--) hh[c] = fmaf(-u, rdlane(u, c), hh[c]);
+    }
+  }
+}
+template <int K, int KEND>
+MRE_DEV void nw_elim_range(float (&hh)[NV], float& g, float& y, float& dinv, int l, unsigned nbm) {
+  nw_elim_col<K>(hh, g, y, dinv, l, nbm);
+  if constexpr (K > KEND) nw_elim_range<K - 1, KEND>(hh, g, y, dinv, l, nbm);
+}
+
+struct NwPoint { float alpha, cost, d1, d2; };
+
+// Per-lane constants of the solver phases
+struct NwLane {
+  int lp, lk;       // cube and local dof of a cube lane (lp = -1: not a cube lane)
+  bool lact;        // this lane owns an active dof
+  float mdiag;      // cube lanes: diagonal entry of M
+  float mu_scale;   // mu = friction * sqrt(R1 / R0) = friction / sqrt(impratio)
+  float scale;      // 1 / (meaninertia * nv)
+};
+MRE_DEV NwLane nw_lane(const DevModel* M, const Sm& s, int l) {
+  NwLane c;
+  c.lp = (l >= NRV && l < NV) ? (l - NRV) / 6 : -1;
+  c.lk = (l >= NRV && l < NV) ? (l - NRV) % 6 : 0;
+  c.lact = l < NRV || (c.lp >= 0 && c.lp < s.nprops);
+  c.mdiag = c.lp >= 0 ? (c.lk < 3 ? s.prop_mass[c.lp] : s.prop_inertia[c.lp][c.lk - 3]) : 0.f;
+  c.mu_scale = __builtin_amdgcn_rsqf(fmaxf(M->impratio, kMinVal));
+  float msum = M->M0_diag_robot_sum;
+  for (int p = 0; p < s.nprops; p++)
+    msum += 3.f * s.prop_mass[p] + s.prop_inertia[p][0] + s.prop_inertia[p][1] + s.prop_inertia[p][2];
+  c.scale = 1.0f / msum;
+  return c;
+}
+
+// constraint update on s.jar, qfrc_con = J' f, gradient; returns the primal cost.
+// In: s.qacc (current iterate), s.nw_Ma.  Out: s.frc, s.rstate, s.hc, s.qfrc_con, s.nw_grad.
+MRE_DEV float nw_update_gradient(Sm& s, int l, const NwLane& c, int nscalar, int ncon) {
+  const float sc = nw_update<true>(s, l, nscalar, ncon, c.mu_scale, s.jar);
+  __syncthreads();
+  const float qc = nw_JTf(s, l, c.lp, c.lk, nscalar);
+  const bool on = l < NV && c.lact;
+  const float fs = on ? s.qfrc_smooth[l] : 0.f, as = on ? s.qacc_smooth[l] : 0.f;
+  const float qa = on ? s.qacc[l] : 0.f, Ma = on ? s.nw_Ma[l] : 0.f;
+  if (l < NVP) {
+    s.qfrc_con[l] = on ? qc : 0.f;
+    s.nw_grad[l] = on ? Ma - fs - qc : 0.f;
+  }
+  const float cost = sc + wave_sum(0.5f * (Ma - fs) * (qa - as));
+  __syncthreads();
+  return cost;
+}
+
+// Phase 1: dense robot M, warm start (the cheaper of qacc_warmstart and qacc_smooth in primal
+// cost), first constraint update and gradient.  Returns the cost.
+MRE_PHASE_FN float nw_setup(const DevModel* M, Sm& s, int l) {
+  const NwLane c = nw_lane(M, s, l);
+  const int nefc = s.nefc, ncon = s.ncon, nscalar = 7 + s.nl;
+  for (int e = l; e < NRV * MD_LD; e += 64) (&s.Md[0][0])[e] = 0.f;
+  __syncthreads();
+  for (int e = l; e < NMR; e += 64) {
+    const int i = M->M_i[e], j = M->M_j[e];
+    const float v = s.qM[e];
+    s.Md[i][j] = v; s.Md[j][i] = v;
+  }
+  __syncthreads();
+  const bool on = l < NV && c.lact;
+  const float fs = on ? s.qfrc_smooth[l] : 0.f, as = on ? s.qacc_smooth[l] : 0.f;
+  float qa = on ? s.qacc_ws[l] : 0.f;
+  float Ma = on ? nw_mulM(s, l, c.mdiag, s.qacc_ws) : 0.f;
+  for (int i = l; i < nefc; i += 64) {
+    const float aref = s.efc_aref[i];
+    s.jar[i] = row_dot(s, i, s.qacc_ws) - aref;
+    s.jv[i] = row_dot(s, i, s.qacc_smooth) - aref;
+  }
+  __syncthreads();
+  const float gauss = wave_sum(0.5f * (Ma - fs) * (qa - as));
+  const float cost_ws = gauss + nw_update<false>(s, l, nscalar, ncon, c.mu_scale, s.jar);
+  const float cost_sm = nw_update<false>(s, l, nscalar, ncon, c.mu_scale, s.jv);
+  if (cost_ws > cost_sm || !(cost_ws == cost_ws)) {
+    qa = as; Ma = fs;  // M qacc_smooth = qfrc_smooth
+    for (int i = l; i < nefc; i += 64) s.jar[i] = s.jv[i];
+  }
+  if (l < NVP) { s.qacc[l] = qa; s.nw_Ma[l] = Ma; }
+  __syncthreads();
+  return nw_update_gradient(s, l, c, nscalar, ncon);
+}
+
+// Phase 2: search = -H^-1 grad.  H = M + J' D J (+ cone Hessians) with its rows in registers,
+// block-sparse factorisation H = W W', both triangular solves.
+MRE_PHASE_FN void nw_direction(const DevModel* M, Sm& s, int l) {
+  const NwLane c = nw_lane(M, s, l);
+  const int nefc = s.nefc, nscalar = 7 + s.nl, nprops = s.nprops;
+  const int lp = c.lp, lk = c.lk;
+  float hh[NV];
+#pragma unroll
+  for (int k = 0; k < NV; k++) {
+    float v = 0.f;
+    if (k < NRV) { if (l < NRV) v = s.Md[l][k]; }
+    else if (l == k) v = c.lact ? c.mdiag : 1.0f;
+    hh[k] = v;
+  }
+  for (int i = 0; i < nefc;) {
+    const int st = uni(s.rstate[i]);
+    const bool contact = i >= nscalar;
+    if (st == NW_SAT) { i += contact ? 3 : 1; continue; }
+    const int h = uni(s.hdr[i]);
+    const int rs = h & 0xFF, pa = (h >> 8) & 0xF, pb = (h >> 12) & 0xF;
+    const bool has_r = rs != HDR_NONE;
+    if (st == NW_QUAD) {
+      const float J = nw_Jl(s, i, h, l, lp, lk);
+      const float t = J * (1.0f / s.efc_R[i]);
+      nw_rank1(hh, t, J, has_r, pa, pb);
+      i += 1;
+    } else {
+      // contact in the middle zone: J_c' H_c J_c with the 3 x 3 cone Hessian
+      const int cc = (i - nscalar) / 3;
+      const int h1 = has_r ? h + 1 : h, h2 = has_r ? h + 2 : h;  // robot slots of rows 1, 2
+      const float J0 = nw_Jl(s, i, h, l, lp, lk), J1 = nw_Jl(s, i + 1, h1, l, lp, lk),
+                  J2 = nw_Jl(s, i + 2, h2, l, lp, lk);
+      const float H00 = s.hc[cc][0], H01 = s.hc[cc][1], H02 = s.hc[cc][2], H11 = s.hc[cc][3],
+                  H12 = s.hc[cc][4], H22 = s.hc[cc][5];
+      const float t0 = H00 * J0 + H01 * J1 + H02 * J2, t1 = H01 * J0 + H11 * J1 + H12 * J2,
+                  t2 = H02 * J0 + H12 * J1 + H22 * J2;
+      nw_rank1(hh, t0, J0, has_r, pa, pb);
+      nw_rank1(hh, t1, J1, has_r, pa, pb);
+      nw_rank1(hh, t2, J2, has_r, pa, pb);
+      i += 3;
+    }
+  }
+  // symbolic elimination over the blocks (node 0 robot, node 1 + p cube p), cubes last to first
+  unsigned adj[5];
+  {
+    const unsigned cr = s.cpl_robot, cq = s.cpl_cubes;
+    adj[0] = 0u;
+#pragma unroll
+    for (int p = 0; p < NPROP; p++) {
+      unsigned a = (cr >> p) & 1u;  // robot
+#pragma unroll
+      for (int q = 0; q < NPROP; q++)
+        if (q != p && ((cq >> cube_pair_bit(p, q)) & 1u)) a |= 1u << (1 + q);
+      adj[1 + p] = a;
+    }
+#pragma unroll
+    for (int a = 4; a >= 1; a--) {
+      const unsigned nb = adj[a] & ((1u << a) - 1u);  // earlier blocks reached by block a
+#pragma unroll
+      for (int b = 1; b < 4; b++)
+        if (b < a && ((nb >> b) & 1u)) adj[b] |= nb & ~(1u << b);
+    }
+#pragma unroll
+    for (int a = 1; a < 5; a++) adj[a] = (unsigned)uni((int)adj[a]);
+  }
+  float g = l < NVP ? s.nw_grad[l] : 0.f, y = 0.f, dinv = 1.0f;
+  if (nprops > 3) nw_elim_range<NRV + 23, NRV + 18>(hh, g, y, dinv, l, adj[4] & 0xFu);
+  if (nprops > 2) nw_elim_range<NRV + 17, NRV + 12>(hh, g, y, dinv, l, adj[3] & 0x7u);
+  if (nprops > 1) nw_elim_range<NRV + 11, NRV + 6>(hh, g, y, dinv, l, adj[2] & 0x3u);
+  if (nprops > 0) nw_elim_range<NRV + 5, NRV>(hh, g, y, dinv, l, adj[1] & 0x1u);
+  nw_elim_range<NRV - 1, 0>(hh, g, y, dinv, l, 0u);
+  // ---- W' x = y: columns of W through LDS (packed by columns: (j, k), j <= k at k(k+1)/2 + j)
+#pragma unroll
+  for (int k = 0; k < NV; k++)
+    if (l <= k) s.W[k * (k + 1) / 2 + l] = hh[k];
+  __syncthreads();
+  {
+    const int base = l < NV ? l * (l + 1) / 2 : 0;
+    const int nva = NRV + 6 * nprops;  // inactive cube blocks: x = 0
+    for (int j = 0; j < nva; j++) {
+      const float cw = (j < l && l < NV) ? s.W[base + j] : 0.f;
+      const float xj = rdlane(y * dinv, j);
+      y = fmaf(-cw, xj, y);
+    }
+  }
+  const float x = y * dinv;
+  if (l < NVP) s.nw_search[l] = (l < NV && c.lact) ? -x : 0.f;
+  __syncthreads();
+}
+
+// Phase 3: exact line search along s.nw_search (PrimalSearch), move, constraint update, gradient.
+// Returns the new cost; s.scratch[0] = step (0 when no step was possible), s.scratch[1] = |grad|.
+MRE_PHASE_FN float nw_search_move(const DevModel* M, Sm& s, int l) {
+  const NwLane c = nw_lane(M, s, l);
+  const int nefc = s.nefc, ncon = s.ncon, nscalar = 7 + s.nl;
+  const float tol = M->tolerance, mu_scale = c.mu_scale;
+  const bool on = l < NV && c.lact;
+  const float fs = on ? s.qfrc_smooth[l] : 0.f, as = on ? s.qacc_smooth[l] : 0.f;
+  float qa = on ? s.qacc[l] : 0.f, Ma = on ? s.nw_Ma[l] : 0.f;
+  const float sv = on ? s.nw_search[l] : 0.f;
+  const float Mv = on ? nw_mulM(s, l, c.mdiag, s.nw_search) : 0.f;
+  for (int i = l; i < nefc; i += 64) s.jv[i] = row_dot(s, i, s.nw_search);
+  __syncthreads();
+  const float snorm = sqrtf(wave_sum(sv * sv));
+  float alpha = 0.f;
+  if (snorm >= kMinVal) {
+    const float gtol = tol * NW_LS_TOL * snorm / c.scale;
+    const float g0 = wave_sum(0.5f * (Ma - fs) * (qa - as));
+    const float g1 = wave_sum(sv * (Ma - fs));
+    const float g2 = wave_sum(0.5f * sv * Mv);
+    // per-lane terms: one scalar row and one contact
+    float sq0 = 0.f, sq1 = 0.f, sq2 = 0.f, sj = 0.f, svv = 0.f;
+    const bool s_on = l < nscalar, s_eq = l < 7;
+    if (s_on) {
+      const float D = 1.0f / s.efc_R[l];
+      sj = s.jar[l]; svv = s.jv[l];
+      sq0 = 0.5f * D * sj * sj; sq1 = D * sj * svv; sq2 = 0.5f * D * svv * svv;
+    }
+    float cq0 = 0.f, cq1 = 0.f, cq2 = 0.f, U0 = 0.f, V0 = 0.f, UU = 0.f, UV = 0.f, VV = 0.f, Dm = 0.f, mu = 0.f;
+    const bool c_on = l < ncon;
+    if (c_on) {
+      const int i = nscalar + 3 * l;
+      const float fr = s.con_fric[l];
+      mu = fr * mu_scale;
+#pragma unroll
+      for (int r = 0; r < 3; r++) {
+        const float D = 1.0f / s.efc_R[i + r], j = s.jar[i + r], v = s.jv[i + r];
+        cq0 += 0.5f * D * j * j; cq1 += D * j * v; cq2 += 0.5f * D * v * v;
+      }
+      const float U1 = s.jar[i + 1] * fr, U2 = s.jar[i + 2] * fr, V1 = s.jv[i + 1] * fr, V2 = s.jv[i + 2] * fr;
+      U0 = s.jar[i] * mu; V0 = s.jv[i] * mu;
+      UU = U1 * U1 + U2 * U2; UV = U1 * V1 + U2 * V2; VV = V1 * V1 + V2 * V2;
+      Dm = (1.0f / s.efc_R[i]) / fmaxf(mu * mu * (1.f + mu * mu), kMinVal);
+    }
+    auto eval = [&](float a) {  // PrimalEval
+      float q0 = 0.f, q1 = 0.f, q2 = 0.f, ec = 0.f, e1 = 0.f, e2 = 0.f;
+      if (s_on && (s_eq || sj + a * svv < 0.f)) { q0 = sq0; q1 = sq1; q2 = sq2; }
+      if (c_on) {
+        const float N = U0 + a * V0, Tsqr = UU + a * (2.f * UV + a * VV);
+        bool quad = false;
+        if (Tsqr <= 0.f) {
+          quad = N < 0.f;
+        } else {
+          const float T = sqrtf(Tsqr);
+          if (N >= mu * T) {
+          } else if (mu * N + T <= 0.f) {
+            quad = true;
+          } else {
+            const float iT = 1.0f / T;
+            const float b = UV + a * VV;
+            const float N1 = V0, T1 = b * iT, T2 = VV * iT - b * b * iT * iT * iT;
+            const float NT = N - mu * T, w = N1 - mu * T1;
+            ec = 0.5f * Dm * NT * NT;
+            e1 = Dm * NT * w;
+            e2 = Dm * (w * w - NT * mu * T2);
+          }
+        }
+        if (quad) { q0 += cq0; q1 += cq1; q2 += cq2; }
+      }
+      NwPoint p;
+      p.alpha = a;
+      p.cost = wave_sum(ec + q0 + a * (q1 + a * q2)) + g0 + a * (g1 + a * g2);
+      p.d1 = wave_sum(e1 + q1 + 2.f * a * q2) + g1 + 2.f * a * g2;
+      p.d2 = wave_sum(e2 + 2.f * q2) + 2.f * g2;
+      return p;
+    };
+    const NwPoint p0 = eval(0.f);
+    if (p0.d2 >= kMinVal) {
+      NwPoint p1 = eval(-p0.d1 / p0.d2);
+      if (!(p1.cost <= p0.cost)) p1 = p0;
+      if (fabsf(p1.d1) < gtol) {
+        alpha = p1.alpha;
+      } else {
+        // convex restriction: Newton steps in alpha, guarded by the bracket [lo, hi] once it exists
+        NwPoint lo = p0, hi = p0;
+        bool have_lo = p0.d1 < 0.f, have_hi = !have_lo;
+        bool found = false;
+        for (int it = 0; it < NW_LS_MAX; it++) {
+          if (p1.d1 < 0.f) { if (!have_lo || p1.alpha > lo.alpha) { lo = p1; have_lo = true; } }
+          else { if (!have_hi || p1.alpha < hi.alpha) { hi = p1; have_hi = true; } }
+          float a = p1.alpha - p1.d1 / p1.d2;
+          if (have_lo && have_hi && !(a > lo.alpha && a < hi.alpha)) a = 0.5f * (lo.alpha + hi.alpha);
+          // fp32: once the step no longer moves alpha the slope cannot be resolved any further
+          if (fabsf(a - p1.alpha) <= 2e-7f * fabsf(p1.alpha)) break;
+          p1 = eval(a);
+          if (fabsf(p1.d1) < gtol) { found = true; break; }
+        }
+        if (found) alpha = p1.alpha;
+        else if (have_lo && have_hi) alpha = lo.cost < hi.cost ? lo.alpha : hi.alpha;
+        else alpha = p1.cost < p0.cost ? p1.alpha : 0.f;
+      }
+    }
+  }
+  if (l == 0) { s.scratch[0] = alpha; s.scratch[1] = 0.f; }
+  if (alpha == 0.f) { __syncthreads(); return 0.f; }
+  qa = fmaf(alpha, sv, qa);
+  Ma = fmaf(alpha, Mv, Ma);
+  if (l < NVP) { s.qacc[l] = qa; s.nw_Ma[l] = Ma; }
+  for (int i = l; i < nefc; i += 64) s.jar[i] = fmaf(alpha, s.jv[i], s.jar[i]);
+  __syncthreads();
+  const float cost = nw_update_gradient(s, l, c, nscalar, ncon);
+  const float gr = l < NVP ? s.nw_grad[l] : 0.f;
+  const float gn = sqrtf(wave_sum(gr * gr));
+  if (l == 0) s.scratch[1] = gn;
+  __syncthreads();
+  return cost;
+}
+
+// ------------------------------------------------------------- mj_fwdConstraint (Newton)
+// Runs from the kernel body (the phases above are real functions and never nest calls).
+// On exit: s.qacc, s.qfrc_con = J' f, s.solver_iters.
+MRE_DEV void newton_solve(const DevModel* M, Sm& s, int l) {
+  const float tol = M->tolerance;
+  const int max_iter = M->iterations;
+  float msum = M->M0_diag_robot_sum;
+  for (int p = 0; p < s.nprops; p++)
+    msum += 3.f * s.prop_mass[p] + s.prop_inertia[p][0] + s.prop_inertia[p][1] + s.prop_inertia[p][2];
+  const float scale = 1.0f / msum;
+  float cost = nw_setup(M, s, l);
+  int iter = 0;
+  while (iter < max_iter) {
+    nw_direction(M, s, l);
+    const float newcost = nw_search_move(M, s, l);
+    const float alpha = s.scratch[0], gradnorm = s.scratch[1];
+    if (alpha == 0.f) break;
+    const float improvement = scale * (cost - newcost);
+    cost = newcost;
+    iter++;
+    // fp32: a cost difference below the resolution of the cost itself is no improvement
+    if (improvement < tol + 2e-7f * scale * fabsf(cost) || scale * gradnorm < tol) break;
+  }
+  if (l < NVP && !(l < NV)) s.qacc[l] = 0.f;
+  if (l == 0) s.solver_iters = iter;
+  __syncthreads();
+}
+
+}  // namespace mre

@@ -30,7 +30,14 @@ constexpr int TAB_OFF = MAXBLK * 5;
 constexpr int TAB_ZEROS = 48;
 static_assert(TAB_BYTES == 8 * (TAB_OFF + 1) + 4 * TAB_ZEROS, "operand table size");
 
+#ifndef MRE_NEWTON
 MRE_DEV void build_schedule(const DevModel* M, Sm& s);
+#endif
+// bit of the unordered cube pair {p, q} in Sm::cpl_cubes: (0,1) (0,2) (0,3) (1,2) (1,3) (2,3)
+MRE_DEV constexpr int cube_pair_bit(int p, int q) {
+  const int a = p < q ? p : q, b = p < q ? q : p;
+  return a == 0 ? b - 1 : (a == 1 ? b + 1 : 5);
+}
 
 MRE_DEV float prop_invM(const Sm& s, int p, int k) {
   return 1.0f / ((k < 3) ? s.prop_mass[p] : s.prop_inertia[p][k - 3]);
@@ -60,7 +67,7 @@ MRE_DEV void geom_pose(const DevModel* M, const Sm& s, int g, float* p, float* R
 MRE_PHASE_FN void collide(const DevModel* M, Sm& s, int l) {
   // per-lane clip buffers alias the Jacobian pools (contiguous Jp|Jr|Br, unused until assembly)
   // [JpA .. sched] is one contiguous block of arrays that are only written after collision
-  static_assert(offsetof(Sm, sched) + sizeof(((Sm*)0)->sched) - offsetof(Sm, JpA) >= sizeof(float) * 64 * COLL_BUF,
+  static_assert(offsetof(Sm, hdr) + sizeof(((Sm*)0)->hdr) - offsetof(Sm, JpA) >= sizeof(float) * 64 * COLL_BUF,
                 "clip buffers do not fit");
   float* buf = &s.JpA[0][0] + l * COLL_BUF;
   float normal[3] = {0.f, 0.f, 1.f};
@@ -168,9 +175,14 @@ MRE_DEV int row_blk(const Sm& s, int i, int& r) {
   r = cr % 3;
   return 8 + cr / 3;
 }
+#ifdef MRE_NEWTON
+MRE_DEV float& rowR(Sm& s, int i) { return s.efc_R[i]; }
+MRE_DEV float& rowB(Sm& s, int i) { return s.efc_aref[i]; }
+#else
 MRE_DEV float& rowR(Sm& s, int i) { int r; const int b = row_blk(s, i, r); return s.blkrec[b][r]; }
 MRE_DEV float& rowB(Sm& s, int i) { int r; const int b = row_blk(s, i, r); return s.blkrec[b][3 + r]; }
 MRE_DEV float& rowAinv(Sm& s, int i) { int r; const int b = row_blk(s, i, r); return s.blkrec[b][6 + r]; }
+#endif
 
 // prop parts of contact row i: part A (first cube of the contact) is indexed by contact row,
 // part B exists only for cube-cube contacts (slot con_bslot)
@@ -205,6 +217,7 @@ MRE_DEV float row_dot(const Sm& s, int i, const float* vec) {
   return acc;
 }
 
+#ifndef MRE_NEWTON
 // Br = M^-1 Jr' (lane = robot slot; register-resident sparse solve unrolled over the dof tree).
 // A function of its own: the unrolled solve wants ~100 registers for the factor entries.
 MRE_PHASE_FN void solve_robot_rows(Sm& s, int l) {
@@ -218,6 +231,8 @@ MRE_PHASE_FN void solve_robot_rows(Sm& s, int l) {
   }
   __syncthreads();
 }
+
+#endif  // !MRE_NEWTON
 
 // ------------------------- mj_makeConstraint + mj_makeImpedance + reference + project
 MRE_PHASE_FN void assemble_constraints(const DevModel* M, Sm& s, int l) {
@@ -266,13 +281,34 @@ MRE_PHASE_FN void assemble_constraints(const DevModel* M, Sm& s, int l) {
     s.nefc = base + 3 * kept;
     s.nrrow = rnext;
     s.npp = bnext;
+#ifdef MRE_NEWTON
+    // per-cube contact lists and the block coupling of the Newton Hessian (mre_newton.h)
+    int cnt[NPROP] = {0, 0, 0, 0};
+    unsigned cr = 0u, cc = 0u;
+    for (int c = 0; c < kept; c++) {
+      const int cb1 = s.con_b1[c], cb2 = s.con_b2[c];
+      int pa = -1, pb = -1;
+      if (cb1 >= NRB) pa = cb1 - NRB;
+      if (cb2 >= NRB) { if (pa < 0) pa = cb2 - NRB; else pb = cb2 - NRB; }
+      if (pa >= 0) s.clist[pa][cnt[pa]++] = (uint8_t)c;
+      if (pb >= 0) s.clist[pb][cnt[pb]++] = (uint8_t)(c | 0x80);
+      if (s.con_rslot[c] != HDR_NONE && pa >= 0) cr |= 1u << pa;
+      if (pb >= 0) cc |= 1u << cube_pair_bit(pa, pb);
+    }
+    for (int p = 0; p < NPROP; p++) s.ccount[p] = (uint8_t)cnt[p];
+    s.cpl_robot = (uint8_t)cr; s.cpl_cubes = (uint8_t)cc;
+    s.nsched = 0; s.nblk = 0;
+#else
     build_schedule(M, s);
+#endif
   }
   __syncthreads();
   const int nefc = s.nefc, nl = s.nl;
   // ---- zero robot slots and the scalar-triple records (rows past a short last triple stay 0)
   for (int e = l; e < s.nrrow * NRV; e += 64) (&s.Jr[0][0])[e] = 0.f;
+#ifndef MRE_NEWTON
   for (int e = l; e < 8 * 16; e += 64) (&s.blkrec[0][0])[e] = 0.f;
+#endif
   __syncthreads();
   // ---- rows (lane = row)
   for (int i = l; i < nefc; i += 64) {
@@ -372,11 +408,16 @@ MRE_PHASE_FN void assemble_constraints(const DevModel* M, Sm& s, int l) {
     const float efc_margin = fric_row ? 0.f : margin;
     const float aref = -B * vel - K * imp * (pos - efc_margin);
     rowR(s, i) = R; rowB(s, i) = aref;
+#ifdef MRE_NEWTON
+    if (i >= 7 + nl && (i - 7 - nl) % 3 == 0) s.con_fric[(i - 7 - nl) / 3] = M->pair_friction[s.con_pair[(i - 7 - nl) / 3]][0];
+#else
     if (i >= 7 + nl && (i - 7 - nl) % 3 == 0) s.blkrec[8 + (i - 7 - nl) / 3][15] = M->pair_friction[s.con_pair[(i - 7 - nl) / 3]][0];
+#endif
   }
   __syncthreads();
 }
 
+#ifndef MRE_NEWTON
 // second half of the assembly, after the kernel body has run solve_robot_rows (Br = M^-1 Jr'); the
 // phases do not nest calls, so none of them needs a callee-saved register (= scratch) to keep
 // state across one
@@ -576,8 +617,9 @@ MRE_PHASE_FN void solve_constraints(const DevModel* M, Sm& s, int l) {
       const float U0 = j0 * mu, U1 = j1 * fr0, U2 = j2 * fr0;
       const float N = U0, T = sqrtf(U1 * U1 + U2 * U2);
       float f0, f1, f2;
-      if (mu * N >= T || (T <= 0.f && N >= 0.f)) { f0 = f1 = f2 = 0.f; }
-      else if (N + mu * T <= 0.f || (T <= 0.f && N < 0.f)) { f0 = -D * j0; f1 = -D1 * j1; f2 = -D2 * j2; }
+      // top zone (jar in the polar cone): no force; bottom zone (-D*jar inside the friction cone)
+      if (N >= mu * T || (T <= 0.f && N >= 0.f)) { f0 = f1 = f2 = 0.f; }
+      else if (mu * N + T <= 0.f || (T <= 0.f && N < 0.f)) { f0 = -D * j0; f1 = -D1 * j1; f2 = -D2 * j2; }
       else {
         const float Dm = D / fmaxf(mu * mu * (1.f + mu * mu), kMinVal);
         const float NT = N - mu * T;
@@ -814,5 +856,7 @@ MRE_PHASE_FN void solve_constraints(const DevModel* M, Sm& s, int l) {
   if (l == 0) s.solver_iters = iters;
   __syncthreads();
 }
+
+#endif  // !MRE_NEWTON
 
 }  // namespace mre

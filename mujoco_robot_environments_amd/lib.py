@@ -13,7 +13,7 @@ from typing import Optional
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 _SO = os.path.join(_CSRC, "libmre.so")
 _SOURCES = ["mre_kernels.hip", "mre_render.hip", "mre_api.cpp"]
-_HEADERS = ["mre_dev.h", "mre_math.h", "mre_collide.h", "mre_solver.h", "mre_osc.h",
+_HEADERS = ["mre_dev.h", "mre_math.h", "mre_collide.h", "mre_solver.h", "mre_newton.h", "mre_osc.h",
             os.path.join("..", "..", "include", "mre.h")]
 _LIB: Optional[C.CDLL] = None
 
@@ -26,7 +26,7 @@ EXPORTS = [
     "mre_set_trace", "mre_osc_set_target", "mre_osc_configure", "mre_gripper_set",
     "mre_run_controller", "mre_get_sites", "mre_get_status", "mre_get_solver_stats",
     "mre_profile_enable", "mre_profile_read", "mre_set_env_id_offset", "mre_set_env_order",
-    "mre_set_fallback", "mre_get_fallback_stats", "mre_osc_configure_env", "mre_set_env_ids", "mre_set_render_colours", "mre_render",
+    "mre_set_fallback", "mre_get_fallback_stats", "mre_set_solver", "mre_get_solver", "mre_osc_configure_env", "mre_set_env_ids", "mre_set_render_colours", "mre_render",
 ]
 
 
@@ -55,8 +55,11 @@ def build(force: bool = False, verbose: bool = False) -> str:
         base.insert(1, "-Rpass-analysis=kernel-resource-usage")
     bdir = os.path.join(_CSRC, "_build")
     os.makedirs(bdir, exist_ok=True)
-    # the step kernel is instantiated twice (compact / large constraint capacities, mre_dev.h)
+    # the step kernel is instantiated four times: {compact, large constraint capacities (mre_dev.h)}
+    # x {PGS, Newton (mre_newton.h)}
     units = [("kernels", "mre_kernels.hip", []), ("kernels_large", "mre_kernels.hip", ["-DMRE_LARGE_CAPS"]),
+             ("kernels_newton", "mre_kernels.hip", ["-DMRE_NEWTON"]),
+             ("kernels_large_newton", "mre_kernels.hip", ["-DMRE_LARGE_CAPS", "-DMRE_NEWTON"]),
              ("render", "mre_render.hip", []), ("api", "mre_api.cpp", [])]
     procs = [(name, subprocess.Popen(base + flags + ["-c", os.path.join(_CSRC, src), "-o",
                                                      os.path.join(bdir, name + ".o")]))
@@ -115,6 +118,8 @@ def lib() -> C.CDLL:
     L.mre_profile_enable.argtypes = [vp, ci]
     L.mre_profile_read.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(ci)]
     L.mre_set_fallback.argtypes = [vp, ci]
+    L.mre_set_solver.argtypes = [vp, ci]
+    L.mre_get_solver.argtypes = [vp]
     L.mre_set_render_colours.argtypes = [vp, fp, fp]
     L.mre_render.argtypes = [vp, fp, fp, C.c_float, ci, ci, fp, fp, fp, fp]
     L.mre_osc_configure_env.argtypes = [vp, fp, fp, fp]

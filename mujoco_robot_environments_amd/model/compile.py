@@ -498,6 +498,9 @@ def compile_scene(scene: dict = None) -> Dict[str, np.ndarray]:
     A["opt_impratio"] = np.array([o["impratio"]])
     A["opt_tolerance"] = np.array([o["tolerance"]])
     A["opt_iterations"] = np.array([o["iterations"]], np.int32)
+    A["opt_solver"] = np.array([{"PGS": 0, "Newton": 2}[o.get("solver", "PGS")]], np.int32)  # mjtSolver
+    A["opt_ls_iterations"] = np.array([o.get("ls_iterations", 50)], np.int32)
+    A["opt_ls_tolerance"] = np.array([o.get("ls_tolerance", 0.01)])
 
     # tendon + actuators
     t = scene["tendon"]

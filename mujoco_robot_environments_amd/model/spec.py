@@ -276,8 +276,10 @@ def default_scene(cfg: Optional[Dict] = None, max_props: int = 4) -> dict:
             gravity=tuple(cfg.get("gravity", (0.0, 0.0, -9.8))),  # config/rearrangement.yaml:4
             integrator="implicitfast",   # inherited from panda_nohand.xml [3P]
             cone="elliptic", impratio=10.0,  # inherited from 2f85.xml [3P]
-            solver="PGS",                 # BASELINE.json north_star (MuJoCo default: Newton)
-            iterations=100, tolerance=1e-8,  # MuJoCo defaults
+            # BASELINE.json's north_star prescribes PGS; the reference leaves MuJoCo's default, Newton
+            # (tasks/rearrangement.py:77-80).  Both solvers are built; cfg["solver"] selects.
+            solver=str(cfg.get("solver", "PGS")),
+            iterations=100, tolerance=1e-8, ls_iterations=50, ls_tolerance=0.01,  # MuJoCo defaults
         ),
         arm_joints=[f"joint{i + 1}" for i in range(7)],
         eef_site="attachment_site",   # models/robot_arm.py:38

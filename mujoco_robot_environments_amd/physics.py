@@ -39,9 +39,14 @@ def _ptr(t) -> Optional[int]:
 
 
 class BatchedPhysics:
+    SOLVERS = {"PGS": 0, "Newton": 2}  # mjtSolver values (include/mre.h)
+
     def __init__(self, num_envs: int, scene: Optional[dict] = None, device: int = 0,
-                 model: Optional[dict] = None):
+                 model: Optional[dict] = None, solver: Optional[str] = None):
         self.model = model if model is not None else _compile.compile_scene(scene)
+        if solver is not None:  # override the model's opt_solver ("PGS" / "Newton")
+            self.model = dict(self.model)
+            self.model["opt_solver"] = np.array([self.SOLVERS[solver]], np.int32)
         self.blob = _compile.to_blob(self.model)
         self.num_envs = int(num_envs)
         self.device_id = int(device)
@@ -67,6 +72,15 @@ class BatchedPhysics:
 
     def sync(self):
         check(_lib.lib().mre_sync(self._h), "mre_sync")
+
+    def set_solver(self, solver: str) -> None:
+        """mjOption.solver of a live handle: "PGS" or "Newton" (state and warm start carry over)."""
+        check(_lib.lib().mre_set_solver(self._h, self.SOLVERS[solver]), "mre_set_solver")
+
+    @property
+    def solver(self) -> str:
+        code = _lib.lib().mre_get_solver(self._h)
+        return {v: k for k, v in self.SOLVERS.items()}[code]
 
     @property
     def stream_ptr(self) -> int:

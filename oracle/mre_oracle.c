@@ -57,14 +57,15 @@ struct mro_model {
   double ten_coef[2];
   int act_dof[MRO_NU];
   double act_ctrlrange[MRO_NU][2], grip_gainprm, grip_biasprm[3], grip_forcerange[2];
-  double timestep, gravity[3], impratio, tolerance;
-  int iterations;
+  double timestep, gravity[3], impratio, tolerance, ls_tolerance;
+  int iterations, solver, ls_iterations; /* solver: 0 = PGS, 2 = Newton (mjtSolver) */
   int arm_dof[7], eef_site, tcp_site, prop_bodyid[MRO_MAXPROP];
   double home_qpos[7];
 };
 
 typedef struct {
   double pos[3], frame[9], dist, includemargin, friction[5], solref[2], solimp[5], mu;
+  double H[9]; /* cone Hessian of the middle zone (Newton), already scaled */
   int geom1, geom2, body1, body2, efc_address;
 } mro_contact_t;
 
@@ -101,6 +102,9 @@ struct mro_data {
       qacc_smooth[MRO_MAXV], qfrc_constraint[MRO_MAXV], qacc[MRO_MAXV];
   int grip_clamped;
   int solver_iters;
+  /* solver selection overrides (-1 / 0 = take the model's) and Newton telemetry */
+  int solver_override, iterations_override, ls_evals, efc_state[MRO_MAXEFC];
+  double tolerance_override, solver_cost, solver_grad;
 };
 
 /* ------------------------------------------------------------------ vec3 */
@@ -295,6 +299,12 @@ mro_model* mro_model_load(const void* blob, size_t nbytes) {
   LD1(timestep, "opt_timestep"); if (blob_d(b, "opt_gravity", m->gravity, 3) < 0) goto fail;
   LD1(impratio, "opt_impratio"); LD1(tolerance, "opt_tolerance");
   LI1(iterations, "opt_iterations");
+  /* optional entries (older blobs: PGS, MuJoCo's line-search defaults) */
+  m->solver = 0; m->ls_iterations = 50; m->ls_tolerance = 0.01;
+  { blob_entry e;
+    if (blob_find(b, "opt_solver", &e)) blob_i(b, "opt_solver", &m->solver, 1);
+    if (blob_find(b, "opt_ls_iterations", &e)) blob_i(b, "opt_ls_iterations", &m->ls_iterations, 1);
+    if (blob_find(b, "opt_ls_tolerance", &e)) blob_d(b, "opt_ls_tolerance", &m->ls_tolerance, 1); }
   LI(arm_dof, 7); LI1(eef_site, "eef_site"); LI1(tcp_site, "tcp_site");
   if (blob_i(b, "prop_bodyid", m->prop_bodyid, MRO_MAXPROP) < 0) goto fail;
   LD(home_qpos, 7);
@@ -310,6 +320,7 @@ mro_data* mro_data_new(const mro_model* m, int nprops, const double* prop_size) 
   d->efc_AR = (double*)calloc((size_t)MRO_MAXEFC * MRO_MAXEFC, sizeof(double));
   d->efc_B = (double(*)[MRO_MAXV])calloc((size_t)MRO_MAXEFC, sizeof(double[MRO_MAXV]));
   d->nprops = nprops;
+  d->solver_override = -1;
   memcpy(d->body_mass, m->body_mass, sizeof(d->body_mass));
   memcpy(d->body_inertia, m->body_inertia, sizeof(d->body_inertia));
   memcpy(d->body_invweight0, m->body_invweight0, sizeof(d->body_invweight0));
@@ -367,6 +378,12 @@ void mro_set_caps(mro_data* d, int ncon_cap, int nefc_cap, int nrrow_cap, int np
   d->ncon_cap = ncon_cap; d->nefc_cap = nefc_cap; d->nrrow_cap = nrrow_cap; d->npp_cap = npp_cap;
 }
 int mro_overflow(const mro_data* d) { return d->overflow; }
+void mro_set_solver(mro_data* d, int solver, int iterations, double tolerance) {
+  d->solver_override = solver; d->iterations_override = iterations; d->tolerance_override = tolerance;
+}
+int mro_ls_evals(const mro_data* d) { return d->ls_evals; }
+double mro_solver_grad(const mro_data* d) { return d->solver_grad; }
+double mro_solver_cost(const mro_data* d) { return d->solver_cost; }
 int mro_solver_iters(const mro_data* d) { return d->solver_iters; }
 int mro_ncon(const mro_data* d) { return d->ncon; }
 int mro_nefc(const mro_data* d) { return d->nefc; }
@@ -1127,30 +1144,88 @@ static void fwd_acceleration(const mro_model* m, mro_data* d) {
 }
 
 /* -------------------------------------------- mj_constraintUpdate (force) */
-static void constraint_update(const mro_model* m, mro_data* d, const double* jar, double* force) {
+enum { ST_QUADRATIC = 0, ST_SATISFIED = 1, ST_CONE = 4 };
+/* One elliptic contact (condim 3) of mj_constraintUpdate_impl: U = (mu jar0, f0 jar1, f1 jar2),
+ * N = U0, T = |U12|.  Top zone N >= mu T: jar lies in the polar cone, no force.  Bottom zone
+ * mu N + T <= 0: -D jar lies inside the friction cone, quadratic cost.  Middle zone: cost
+ * Dm/2 (N - mu T)^2 with Dm = D0 / (mu^2 (1 + mu^2)).  Returns the cost; force = -dcost/djar;
+ * H (optional) = d2cost/djar2 in the middle zone. */
+double mro_cone_eval(const double* jar, const double* D, const double* friction, double mu,
+                     double* force, double* H, int* state) {
+  double U[3] = {jar[0] * mu, jar[1] * friction[0], jar[2] * friction[1]};
+  double N = U[0], T = sqrt(U[1] * U[1] + U[2] * U[2]), cost = 0;
+  if (N >= mu * T || (T <= 0 && N >= 0)) {
+    force[0] = force[1] = force[2] = 0;
+    *state = ST_SATISFIED;
+  } else if (mu * N + T <= 0 || (T <= 0 && N < 0)) {
+    for (int j = 0; j < 3; j++) {
+      force[j] = -D[j] * jar[j];
+      cost += 0.5 * D[j] * jar[j] * jar[j];
+    }
+    *state = ST_QUADRATIC;
+  } else {
+    double den = mu * mu * (1 + mu * mu);
+    double Dm = D[0] / (den > MINVAL ? den : MINVAL);
+    double NT = N - mu * T;
+    cost = 0.5 * Dm * NT * NT;
+    force[0] = -Dm * NT * mu;
+    force[1] = -force[0] / T * U[1] * friction[0];
+    force[2] = -force[0] / T * U[2] * friction[1];
+    *state = ST_CONE;
+    if (H) {
+      /* in U coordinates [1, -mu U'/T; ., mu N/T^3 UU' + (mu^2 - mu N/T) I], then pre/post
+       * multiplied by diag(mu, friction) and scaled by Dm */
+      double h[9], scl[3] = {mu, friction[0], friction[1]};
+      h[0] = 1;
+      for (int j = 1; j < 3; j++) h[j] = h[3 * j] = -mu * U[j] / T;
+      for (int j = 1; j < 3; j++)
+        for (int k = 1; k < 3; k++)
+          h[3 * j + k] = mu * N / (T * T * T) * U[j] * U[k] + (j == k ? mu * mu - mu * N / T : 0.0);
+      for (int j = 0; j < 3; j++)
+        for (int k = 0; k < 3; k++) H[3 * j + k] = Dm * scl[j] * scl[k] * h[3 * j + k];
+    }
+  }
+  return cost;
+}
+
+/* force (and optionally the cost s(jar), the row states and the cone Hessians of contacts in the
+ * middle zone) from jar = J*qacc - aref; mj_constraintUpdate_impl for equality, limit and
+ * elliptic-contact rows */
+static double constraint_update_full(const mro_model* m, mro_data* d, const double* jar,
+                                     double* force, int* state, int flg_hess) {
   (void)m;
+  double cost = 0;
   for (int i = 0; i < d->nefc;) {
     int type = d->efc_type[i];
-    if (type == EFC_EQ) { force[i] = -d->efc_D[i] * jar[i]; i++; continue; }
-    if (type == EFC_LIMIT) { force[i] = jar[i] < 0 ? -d->efc_D[i] * jar[i] : 0.0; i++; continue; }
-    const mro_contact_t* con = &d->contact[d->efc_id[i]];
-    double mu = con->mu, U[3];
-    U[0] = jar[i] * mu; U[1] = jar[i + 1] * con->friction[0]; U[2] = jar[i + 2] * con->friction[1];
-    double N = U[0], T = sqrt(U[1] * U[1] + U[2] * U[2]);
-    if (mu * N >= T || (T <= 0 && N >= 0)) {
-      force[i] = force[i + 1] = force[i + 2] = 0;
-    } else if (N + mu * T <= 0 || (T <= 0 && N < 0)) {
-      for (int j = 0; j < 3; j++) force[i + j] = -d->efc_D[i + j] * jar[i + j];
-    } else {
-      double den = mu * mu * (1 + mu * mu);
-      double Dm = d->efc_D[i] / (den > MINVAL ? den : MINVAL);
-      double NT = N - mu * T;
-      force[i] = -Dm * NT * mu;
-      force[i + 1] = -force[i] / T * U[1] * con->friction[0];
-      force[i + 2] = -force[i] / T * U[2] * con->friction[1];
+    if (type == EFC_EQ) {
+      force[i] = -d->efc_D[i] * jar[i];
+      cost += 0.5 * d->efc_D[i] * jar[i] * jar[i];
+      if (state) state[i] = ST_QUADRATIC;
+      i++;
+      continue;
     }
+    if (type == EFC_LIMIT) {
+      if (jar[i] < 0) {
+        force[i] = -d->efc_D[i] * jar[i];
+        cost += 0.5 * d->efc_D[i] * jar[i] * jar[i];
+        if (state) state[i] = ST_QUADRATIC;
+      } else {
+        force[i] = 0;
+        if (state) state[i] = ST_SATISFIED;
+      }
+      i++;
+      continue;
+    }
+    mro_contact_t* con = &d->contact[d->efc_id[i]];
+    int st;
+    cost += mro_cone_eval(jar + i, d->efc_D + i, con->friction, con->mu, force + i, flg_hess ? con->H : NULL, &st);
+    if (state) state[i] = state[i + 1] = state[i + 2] = st;
     i += 3;
   }
+  return cost;
+}
+static void constraint_update(const mro_model* m, mro_data* d, const double* jar, double* force) {
+  constraint_update_full(m, d, jar, force, NULL, 0);
 }
 
 /* mju_QCQP2: min 0.5 x'Ax + x'b  s.t. sum (x_i/d_i)^2 <= r^2 ; returns active flag */
@@ -1178,13 +1253,14 @@ static int qcqp2(double* res, const double* Ain, const double* bin, const double
 }
 
 /* ------------------------------------------------------------- mj_solPGS */
-static void sol_pgs(const mro_model* m, mro_data* d) {
+static void sol_pgs(const mro_model* m, mro_data* d, int maxiter, double tolerance) {
+  (void)m;
   int n = d->nefc;
   const double* AR = d->efc_AR;
   double* f = d->efc_force;
   double scale = 1.0 / (d->meaninertia * (d->nv_active > 1 ? d->nv_active : 1));
   d->solver_iters = 0;
-  for (int iter = 0; iter < m->iterations; iter++) {
+  for (int iter = 0; iter < maxiter; iter++) {
     double improvement = 0;
     for (int i = 0; i < n;) {
       int type = d->efc_type[i];
@@ -1257,8 +1333,282 @@ static void sol_pgs(const mro_model* m, mro_data* d) {
       i += dim;
     }
     d->solver_iters = iter + 1;
-    if (improvement * scale < m->tolerance) break;
+    if (improvement * scale < tolerance) break;
   }
+}
+
+/* ---------------------------------------------------------------- mj_mulM */
+static void mul_m(const mro_model* m, const mro_data* d, double* res, const double* vec) {
+  int nv = m->nv;
+  for (int i = 0; i < nv; i++) res[i] = 0;
+  for (int i = 0; i < nv; i++) {
+    int adr = m->dof_Madr[i];
+    res[i] += d->qM[adr++] * vec[i];
+    for (int j = m->dof_parentid[i]; j >= 0; j = m->dof_parentid[j], adr++) {
+      res[i] += d->qM[adr] * vec[j];
+      res[j] += d->qM[adr] * vec[i];
+    }
+  }
+}
+static void mul_jac(const mro_data* d, int nv, double* res, const double* vec) {
+  for (int i = 0; i < d->nefc; i++) {
+    double s = 0;
+    for (int k = 0; k < nv; k++) s += d->efc_J[i][k] * vec[k];
+    res[i] = s;
+  }
+}
+
+/* ------------------------------------------- mj_solNewton (mj_solPrimal, flg_Newton)
+ * Primal problem in qacc:  cost(a) = 0.5 (a - a_smooth)' M (a - a_smooth) + s(J a - aref).
+ * Newton direction from H = M + J' diag(D_active) J + sum_cone J_c' H_c J_c (dense Cholesky,
+ * nv <= 39), exact line search on the piecewise-smooth 1-D restriction (PrimalSearch: Newton steps
+ * in alpha until |dcost/dalpha| < gtol, safeguarded by the bracket they span), termination on
+ * scale*improvement < tolerance or scale*|grad| < tolerance.  MuJoCo updates the Cholesky factor
+ * incrementally when constraint states change; the factor is recomputed here (same H). */
+typedef struct {
+  double qacc[MRO_MAXV], Ma[MRO_MAXV], grad[MRO_MAXV], Mgrad[MRO_MAXV], search[MRO_MAXV],
+      Mv[MRO_MAXV], jar[MRO_MAXEFC], jv[MRO_MAXEFC], quad[MRO_MAXEFC][3], quadGauss[3], cost;
+  double H[MRO_MAXV * MRO_MAXV];
+} newton_ctx;
+
+static void newton_update_constraint(const mro_model* m, mro_data* d, newton_ctx* c) {
+  int nv = m->nv;
+  double cost = constraint_update_full(m, d, c->jar, d->efc_force, d->efc_state, 1);
+  for (int k = 0; k < nv; k++) d->qfrc_constraint[k] = 0;
+  for (int i = 0; i < d->nefc; i++) {
+    double f = d->efc_force[i];
+    if (f == 0) continue;
+    for (int k = 0; k < nv; k++) d->qfrc_constraint[k] += d->efc_J[i][k] * f;
+  }
+  double gauss = 0;
+  for (int k = 0; k < nv; k++) gauss += 0.5 * (c->Ma[k] - d->qfrc_smooth[k]) * (c->qacc[k] - d->qacc_smooth[k]);
+  c->cost = cost + gauss;
+}
+
+/* grad, H, Cholesky, Mgrad = H^-1 grad */
+static void newton_update_gradient(const mro_model* m, mro_data* d, newton_ctx* c) {
+  int nv = m->nv, n = d->nefc;
+  double* H = c->H;
+  for (int k = 0; k < nv; k++) c->grad[k] = c->Ma[k] - d->qfrc_smooth[k] - d->qfrc_constraint[k];
+  memset(H, 0, sizeof(double) * nv * nv);
+  for (int i = 0; i < nv; i++) {
+    int adr = m->dof_Madr[i];
+    for (int j = i; j >= 0; j = m->dof_parentid[j], adr++) { H[i * nv + j] = d->qM[adr]; H[j * nv + i] = d->qM[adr]; }
+  }
+  for (int i = 0; i < n;) {
+    int st = d->efc_state[i];
+    if (st == ST_CONE) {
+      const double* Hc = d->contact[d->efc_id[i]].H;
+      for (int p = 0; p < 3; p++)
+        for (int q = 0; q < 3; q++) {
+          double h = Hc[3 * p + q];
+          const double *Jp = d->efc_J[i + p], *Jq = d->efc_J[i + q];
+          for (int a = 0; a < nv; a++) {
+            if (Jp[a] == 0) continue;
+            double t = h * Jp[a];
+            for (int b = 0; b < nv; b++) H[a * nv + b] += t * Jq[b];
+          }
+        }
+      i += 3;
+      continue;
+    }
+    if (st == ST_QUADRATIC) {
+      const double* J = d->efc_J[i];
+      double D = d->efc_D[i];
+      for (int a = 0; a < nv; a++) {
+        if (J[a] == 0) continue;
+        double t = D * J[a];
+        for (int b = 0; b < nv; b++) H[a * nv + b] += t * J[b];
+      }
+    }
+    i++;
+  }
+  /* mju_cholFactor (lower triangle in place) */
+  for (int j = 0; j < nv; j++) {
+    double t = H[j * nv + j];
+    for (int k = 0; k < j; k++) t -= H[j * nv + k] * H[j * nv + k];
+    if (t < MINVAL) t = MINVAL;
+    t = sqrt(t);
+    H[j * nv + j] = t;
+    for (int i = j + 1; i < nv; i++) {
+      double u = H[i * nv + j];
+      for (int k = 0; k < j; k++) u -= H[i * nv + k] * H[j * nv + k];
+      H[i * nv + j] = u / t;
+    }
+  }
+  /* mju_cholSolve */
+  double* x = c->Mgrad;
+  for (int i = 0; i < nv; i++) {
+    double t = c->grad[i];
+    for (int k = 0; k < i; k++) t -= H[i * nv + k] * x[k];
+    x[i] = t / H[i * nv + i];
+  }
+  for (int i = nv - 1; i >= 0; i--) {
+    double t = x[i];
+    for (int k = i + 1; k < nv; k++) t -= H[k * nv + i] * x[k];
+    x[i] = t / H[i * nv + i];
+  }
+}
+
+/* PrimalPrepare: quadratic coefficients of every row along the search line; elliptic contacts
+ * keep (U0, V0, UU) and (UV, VV, Dm) in the rows of their friction dimensions */
+static void newton_ls_prepare(const mro_model* m, mro_data* d, newton_ctx* c) {
+  int nv = m->nv, n = d->nefc;
+  c->quadGauss[0] = 0; c->quadGauss[1] = 0; c->quadGauss[2] = 0;
+  double gauss = 0;
+  for (int k = 0; k < nv; k++) {
+    gauss += 0.5 * (c->Ma[k] - d->qfrc_smooth[k]) * (c->qacc[k] - d->qacc_smooth[k]);
+    c->quadGauss[1] += c->search[k] * (c->Ma[k] - d->qfrc_smooth[k]);
+    c->quadGauss[2] += 0.5 * c->search[k] * c->Mv[k];
+  }
+  c->quadGauss[0] = gauss;
+  for (int i = 0; i < n;) {
+    if (d->efc_type[i] != EFC_CONTACT) {
+      double D = d->efc_D[i], j = c->jar[i], v = c->jv[i];
+      c->quad[i][0] = 0.5 * D * j * j; c->quad[i][1] = D * j * v; c->quad[i][2] = 0.5 * D * v * v;
+      i++;
+      continue;
+    }
+    const mro_contact_t* con = &d->contact[d->efc_id[i]];
+    double q0 = 0, q1 = 0, q2 = 0;
+    for (int r = 0; r < 3; r++) {
+      double D = d->efc_D[i + r], j = c->jar[i + r], v = c->jv[i + r];
+      q0 += 0.5 * D * j * j; q1 += D * j * v; q2 += 0.5 * D * v * v;
+    }
+    c->quad[i][0] = q0; c->quad[i][1] = q1; c->quad[i][2] = q2;
+    double mu = con->mu;
+    double U1 = c->jar[i + 1] * con->friction[0], U2 = c->jar[i + 2] * con->friction[1];
+    double V1 = c->jv[i + 1] * con->friction[0], V2 = c->jv[i + 2] * con->friction[1];
+    c->quad[i + 1][0] = c->jar[i] * mu;        /* U0 */
+    c->quad[i + 1][1] = c->jv[i] * mu;         /* V0 */
+    c->quad[i + 1][2] = U1 * U1 + U2 * U2;     /* UU */
+    c->quad[i + 2][0] = U1 * V1 + U2 * V2;     /* UV */
+    c->quad[i + 2][1] = V1 * V1 + V2 * V2;     /* VV */
+    double den = mu * mu * (1 + mu * mu);
+    c->quad[i + 2][2] = d->efc_D[i] / (den > MINVAL ? den : MINVAL); /* Dm */
+    i += 3;
+  }
+}
+typedef struct { double alpha, cost, deriv[2]; } ls_point;
+/* PrimalEval */
+static void newton_ls_eval(const mro_model* m, mro_data* d, const newton_ctx* c, ls_point* p, double alpha) {
+  (void)m;
+  int n = d->nefc;
+  double q0 = c->quadGauss[0], q1 = c->quadGauss[1], q2 = c->quadGauss[2];
+  double cost = 0, d1 = 0, d2 = 0;
+  for (int i = 0; i < n;) {
+    int type = d->efc_type[i];
+    const double* q = c->quad[i];
+    if (type == EFC_EQ) { q0 += q[0]; q1 += q[1]; q2 += q[2]; i++; continue; }
+    if (type == EFC_LIMIT) {
+      if (c->jar[i] + alpha * c->jv[i] < 0) { q0 += q[0]; q1 += q[1]; q2 += q[2]; }
+      i++;
+      continue;
+    }
+    const mro_contact_t* con = &d->contact[d->efc_id[i]];
+    double mu = con->mu;
+    double U0 = c->quad[i + 1][0], V0 = c->quad[i + 1][1], UU = c->quad[i + 1][2];
+    double UV = c->quad[i + 2][0], VV = c->quad[i + 2][1], Dm = c->quad[i + 2][2];
+    double N = U0 + alpha * V0, Tsqr = UU + alpha * (2 * UV + alpha * VV);
+    if (Tsqr <= 0) {
+      if (N < 0) { q0 += q[0]; q1 += q[1]; q2 += q[2]; }
+    } else {
+      double T = sqrt(Tsqr);
+      if (N >= mu * T) {
+        /* top zone: nothing */
+      } else if (mu * N + T <= 0) {
+        q0 += q[0]; q1 += q[1]; q2 += q[2];
+      } else {
+        double N1 = V0, T1 = (UV + alpha * VV) / T, T2 = VV / T - (UV + alpha * VV) * T1 / (T * T);
+        double NT = N - mu * T;
+        cost += 0.5 * Dm * NT * NT;
+        d1 += Dm * NT * (N1 - mu * T1);
+        d2 += Dm * ((N1 - mu * T1) * (N1 - mu * T1) + NT * (-mu * T2));
+      }
+    }
+    i += 3;
+  }
+  p->alpha = alpha;
+  p->cost = cost + alpha * alpha * q2 + alpha * q1 + q0;
+  p->deriv[0] = d1 + 2 * alpha * q2 + q1;
+  p->deriv[1] = d2 + 2 * q2;
+  d->ls_evals++;
+}
+/* PrimalSearch: returns the step; 0 = no progress possible */
+static double newton_line_search(const mro_model* m, mro_data* d, newton_ctx* c, double tolerance,
+                                 double scale) {
+  int nv = m->nv;
+  double snorm = 0;
+  for (int k = 0; k < nv; k++) snorm += c->search[k] * c->search[k];
+  snorm = sqrt(snorm);
+  if (snorm < MINVAL) return 0;
+  double gtol = tolerance * m->ls_tolerance * snorm / scale;
+  mul_m(m, d, c->Mv, c->search);
+  mul_jac(d, nv, c->jv, c->search);
+  newton_ls_prepare(m, d, c);
+  ls_point p0, p1, lo, hi;
+  newton_ls_eval(m, d, c, &p0, 0.0);
+  lo = p0; hi = p0;
+  if (p0.deriv[1] < MINVAL) return 0;
+  newton_ls_eval(m, d, c, &p1, p0.alpha - p0.deriv[0] / p0.deriv[1]);
+  if (p0.cost < p1.cost) p1 = p0;
+  if (fabs(p1.deriv[0]) < gtol) return p1.alpha;
+  /* the restriction is convex: its derivative is increasing, so the minimiser lies right of a
+   * point with negative slope and left of one with positive slope; Newton steps move towards it
+   * and the bracket [lo, hi] (once both ends exist) guards them */
+  int have_lo = 0, have_hi = 0;
+  if (p0.deriv[0] < 0) { lo = p0; have_lo = 1; } else { hi = p0; have_hi = 1; }
+  for (int it = 0; it < m->ls_iterations; it++) {
+    if (p1.deriv[0] < 0) { if (!have_lo || p1.alpha > lo.alpha) { lo = p1; have_lo = 1; } }
+    else { if (!have_hi || p1.alpha < hi.alpha) { hi = p1; have_hi = 1; } }
+    double a = p1.alpha - p1.deriv[0] / p1.deriv[1];
+    if (have_lo && have_hi && !(a > lo.alpha && a < hi.alpha)) a = 0.5 * (lo.alpha + hi.alpha);
+    ls_point pn;
+    newton_ls_eval(m, d, c, &pn, a);
+    p1 = pn;
+    if (fabs(p1.deriv[0]) < gtol) return p1.alpha;
+    if (have_lo && have_hi && hi.alpha - lo.alpha < 1e-14 * fabs(hi.alpha)) break;
+  }
+  /* out of iterations: best point seen */
+  if (have_lo && have_hi) return (lo.cost < hi.cost ? lo.alpha : hi.alpha);
+  return p1.cost < p0.cost ? p1.alpha : 0.0;
+}
+
+static void sol_newton(const mro_model* m, mro_data* d, int maxiter, double tolerance) {
+  int nv = m->nv, n = d->nefc;
+  newton_ctx* c = (newton_ctx*)malloc(sizeof(newton_ctx));
+  memcpy(c->qacc, d->qacc, sizeof(double) * nv);
+  mul_m(m, d, c->Ma, c->qacc);
+  mul_jac(d, nv, c->jar, c->qacc);
+  for (int i = 0; i < n; i++) c->jar[i] -= d->efc_aref[i];
+  newton_update_constraint(m, d, c);
+  newton_update_gradient(m, d, c);
+  for (int k = 0; k < nv; k++) c->search[k] = -c->Mgrad[k];
+  double scale = 1.0 / (d->meaninertia * (d->nv_active > 1 ? d->nv_active : 1));
+  int iter = 0;
+  d->ls_evals = 0;
+  while (iter < maxiter) {
+    double alpha = newton_line_search(m, d, c, tolerance, scale);
+    if (alpha == 0) break;
+    for (int k = 0; k < nv; k++) { c->qacc[k] += alpha * c->search[k]; c->Ma[k] += alpha * c->Mv[k]; }
+    for (int i = 0; i < n; i++) c->jar[i] += alpha * c->jv[i];
+    double oldcost = c->cost;
+    newton_update_constraint(m, d, c);
+    newton_update_gradient(m, d, c);
+    double improvement = scale * (oldcost - c->cost), gn = 0;
+    for (int k = 0; k < nv; k++) gn += c->grad[k] * c->grad[k];
+    double gradient = scale * sqrt(gn);
+    iter++;
+    if (improvement < tolerance || gradient < tolerance) break;
+    for (int k = 0; k < nv; k++) c->search[k] = -c->Mgrad[k];
+  }
+  double gn = 0;
+  for (int k = 0; k < nv; k++) gn += c->grad[k] * c->grad[k];
+  d->solver_iters = iter;
+  d->solver_cost = c->cost;
+  d->solver_grad = scale * sqrt(gn);
+  memcpy(d->qacc, c->qacc, sizeof(double) * nv);
+  free(c);
 }
 
 /* --------------------------------------------------------- mj_fwdConstraint */
@@ -1277,8 +1627,24 @@ static void fwd_constraint(const mro_model* m, mro_data* d) {
     for (int k = 0; k < nv; k++) s += d->efc_J[i][k] * d->qacc_smooth[k];
     d->efc_b[i] = s - d->efc_aref[i];
   }
+  int solver = d->solver_override >= 0 ? d->solver_override : m->solver;
+  int maxiter = d->iterations_override > 0 ? d->iterations_override : m->iterations;
+  double tolerance = d->tolerance_override > 0 ? d->tolerance_override : m->tolerance;
+  double jar[MRO_MAXEFC] = {0};
+  if (solver == 2) {
+    /* warmstart (engine_forward.c): the cheaper of qacc_warmstart and qacc_smooth in primal cost */
+    double Ma[MRO_MAXV], gauss = 0;
+    mul_m(m, d, Ma, d->qacc_warmstart);
+    for (int k = 0; k < nv; k++) gauss += 0.5 * (Ma[k] - d->qfrc_smooth[k]) * (d->qacc_warmstart[k] - d->qacc_smooth[k]);
+    mul_jac(d, nv, jar, d->qacc_warmstart);
+    for (int i = 0; i < n; i++) jar[i] -= d->efc_aref[i];
+    double cost_ws = gauss + constraint_update_full(m, d, jar, d->efc_force, NULL, 0);
+    double cost_sm = constraint_update_full(m, d, d->efc_b, d->efc_force, NULL, 0);
+    memcpy(d->qacc, cost_ws > cost_sm ? d->qacc_smooth : d->qacc_warmstart, sizeof(double) * nv);
+    sol_newton(m, d, maxiter, tolerance);
+    return;
+  }
   /* warmstart: force from qacc_warmstart through the primal->dual map; keep if dual cost < 0 */
-  double jar[MRO_MAXEFC];
   for (int i = 0; i < n; i++) {
     double s = 0;
     for (int k = 0; k < nv; k++) s += d->efc_J[i][k] * d->qacc_warmstart[k];
@@ -1293,7 +1659,7 @@ static void fwd_constraint(const mro_model* m, mro_data* d) {
     cost += d->efc_force[i] * (0.5 * s + d->efc_b[i]);
   }
   if (cost > 0) memset(d->efc_force, 0, sizeof(double) * n);
-  sol_pgs(m, d);
+  sol_pgs(m, d, maxiter, tolerance);
   /* dual -> primal */
   for (int k = 0; k < nv; k++) d->qfrc_constraint[k] = 0;
   for (int i = 0; i < n; i++)

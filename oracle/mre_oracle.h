@@ -60,6 +60,12 @@ void mro_set_caps(mro_data*, int ncon_cap, int nefc_cap, int nrrow_cap, int npp_
 int mro_overflow(const mro_data*);
 /* solver telemetry of the last solve */
 int mro_solver_iters(const mro_data*);
+/* per-env solver override: solver -1 = the model's opt_solver, 0 = PGS, 2 = Newton (mjtSolver);
+ * iterations / tolerance <= 0 = the model's */
+void mro_set_solver(mro_data*, int solver, int iterations, double tolerance);
+int mro_ls_evals(const mro_data*);        /* Newton: line-search evaluations of the last solve */
+double mro_solver_grad(const mro_data*);  /* Newton: scale * |grad| at exit */
+double mro_solver_cost(const mro_data*);  /* Newton: primal cost at exit */
 
 /* named access to mjData-like arrays ("qpos","qvel","ctrl","qacc",...);
  * returns NULL if unknown; *n receives the element count */
@@ -85,6 +91,12 @@ int mro_osc_converged(const mro_model*, mro_data*, const mro_osc*);
  * Returns arm_converged flag of the last tick evaluation semantics. */
 int mro_run_controller(const mro_model*, mro_data*, const mro_osc*, double grip_ctrl,
                        int nticks, int control_steps);
+
+/* stand-alone elliptic-cone term of mj_constraintUpdate for unit tests: cost of one condim-3 contact
+ * as a function of jar[3]; force[3] = -gradient; H[9] (or NULL) = Hessian in the middle zone;
+ * *state = 0 quadratic, 1 satisfied, 4 cone */
+double mro_cone_eval(const double* jar, const double* D, const double* friction, double mu,
+                     double* force, double* H, int* state);
 
 /* stand-alone narrow phase for unit tests: returns #contacts (<=8) */
 int mro_boxbox(const double* p1, const double* R1, const double* s1, const double* p2,

@@ -52,6 +52,12 @@ def lib() -> C.CDLL:
         L.mro_set_no_constraints.argtypes = [C.c_void_p, C.c_int]
         L.mro_set_caps.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
         L.mro_overflow.argtypes = [C.c_void_p]
+        L.mro_set_solver.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double]
+        L.mro_ls_evals.argtypes = [C.c_void_p]
+        L.mro_solver_grad.restype = C.c_double
+        L.mro_solver_grad.argtypes = [C.c_void_p]
+        L.mro_solver_cost.restype = C.c_double
+        L.mro_solver_cost.argtypes = [C.c_void_p]
         L.mro_get.restype = C.POINTER(C.c_double)
         L.mro_get.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int)]
         L.mro_ncon.argtypes = [C.c_void_p]
@@ -63,6 +69,8 @@ def lib() -> C.CDLL:
         L.mro_run_controller.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(OscParams),
                                          C.c_double, C.c_int, C.c_int]
         L.mro_boxbox.argtypes = [C.POINTER(C.c_double)] * 6 + [C.c_double] + [C.POINTER(C.c_double)] * 3
+        L.mro_cone_eval.restype = C.c_double
+        L.mro_cone_eval.argtypes = [C.POINTER(C.c_double)] * 3 + [C.c_double] + [C.POINTER(C.c_double)] * 2 + [C.POINTER(C.c_int)]
         L.mro_batch_step.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int,
                                      C.POINTER(C.c_double), C.c_int, C.c_int]
         _LIB = L
@@ -127,6 +135,24 @@ class Env:
         """Emulate the device capacities (csrc/mre_dev.h: NCON_MAX, NEFC_MAX, NRROW_MAX, NPP_MAX)."""
         lib().mro_set_caps(self.ptr, int(ncon_cap), int(nefc_cap), int(nrrow_cap), int(npp_cap))
 
+    def set_solver(self, solver: str = "model", iterations: int = 0, tolerance: float = 0.0):
+        """Per-env solver override: "model" (the blob's opt_solver), "PGS" or "Newton"; iterations /
+        tolerance 0 keep the model's (MuJoCo defaults 100 / 1e-8)."""
+        code = {"model": -1, "PGS": 0, "Newton": 2}[solver]
+        lib().mro_set_solver(self.ptr, code, int(iterations), float(tolerance))
+
+    @property
+    def ls_evals(self) -> int:
+        return lib().mro_ls_evals(self.ptr)
+
+    @property
+    def solver_grad(self) -> float:
+        return lib().mro_solver_grad(self.ptr)
+
+    @property
+    def solver_cost(self) -> float:
+        return lib().mro_solver_cost(self.ptr)
+
     @property
     def overflow(self) -> bool:
         return bool(lib().mro_overflow(self.ptr))
@@ -170,6 +196,14 @@ def batch_step(model: Model, envs: Sequence[Env], ctrl: Optional[np.ndarray], ns
         ctrl = np.ascontiguousarray(ctrl, np.float64)
         cp = _dp(ctrl)
     return lib().mro_batch_step(model.ptr, ptrs, len(envs), cp, int(nstep), int(nthreads))
+
+
+def cone_eval(jar, D, friction, mu):
+    """(cost, force[3], H[3,3], state) of one elliptic contact (mj_constraintUpdate)."""
+    jar, D, friction = [np.ascontiguousarray(x, np.float64) for x in (jar, D, friction)]
+    force, H, st = np.zeros(3), np.zeros(9), C.c_int(0)
+    cost = lib().mro_cone_eval(_dp(jar), _dp(D), _dp(friction), float(mu), _dp(force), _dp(H), C.byref(st))
+    return cost, force, H.reshape(3, 3), st.value
 
 
 def boxbox(p1, R1, s1, p2, R2, s2, margin=0.0):

@@ -1,4 +1,5 @@
-"""Generates tests/golden/oracle_rollout_v1.npz from THIS repo's fp64 CPU oracle.
+"""Generates tests/golden/oracle_rollout_v2.npz from THIS repo's fp64 CPU oracle (one rollout per
+solver: PGS as BASELINE.json prescribes, Newton as the reference's MuJoCo runs).
 
 The reference cannot produce vectors here (MuJoCo / dm_control / mujoco_controllers are
 absent), so the fixture pins the oracle against regressions and gives
@@ -28,7 +29,7 @@ def scenario():
     return ids, nprops, sizes, yaws, acts
 
 
-def run():
+def run(solver="PGS"):
     A = MC.compile_scene()
     m = O.Model(MC.to_blob(A))
     ids, nprops, sizes, yaws, acts = scenario()
@@ -37,6 +38,7 @@ def run():
     qvel = np.zeros((T, N, 39))
     for i in range(N):
         e = O.Env(m, int(nprops[i]), sizes[i])
+        e.set_solver(solver)
         init_oracle_env(e, int(nprops[i]), sizes[i], yaw=yaws[i], z_extra=0.002)
         e.forward()
         q0[i] = e.arr("qpos")[:43]
@@ -52,6 +54,8 @@ def run():
 
 
 if __name__ == "__main__":
-    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle_rollout_v1.npz")
-    np.savez_compressed(out, **run())
+    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle_rollout_v2.npz")
+    r, rn = run("PGS"), run("Newton")
+    r["qpos_newton"], r["qvel_newton"] = rn["qpos"], rn["qvel"]
+    np.savez_compressed(out, **r)
     print("wrote", out)

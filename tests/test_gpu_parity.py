@@ -11,11 +11,11 @@ pytestmark = pytest.mark.gpu
 QPOS_TOL = 1e-4
 
 
-def _make(num_envs, model):
+def _make(num_envs, model, solver=None):
     import torch
     from mujoco_robot_environments_amd.physics import BatchedPhysics
     assert torch.cuda.is_available(), "GPU tests need a GPU"
-    return BatchedPhysics(num_envs, model=model)
+    return BatchedPhysics(num_envs, model=model, solver=solver)
 
 
 def _oracle_envs(oracle_model, nprops, sizes):
@@ -27,7 +27,7 @@ def _oracle_envs(oracle_model, nprops, sizes):
 
 
 def _rollout_both(compiled_model, oracle_model, N, T, flags, scale, seed=0, no_constraints=False,
-                  control_steps=5, z_extra=0.0, gravity_comp=False, yaw=False):
+                  control_steps=5, z_extra=0.0, gravity_comp=False, yaw=False, solver=None):
     import torch
     from mujoco_robot_environments_amd import rng
     A, _ = compiled_model
@@ -43,8 +43,10 @@ def _rollout_both(compiled_model, oracle_model, N, T, flags, scale, seed=0, no_c
                                 yaw=None if yaws is None else yaws[i])
         # inactive cube slots keep the parked pose of mro_reset
         e.no_constraints(no_constraints)
+        if solver is not None:
+            e.set_solver(solver)
         e.forward()
-    phys = _make(N, A)
+    phys = _make(N, A, solver)
     phys.set_props(nprops, sizes)
     # parked poses for inactive cubes come from reset(); overwrite active part
     qp = phys.qpos().copy()
