@@ -48,27 +48,28 @@ def baseline_metric():
         return "env steps/sec (whole node), RearrangementEnv batch=4096 at 1/2/4/8 MI355X"
 
 
-def pmc_summary():
-    """Latest committed PMC pass (profiles/*_pmc_summary.json: separate rocprofv3 --pmc FETCH_SIZE /
-    WRITE_SIZE / SQ_* runs of this same bench command); the counters cannot be read from inside
-    the process, so the per-launch figures are carried over."""
+def pmc_summary(solver="PGS"):
+    """Latest committed PMC pass of the solver's kernel (profiles/*_pmc_summary[_newton].json: separate
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* runs of this same bench command); the counters cannot
+    be read from inside the process, so the per-launch figures are carried over."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
+    sfx = "_pmc_summary.json" if solver == "PGS" else "_pmc_summary_newton.json"
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*" + sfx)))
     if not files:
         return {}, None
     with open(files[-1]) as f:
         return json.load(f), os.path.basename(files[-1])
 
 
-def pmc_traffic():
-    d, name = pmc_summary()
+def pmc_traffic(solver="PGS"):
+    d, name = pmc_summary(solver)
     return d.get("traffic_bytes_per_launch"), name
 
 
-def valu_issue(avg_launch_s):
+def valu_issue(avg_launch_s, solver="PGS"):
     """What actually bounds the kernel: VALU issue slots.  A wave64 VALU instruction occupies its
     SIMD for 4 cycles (16 lanes per SIMD), so  util = SQ_INSTS_VALU * 4 / (SIMDs * clock * time)."""
-    d, name = pmc_summary()
+    d, name = pmc_summary(solver)
     n = d.get("SQ_INSTS_VALU_per_launch")
     if not n or avg_launch_s <= 0:
         return None
@@ -139,49 +140,22 @@ def cpu_baseline(seed, budget_s=12.0, nenv=64):
             "single_thread_value": 4 * ticks1 * CONTROL_STEPS / dt1}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
-    ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--fused", type=int, default=1, help="control ticks per kernel launch")
-    args = ap.parse_args()
+def spawn_ranks(args) -> int:
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks as fresh child
+    processes BEFORE this process touches the GPU (never re-exec a process that holds the device),
+    relay their output and exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
 
-    import torch
-    import torch.distributed as dist
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    # rehearsal knobs (1-GPU box): MRE_BENCH_DEVICE pins every rank to one device and
-    # MRE_BENCH_BACKEND=gloo replaces RCCL (two ranks cannot share a device under RCCL)
-    backend = os.environ.get("MRE_BENCH_BACKEND", "nccl")
-    if "MRE_BENCH_DEVICE" in os.environ:
-        local_rank = int(os.environ["MRE_BENCH_DEVICE"])
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
-    from mujoco_robot_environments_amd import rng
-    from mujoco_robot_environments_amd.physics import BatchedPhysics
-    n_local = args.envs_per_gpu
-    env_ids = np.arange(rank * n_local, (rank + 1) * n_local)  # global ids: results independent of sharding
-    phys = BatchedPhysics(n_local, device=local_rank)
-    nprops, _ = setup_envs(phys, args.seed, env_ids)
-
-    K, W, F = args.steps, args.warmup, max(1, args.fused)
-    assert K % F == 0 and W % F == 0, "--fused must divide --steps and --warmup"
-    acts = rng.random_actions(args.seed, env_ids, np.arange(W + K)).astype(np.float32)
-    seq = torch.from_numpy(acts).to(phys.device).contiguous()  # resident in HBM before timing
-
+def timed_run(phys, seq, K, W, F, world, backend, dist, torch, n_local):
+    """W untimed warm-up ticks, then exactly K timed ticks between barrier + synchronize pairs."""
     def barrier():
         if world > 1:
             dist.barrier()
@@ -217,38 +191,112 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=phys.device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    return elapsed, kern_ms, launches, gather_ms
 
-    status = phys.status()
-    stats = phys.solver_stats()
-    total_env_steps = world * n_local * K * CONTROL_STEPS
-    value = total_env_steps / elapsed
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fused", type=int, default=1, help="control ticks per kernel launch")
+    ap.add_argument("--solver", choices=["both", "PGS", "Newton"], default="both",
+                    help="PGS is the headline line (BASELINE.json north_star); Newton (MuJoCo's default, "
+                         "what the reference runs) is timed on the same start state and printed beside it")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    # rehearsal knobs (1-GPU box): MRE_BENCH_DEVICE pins every rank to one device and
+    # MRE_BENCH_BACKEND=gloo replaces RCCL (two ranks cannot share a device under RCCL)
+    backend = os.environ.get("MRE_BENCH_BACKEND", "nccl")
+    if "MRE_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["MRE_BENCH_DEVICE"])
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+
+    from mujoco_robot_environments_amd import rng
+    from mujoco_robot_environments_amd.physics import BatchedPhysics
+    n_local = args.envs_per_gpu
+    env_ids = np.arange(rank * n_local, (rank + 1) * n_local)  # global ids: results independent of sharding
+    phys = BatchedPhysics(n_local, device=local_rank)
+    nprops, _ = setup_envs(phys, args.seed, env_ids)
+    qp0, qv0 = phys.get_state()
+    ws0 = phys.get_warmstart()
+
+    K, W, F = args.steps, args.warmup, max(1, args.fused)
+    assert K % F == 0 and W % F == 0, "--fused must divide --steps and --warmup"
+    acts = rng.random_actions(args.seed, env_ids, np.arange(W + K)).astype(np.float32)
+    seq = torch.from_numpy(acts).to(phys.device).contiguous()  # resident in HBM before timing
     bytes_per_launch = algorithmic_bytes_per_env_step(nprops) * n_local * CONTROL_STEPS * F
-    avg_launch_s = (kern_ms / max(launches, 1)) * 1e-3
-    achieved = bytes_per_launch / avg_launch_s / 1e9
+    total_env_steps = world * n_local * K * CONTROL_STEPS
+    pmc = (F == 1 and n_local == ENVS_PER_GPU)
+
+    def run(solver):
+        phys.set_solver(solver)
+        phys.reset()
+        phys.set_state(qp0, qv0)
+        phys.set_warmstart(ws0)
+        phys.sync()
+        elapsed, kern_ms, launches, gather_ms = timed_run(phys, seq, K, W, F, world, backend, dist, torch, n_local)
+        status, stats = phys.status(), phys.solver_stats()
+        avg_launch_s = (kern_ms / max(launches, 1)) * 1e-3
+        achieved = bytes_per_launch / avg_launch_s / 1e9
+        kname = "mre::k_step" if solver == "PGS" else "mre::k_step_newton"
+        return {
+            "solver": solver, "value": total_env_steps / elapsed, "ms_per_step": elapsed / K * 1e3, "gather_ms": gather_ms,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": pmc_traffic(solver)[0] if pmc else None, "traffic_source": pmc_traffic(solver)[1],
+                         "kernel": kname, "avg_launch_ms": avg_launch_s * 1e3, "launches": launches,
+                         "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "valu_issue": valu_issue(avg_launch_s, solver) if pmc else None,
+                         "note": "the path is bound by VALU issue, not by HBM: per-env state stays in LDS across the "
+                                 "5 fused steps (see valu_issue)"},
+            "health": {"nan_envs": int(((status & 2) != 0).sum()), "overflow_envs": int(((status & 4) != 0).sum()),
+                       "mean_ncon": float(stats[:, 0].mean()), "mean_nefc": float(stats[:, 1].mean()),
+                       "mean_solver_iters": float(stats[:, 2].mean()), "max_solver_iters": int(stats[:, 2].max()),
+                       "solver_iters_histogram": np.bincount(np.minimum(stats[:, 2], 10), minlength=11).tolist(),
+                       "capacity_fallback": phys.fallback_stats()},
+        }
+
+    runs = {s: run(s) for s in (["PGS", "Newton"] if args.solver == "both" else [args.solver])}
+    head = runs.get("PGS") or runs["Newton"]
     res = {
         "metric": baseline_metric(),
-        "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
-        "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
+        "value": head["value"], "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
+        "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "configs[1]: 4096 parallel RearrangementEnv per GPU (2-4 cubes), random "
                    "actions every 5 ms tick, 5 x 1 ms physics steps per bench step",
                    "envs_per_gpu": n_local, "control_steps": CONTROL_STEPS, "ticks_per_launch": F,
-                   "solver": "PGS<=100 iters, tol 1e-8", "integrator": "implicitfast"},
-        "control_ticks_per_s": value / CONTROL_STEPS,
-        "pick_place_macro_steps_per_s": value / 18000.0,
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic()[0] if (F == 1 and n_local == ENVS_PER_GPU) else None,
-                     "traffic_source": pmc_traffic()[1],
-                     "kernel": "mre::k_step", "avg_launch_ms": avg_launch_s * 1e3, "launches": launches,
-                     "algorithmic_bytes_per_launch": bytes_per_launch,
-                     "valu_issue": valu_issue(avg_launch_s) if (F == 1 and n_local == ENVS_PER_GPU) else None,
-                     "note": "path is bound by VALU issue of the sequential Gauss-Seidel sweeps (see valu_issue), "
-                             "not by HBM: per-env state stays in LDS across the 5 fused steps"},
-        "health": {"nan_envs": int(((status & 2) != 0).sum()), "overflow_envs": int(((status & 4) != 0).sum()),
-                   "mean_ncon": float(stats[:, 0].mean()), "mean_nefc": float(stats[:, 1].mean()),
-                   "mean_pgs_iters": float(stats[:, 2].mean()), "capacity_fallback": phys.fallback_stats()},
-        "gather_ms": gather_ms,
+                   "solver": ("PGS<=100 sweeps, tol 1e-8 (north_star)" if head["solver"] == "PGS"
+                              else "Newton<=100 iterations, tol 1e-8 (MuJoCo default)"),
+                   "integrator": "implicitfast"},
+        "control_ticks_per_s": head["value"] / CONTROL_STEPS,
+        "pick_place_macro_steps_per_s": head["value"] / 18000.0,
+        "roofline": head["roofline"], "health": head["health"], "gather_ms": head["gather_ms"],
     }
+    if "Newton" in runs and head is not runs["Newton"]:
+        # the reference's own solver (MuJoCo default, tasks/rearrangement.py:77-80 sets no solver),
+        # same start state, same actions, timed the same way
+        res["newton"] = runs["Newton"]
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(args.seed)
     elif rank == 0:

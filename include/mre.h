@@ -128,7 +128,8 @@ int mre_run_controller(mre_env*, int nticks, int control_steps, uint8_t* converg
  * prop poses (props_info, tasks/rearrangement.py:245-246): rows [N][3], [N][7], [N][4][7] */
 int mre_get_sites(mre_env*, float* tcp_pos, float* eef_pose, float* prop_pose);
 int mre_get_status(mre_env*, uint32_t* status);
-/* telemetry: per-env [ncon, nefc, solver_iters, reserved] of the last step */
+/* telemetry: per-env [active contacts, constraint rows, solver iterations (PGS sweeps / Newton
+ * iterations in the low byte, Newton: Hessian factorisations << 8), active limit rows] of the last step */
 int mre_get_solver_stats(mre_env*, int32_t* stats);
 
 /* dispatch order: workgroup b of the step kernel advances env order[b] (a permutation of
@@ -167,6 +168,13 @@ int mre_set_fallback(mre_env*, int mode);
  * (tasks/rearrangement.py:77-80 sets timestep / gravity / nconmax / njmax only), BASELINE.json's
  * north_star prescribes PGS.  Both are built; mre_set_solver switches a live handle (the state,
  * warm start included, carries over). mre_get_solver returns the current value. */
+/* Stream ordering with the caller's own stream: device buffers handed to the library (controls,
+ * control sequences, trace buffers) are consumed on the handle's stream (mre_stream); when another
+ * stream produced them, mre_wait_stream(h, that_stream) makes every later launch of the handle wait
+ * for the work already enqueued there (hipEventRecord + hipStreamWaitEvent; stream = hipStream_t,
+ * NULL = the legacy default stream).  The caller keeps the buffers alive until mre_sync. */
+int mre_wait_stream(mre_env*, void* stream);
+
 #define MRE_SOLVER_PGS 0
 #define MRE_SOLVER_NEWTON 2
 int mre_set_solver(mre_env*, int solver);

@@ -91,7 +91,7 @@ struct mre_env {
   bool large_only = false;
   bool compact_only = false;  // mre_set_fallback(0)  // mre_set_fallback(2): every env on the large kernel (reference run for the fallback)
   hipStream_t stream2 = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_order = nullptr;
   uint8_t *d_large = nullptr, *mask_c = nullptr, *mask_l = nullptr, *mask_r = nullptr;
   float *sv_qpos = nullptr, *sv_qvel = nullptr, *sv_qacc_ws = nullptr, *sv_ctrl = nullptr;
   uint32_t* sv_status = nullptr;
@@ -536,6 +536,8 @@ extern "C" int mre_destroy(mre_env* e) {
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (e->h_launch_info) (void)hipHostFree(e->h_launch_info);
   if (e->h_auto_order) (void)hipHostFree(e->h_auto_order);
+  for (auto& pr : e->events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+  if (e->ev_order) (void)hipEventDestroy(e->ev_order);
   if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
   if (e->ev_join) (void)hipEventDestroy(e->ev_join);
   if (e->stream2) (void)hipStreamDestroy(e->stream2);
@@ -588,10 +590,16 @@ extern "C" int mre_reset(mre_env* e, const uint8_t* mask) {
   if (rc) return rc;
   mre_launch_reset(e->dM, e->N, e->qpos, e->qvel, e->qacc_ws, e->ctrl, e->status, dmask, e->stream);
   HIPCHK(hipGetLastError());
-  // a reset env starts on the compact kernel again
+  // a reset env starts on the compact kernel again (the mask may be a device pointer: read a host copy)
   bool changed = false;
+  std::vector<uint8_t> hmask;
+  if (mask) {
+    hmask.resize((size_t)e->N);
+    rc = copy_out(e, hmask.data(), dmask, (size_t)e->N);
+    if (rc) return rc;
+  }
   for (int i = 0; i < e->N; i++)
-    if (!e->large_only && e->h_large[i] && (!mask || mask[i])) { e->h_large[i] = 0; e->n_large--; changed = true; }
+    if (!e->large_only && e->h_large[i] && (!mask || hmask[i])) { e->h_large[i] = 0; e->n_large--; changed = true; }
   if (changed) {
     HIPCHK(hipMemcpyAsync(e->d_large, e->h_large.data(), (size_t)e->N, hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -677,6 +685,7 @@ extern "C" int mre_render(mre_env* e, const float* cam_pos, const float* cam_mat
   int row_groups = (height + rows_per_iter - 1) / rows_per_iter;
   int cap = 8;  // 8 row groups per env: the per-workgroup geom set-up is amortised over 30 row pairs
   if (const char* rg = getenv("MRE_RENDER_ROW_GROUPS")) cap = atoi(rg);  // tuning knob
+  if (cap < 1) cap = 1;
   if (row_groups > cap) row_groups = cap;
   // The static geoms (ground plane, table: geoms 0 and 1, fixed to the world) look the same in every
   // env and every frame of a camera: their image is rendered once per camera and every frame then
@@ -733,6 +742,15 @@ extern "C" int mre_set_fallback(mre_env* e, int mode) {
     e->h_large.assign((size_t)e->N, mode == 2 ? 1 : 0);
     HIPCHK(hipMemcpy(e->d_large, e->h_large.data(), (size_t)e->N, hipMemcpyHostToDevice));
   }
+  return MRE_OK;
+}
+
+extern "C" int mre_wait_stream(mre_env* e, void* stream) {
+  if (!e) return fail(MRE_ERR_ARG, "null handle");
+  HIPCHK(hipSetDevice(e->device));
+  if (!e->ev_order) HIPCHK(hipEventCreateWithFlags(&e->ev_order, hipEventDisableTiming));
+  HIPCHK(hipEventRecord(e->ev_order, (hipStream_t)stream));
+  HIPCHK(hipStreamWaitEvent(e->stream, e->ev_order, 0));
   return MRE_OK;
 }
 

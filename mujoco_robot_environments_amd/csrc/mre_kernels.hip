@@ -52,6 +52,8 @@ struct Sm {
   // state
   float qpos[NQP], qvel[NVP], qacc_ws[NVP], ctrl[NU];
   // generalized vectors
+  // (qfrc_con is dead between integrate and the next solve: its head carries the fp64-evaluated
+  //  residuals of the two connect rows from connect_residuals to assemble_constraints)
   float qfrc_smooth[NVP], qacc_smooth[NVP], qacc[NVP], qfrc_bias[NVP], qfrc_con[NVP];
   // LDS regions reused along the step (lifetimes: S1a kinematics..factor, S1b velocity stage,
   // S1c collision + assembly, tick-boundary controller, S2 solve + integrate)
@@ -717,8 +719,11 @@ MRE_DEV void step_body(const StepArgs& a, Sm& s) {
 
       collide(M, s, l);
       MRE_STAMP(2);
+      connect_residuals(M, s, l);
       assemble_constraints(M, s, l);
-#ifndef MRE_NEWTON
+#ifdef MRE_NEWTON
+      nw_build_lists(s, l);
+#else
       solve_robot_rows(s, l);
       assemble_blocks(M, s, l);
 #endif
@@ -762,8 +767,17 @@ MRE_DEV void step_body(const StepArgs& a, Sm& s) {
     solve_robot_par(M, s.qLD, s.qLDinv, s.scratch, 0, 1, l);
     integrate(M, s, l, a.flags);
     if (a.trace != nullptr && env < a.trace_nenv && (a.trace_base + step) < a.trace_max) {
-      if (l < NQP)
-        a.trace[((size_t)(a.trace_base + step) * a.trace_nenv + env) * NQP + l] = s.qpos[l];
+      // the pad element of the row carries the step's constraint census (an integer < 2^24, exact
+      // in fp32): active contacts + 64 * (bit b - 1 set: the joint of robot body b is at a limit)
+      if (l < NQP) {
+        float v = l < NQ ? s.qpos[l] : 0.f;
+        if (l == NQ && constrained) {
+          int mask = 0;
+          for (int k = 0; k < s.nl; k++) mask |= 1 << ((s.lim_info[k] & 0xFF) - 1);
+          v = (float)(s.ncon + 64 * mask);
+        }
+        a.trace[((size_t)(a.trace_base + step) * a.trace_nenv + env) * NQP + l] = v;
+      }
     }
   }
   MRE_STAMP(7);

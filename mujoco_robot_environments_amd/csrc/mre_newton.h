@@ -134,6 +134,20 @@ MRE_DEV float nw_update(Sm& s, int l, int nscalar, int ncon, float mu_scale, con
   return wave_sum(cost);
 }
 
+// The active set as three lane masks (scalar rows with a force, contacts in the quadratic zone,
+// contacts in the cone zone): equal masks = same rows in H.
+struct NwMasks { unsigned long long sc, cq, cc; };
+MRE_DEV bool operator==(const NwMasks& a, const NwMasks& b) { return a.sc == b.sc && a.cq == b.cq && a.cc == b.cc; }
+MRE_DEV NwMasks nw_masks(const Sm& s, int l, int nscalar, int ncon) {
+  NwMasks m;
+  const int st_s = l < nscalar ? s.rstate[l] : NW_SAT;
+  const int st_c = l < ncon ? s.rstate[nscalar + 3 * l] : NW_SAT;
+  m.sc = __ballot(st_s == NW_QUAD);
+  m.cq = __ballot(st_c == NW_QUAD);
+  m.cc = __ballot(st_c == NW_CONE);
+  return m;
+}
+
 // (J' f)[dof of this lane]: robot lanes run over the robot-row slots, cube lanes over the
 // contacts that touch their cube
 MRE_DEV float nw_JTf(const Sm& s, int l, int lp, int lk, int nscalar) {
@@ -211,6 +225,30 @@ MRE_DEV void nw_elim_range(float (&hh)[NV], float& g, float& y, float& dinv, int
 }
 
 struct NwPoint { float alpha, cost, d1, d2; };
+
+// Per-cube contact lists and the block coupling of the Hessian (lane 0, after the assembly has
+// fixed the kept contacts and their robot slots).  A phase of its own: the row assembly is at the
+// edge of its register budget.
+MRE_PHASE_FN void nw_build_lists(Sm& s, int l) {
+  if (l == 0) {
+    int cnt[NPROP] = {0, 0, 0, 0};
+    unsigned cr = 0u, cc = 0u;
+    const int kept = s.ncon;
+    for (int c = 0; c < kept; c++) {
+      const int cb1 = s.con_b1[c], cb2 = s.con_b2[c];
+      int pa = -1, pb = -1;
+      if (cb1 >= NRB) pa = cb1 - NRB;
+      if (cb2 >= NRB) { if (pa < 0) pa = cb2 - NRB; else pb = cb2 - NRB; }
+      if (pa >= 0) s.clist[pa][cnt[pa]++] = (uint8_t)c;
+      if (pb >= 0) s.clist[pb][cnt[pb]++] = (uint8_t)(c | 0x80);
+      if (s.con_rslot[c] != HDR_NONE && pa >= 0) cr |= 1u << pa;
+      if (pb >= 0) cc |= 1u << cube_pair_bit(pa, pb);
+    }
+    for (int p = 0; p < NPROP; p++) s.ccount[p] = (uint8_t)cnt[p];
+    s.cpl_robot = (uint8_t)cr; s.cpl_cubes = (uint8_t)cc;
+  }
+  __syncthreads();
+}
 
 // Per-lane constants of the solver phases
 struct NwLane {
@@ -372,8 +410,42 @@ MRE_PHASE_FN void nw_direction(const DevModel* M, Sm& s, int l) {
       y = fmaf(-cw, xj, y);
     }
   }
-  const float x = y * dinv;
-  if (l < NVP) s.nw_search[l] = (l < NV && c.lact) ? -x : 0.f;
+  const float x = (l < NV && c.lact) ? y * dinv : 0.f;
+  if (l < NVP) s.nw_search[l] = -x;
+  // Newton decrement grad' H^-1 grad: the cost decrease the quadratic model predicts is half of it
+  const float dec = wave_sum((l < NVP ? s.nw_grad[l] : 0.f) * x);
+  if (l == 0) s.scratch[2] = dec;
+  __syncthreads();
+}
+
+// Phase 2': the same direction from the factor of the last nw_direction call (still in s.W), for a
+// gradient whose active set did not change -- MuJoCo's Newton likewise keeps its Cholesky factor
+// while the constraint states stand.  Both triangular solves read W from LDS: W y = g by columns
+// (for column k the lanes j < k read consecutive words), W' x = y as in nw_direction.
+MRE_PHASE_FN void nw_direction_reuse(const DevModel* M, Sm& s, int l) {
+  const NwLane c = nw_lane(M, s, l);
+  const int nva = NRV + 6 * s.nprops;
+  const bool on = l < NV && c.lact;
+  const float gin = on ? s.nw_grad[l] : 0.f;
+  float g = gin;
+  const float dinv = on ? 1.0f / s.W[l * (l + 1) / 2 + l] : 1.0f;
+  float y = 0.f;
+  for (int k = nva - 1; k >= 0; k--) {
+    const float yk = rdlane(g * dinv, k);
+    const float w = (l < k) ? s.W[k * (k + 1) / 2 + l] : 0.f;
+    g = fmaf(-w, yk, g);
+    y = (l == k) ? yk : y;
+  }
+  const int base = l < NV ? l * (l + 1) / 2 : 0;
+  for (int j = 0; j < nva; j++) {
+    const float cw = (j < l && l < NV) ? s.W[base + j] : 0.f;
+    const float xj = rdlane(y * dinv, j);
+    y = fmaf(-cw, xj, y);
+  }
+  const float x = on ? y * dinv : 0.f;
+  if (l < NVP) s.nw_search[l] = -x;
+  const float dec = wave_sum(gin * x);
+  if (l == 0) s.scratch[2] = dec;
   __syncthreads();
 }
 
@@ -498,28 +570,65 @@ MRE_PHASE_FN float nw_search_move(const DevModel* M, Sm& s, int l) {
 // ------------------------------------------------------------- mj_fwdConstraint (Newton)
 // Runs from the kernel body (the phases above are real functions and never nest calls).
 // On exit: s.qacc, s.qfrc_con = J' f, s.solver_iters.
+//
+// Termination.  mj_solPrimal stops on scale * (cost decrease of the last iteration) < tolerance or
+// scale * |grad| < tolerance (1e-8).  Neither can be evaluated in fp32: the cost is a sum of terms up
+// to 1e4 (resolution 1e-3), the gradient of the arm dofs carries 1e-5 N m of rounding.  The Newton
+// decrement d = grad' H^-1 grad can -- it is formed from the gradient and the search direction with
+// no cancellation, and d / 2 IS the decrease the next iteration would achieve: the loop stops on
+// scale * d / 2 < tolerance, the same test one iteration ahead.  (Stopping on the fp32 cost
+// difference left residual forces of ~3e-5 N m on the finger links, whose inertia is 1e-5 kg m^2:
+// a drift of 1e-4 .. 3e-3 rad over 1000 steps against the oracle.)  The check costs one more
+// direction, which re-uses the factor when the active set did not change.
 MRE_DEV void newton_solve(const DevModel* M, Sm& s, int l) {
   const float tol = M->tolerance;
   const int max_iter = M->iterations;
+  const int nscalar = 7 + s.nl, ncon = s.ncon;
   float msum = M->M0_diag_robot_sum;
   for (int p = 0; p < s.nprops; p++)
     msum += 3.f * s.prop_mass[p] + s.prop_inertia[p][0] + s.prop_inertia[p][1] + s.prop_inertia[p][2];
   const float scale = 1.0f / msum;
-  float cost = nw_setup(M, s, l);
-  int iter = 0;
+  nw_setup(M, s, l);
+  // fp32 runs the decrement test a decade below MuJoCo's tolerance: the reference's Newton
+  // converges quadratically in fp64 and so ends far below its own threshold, while a solve that
+  // stops AT the threshold keeps a residual force of the threshold's size (2e-5 N m on the finger
+  // mechanism at 1e-8: a drift of 2e-4 rad/s against the oracle).  The rounding floor of the
+  // decrement lies another decade lower.
+  const float tol_eff = 0.1f * tol;
+  NwMasks mf = {0ull, 0ull, 0ull}, mprev = {~0ull, ~0ull, ~0ull};
+  bool have_factor = false, force_full = false;
+  float prev_dec = 3.0e38f;
+  int iter = 0, nfull = 0, stalls = 0;
   while (iter < max_iter) {
-    nw_direction(M, s, l);
-    const float newcost = nw_search_move(M, s, l);
-    const float alpha = s.scratch[0], gradnorm = s.scratch[1];
-    if (alpha == 0.f) break;
-    const float improvement = scale * (cost - newcost);
-    cost = newcost;
+    const NwMasks mk = nw_masks(s, l, nscalar, ncon);
+    const bool reuse = have_factor && !force_full && mk == mf;
+    if (reuse) {
+      nw_direction_reuse(M, s, l);
+    } else {
+      nw_direction(M, s, l);
+      mf = mk; have_factor = true; nfull++;
+    }
+    const float dec = s.scratch[2];
+    if (!(dec == dec)) break;                          // non-finite: keep the last iterate
+    if (0.5f * scale * dec < tol_eff) break;           // converged
+    if (mk == mprev && dec > 0.1f * prev_dec) {
+      // same active set, poor contraction: a stale factor gets a fresh try from the same iterate;
+      // with a fresh factor and the decrement already within two decades of the tolerance it is the
+      // rounding floor (two strikes), otherwise ordinary slow progress far from the optimum
+      if (reuse) { force_full = true; continue; }
+      if (0.5f * scale * dec < 100.f * tol_eff && ++stalls >= 2) break;
+    }
+    prev_dec = dec; mprev = mk; force_full = false;
+    nw_search_move(M, s, l);
+    const float alpha = s.scratch[0];
+    if (alpha == 0.f) {
+      if (reuse) { force_full = true; continue; }
+      break;
+    }
     iter++;
-    // fp32: a cost difference below the resolution of the cost itself is no improvement
-    if (improvement < tol + 2e-7f * scale * fabsf(cost) || scale * gradnorm < tol) break;
   }
   if (l < NVP && !(l < NV)) s.qacc[l] = 0.f;
-  if (l == 0) s.solver_iters = iter;
+  if (l == 0) s.solver_iters = iter | (nfull << 8);
   __syncthreads();
 }
 

@@ -234,6 +234,80 @@ MRE_PHASE_FN void solve_robot_rows(Sm& s, int l) {
 
 #endif  // !MRE_NEWTON
 
+// ---- connect residual of the gripper linkage in double precision
+// The two `connect` rows close each finger's four-bar (follower <-> coupler).  Their residual is a
+// 1e-5 m difference of two anchor positions; evaluated from the fp32 world poses (|x| ~ 0.8 m) it
+// carries ~5e-8 m of rounding noise, which the stiff reference acceleration (K ~ 2.5e5 1/s^2)
+// turns into torques on links of a few grams: measured finger-joint divergence from the fp64 oracle
+// 1e-4 .. 3e-2 rad over 1000 steps, although neither the state nor the solver is at fault (the same
+// noise injected into the fp64 oracle reproduces it; 1e-9 m does not).  Both anchors hang off the
+// same arm link, so the residual is evaluated in THAT link's frame from the four joint angles alone,
+// in fp64 (sin / cos by Taylor polynomials, |half angle| < 1), and only then rotated to the world.
+MRE_DEV void sincos_poly_d(double x, double& sn, double& cs) {
+  const double z = x * x;
+  sn = x * (1.0 - z / 6.0 * (1.0 - z / 20.0 * (1.0 - z / 42.0 * (1.0 - z / 72.0 * (1.0 - z / 110.0 *
+       (1.0 - z / 156.0 * (1.0 - z / 210.0)))))));
+  cs = 1.0 - z / 2.0 * (1.0 - z / 12.0 * (1.0 - z / 30.0 * (1.0 - z / 56.0 * (1.0 - z / 90.0 *
+       (1.0 - z / 132.0 * (1.0 - z / 182.0 * (1.0 - z / 240.0)))))));
+}
+MRE_DEV void dq_mul(double* r, const double* a, const double* b) {
+  const double w = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+  const double x = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+  const double y = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
+  const double z = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+  r[0] = w; r[1] = x; r[2] = y; r[3] = z;
+}
+MRE_DEV void dq_rot(double* r, const double* q, const double* v) {
+  // v + 2 w (u x v) + 2 u x (u x v)
+  const double ux = q[1], uy = q[2], uz = q[3], w = q[0];
+  const double cx = uy * v[2] - uz * v[1], cy = uz * v[0] - ux * v[2], cz = ux * v[1] - uy * v[0];
+  const double dx = uy * cz - uz * cy, dy = uz * cx - ux * cz, dz = ux * cy - uy * cx;
+  r[0] = v[0] + 2.0 * (w * cx + dx); r[1] = v[1] + 2.0 * (w * cy + dy); r[2] = v[2] + 2.0 * (w * cz + dz);
+}
+// pose of hinge body b in its parent's frame (mj_kinematics, one body): position p, rotation q
+MRE_DEV void hinge_local_d(const DevModel* M, const Sm& s, int b, double* p, double* q) {
+  double q0[4], ql[4], ax[3], jp[3], t0[3], t1[3];
+  for (int k = 0; k < 4; k++) q0[k] = (double)M->body_quat[b][k];
+  for (int k = 0; k < 3; k++) { ax[k] = (double)M->jnt_axis[b][k]; jp[k] = (double)M->jnt_pos[b][k]; }
+  const int qa = M->body_qposadr[b];
+  double sn, cs;
+  sincos_poly_d(0.5 * ((double)s.qpos[qa] - (double)M->qpos0[qa]), sn, cs);
+  ql[0] = cs; ql[1] = ax[0] * sn; ql[2] = ax[1] * sn; ql[3] = ax[2] * sn;
+  dq_mul(q, q0, ql);
+  const double n = 1.0 / sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  for (int k = 0; k < 4; k++) q[k] *= n;
+  dq_rot(t0, q0, jp);
+  dq_rot(t1, q, jp);
+  for (int k = 0; k < 3; k++) p[k] = (double)M->body_pos[b][k] + t0[k] - t1[k];
+}
+// point a (in the frame of body b) expressed in the frame of the first ancestor of b that is an arm
+// link (id < first gripper body GRIP0); chains are at most two bodies long (mre_create checks)
+constexpr int GRIP0 = 8;
+MRE_DEV int anchor_in_arm_frame_d(const DevModel* M, const Sm& s, int b, const float* a, double* out) {
+  double p[3], q[4], x[3] = {(double)a[0], (double)a[1], (double)a[2]}, t[3];
+  int cur = b;
+  for (int hop = 0; hop < 2 && cur >= GRIP0; hop++) {
+    hinge_local_d(M, s, cur, p, q);
+    dq_rot(t, q, x);
+    for (int k = 0; k < 3; k++) x[k] = p[k] + t[k];
+    cur = M->body_parent[cur];
+  }
+  for (int k = 0; k < 3; k++) out[k] = x[k];
+  return cur;
+}
+
+// a phase of its own (lanes 0, 1 = the two connect constraints): fp64 register pressure stays
+// out of the row assembly
+MRE_PHASE_FN void connect_residuals(const DevModel* M, Sm& s, int l) {
+  if (l < 2 && M->eq_type[l] == 0) {
+    double l1[3], l2[3];
+    anchor_in_arm_frame_d(M, s, M->eq_obj[l][0], M->eq_data[l], l1);
+    anchor_in_arm_frame_d(M, s, M->eq_obj[l][1], M->eq_data[l] + 3, l2);
+    for (int k = 0; k < 3; k++) s.qfrc_con[3 * l + k] = (float)(l1[k] - l2[k]);
+  }
+  __syncthreads();
+}
+
 // ------------------------- mj_makeConstraint + mj_makeImpedance + reference + project
 MRE_PHASE_FN void assemble_constraints(const DevModel* M, Sm& s, int l) {
   // ---- joint limits: lane = robot body; at most one side can be violated
@@ -282,22 +356,7 @@ MRE_PHASE_FN void assemble_constraints(const DevModel* M, Sm& s, int l) {
     s.nrrow = rnext;
     s.npp = bnext;
 #ifdef MRE_NEWTON
-    // per-cube contact lists and the block coupling of the Newton Hessian (mre_newton.h)
-    int cnt[NPROP] = {0, 0, 0, 0};
-    unsigned cr = 0u, cc = 0u;
-    for (int c = 0; c < kept; c++) {
-      const int cb1 = s.con_b1[c], cb2 = s.con_b2[c];
-      int pa = -1, pb = -1;
-      if (cb1 >= NRB) pa = cb1 - NRB;
-      if (cb2 >= NRB) { if (pa < 0) pa = cb2 - NRB; else pb = cb2 - NRB; }
-      if (pa >= 0) s.clist[pa][cnt[pa]++] = (uint8_t)c;
-      if (pb >= 0) s.clist[pb][cnt[pb]++] = (uint8_t)(c | 0x80);
-      if (s.con_rslot[c] != HDR_NONE && pa >= 0) cr |= 1u << pa;
-      if (pb >= 0) cc |= 1u << cube_pair_bit(pa, pb);
-    }
-    for (int p = 0; p < NPROP; p++) s.ccount[p] = (uint8_t)cnt[p];
-    s.cpl_robot = (uint8_t)cr; s.cpl_cubes = (uint8_t)cc;
-    s.nsched = 0; s.nblk = 0;
+    s.nsched = 0; s.nblk = 0;  // (contact lists of the Newton solver: nw_build_lists, mre_newton.h)
 #else
     build_schedule(M, s);
 #endif
@@ -327,7 +386,12 @@ MRE_PHASE_FN void assemble_constraints(const DevModel* M, Sm& s, int l) {
         const float ax[3] = {k == 0 ? 1.f : 0.f, k == 1 ? 1.f : 0.f, k == 2 ? 1.f : 0.f};
         m3mulv(p1, s.xmat[b1], M->eq_data[e]); v3add(p1, p1, s.xpos[b1]);
         m3mulv(p2, s.xmat[b2], M->eq_data[e] + 3); v3add(p2, p2, s.xpos[b2]);
-        v3sub(cp, p1, p2);
+        {
+          // residual evaluated in the common arm link's frame in fp64 (connect_residuals)
+          int root = b1;
+          while (root >= GRIP0) root = M->body_parent[root];
+          m3mulv(cp, s.xmat[root], &s.qfrc_con[3 * e]);
+        }
         jac_robot(M, s, rs, b1, p1, ax, 1.f);
         jac_robot(M, s, rs, b2, p2, ax, -1.f);
         pos = sel3(cp, k);

@@ -72,6 +72,16 @@ class BatchedPhysics:
 
     def sync(self):
         check(_lib.lib().mre_sync(self._h), "mre_sync")
+        self._keepalive = []
+
+    def _after_torch(self, *tensors) -> None:
+        """Order the handle's stream after torch's current stream (the tensors about to be handed over
+        may still be in flight there) and keep them alive until the next sync()."""
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        check(_lib.lib().mre_wait_stream(self._h, C.c_void_p(st)), "mre_wait_stream")
+        if not hasattr(self, "_keepalive"):
+            self._keepalive = []
+        self._keepalive.extend(tensors)
 
     def set_solver(self, solver: str) -> None:
         """mjOption.solver of a live handle: "PGS" or "Newton" (state and warm start carry over)."""
@@ -154,6 +164,11 @@ class BatchedPhysics:
     def qvel(self) -> np.ndarray:
         return self.get_state()[1]
 
+    def get_warmstart(self) -> np.ndarray:
+        w = np.empty((self.num_envs, MRE_NV_PAD), np.float32)
+        check(_lib.lib().mre_get_warmstart(self._h, _ptr(w)), "mre_get_warmstart")
+        return w[:, :MRE_NV]
+
     def set_warmstart(self, w) -> None:
         w = np.asarray(w, np.float32)
         if w.shape[-1] == MRE_NV:
@@ -168,6 +183,8 @@ class BatchedPhysics:
         else:
             c = np.ascontiguousarray(ctrl, np.float32)
         assert tuple(c.shape) == (self.num_envs, MRE_NU)
+        if isinstance(c, torch.Tensor) and c.is_cuda:
+            self._after_torch(c)
         check(_lib.lib().mre_set_ctrl(self._h, _ptr(c)), "mre_set_ctrl")
         if not isinstance(ctrl, torch.Tensor):
             self.sync()
@@ -180,6 +197,7 @@ class BatchedPhysics:
         """ctrl_seq: cuda float32 [T, N, 8]; one launch for T*control_steps steps."""
         assert ctrl_seq.is_cuda and ctrl_seq.dtype == torch.float32 and ctrl_seq.is_contiguous()
         assert ctrl_seq.shape[1:] == (self.num_envs, MRE_NU)
+        self._after_torch(ctrl_seq)
         check(_lib.lib().mre_rollout(self._h, ctrl_seq.data_ptr(), int(ctrl_seq.shape[0]),
                                      int(control_steps), int(flags)), "mre_rollout")
 
@@ -191,6 +209,7 @@ class BatchedPhysics:
             return None
         self._trace = torch.zeros((max_steps, nenv, MRE_NQ_PAD), dtype=torch.float32,
                                   device=self.device)
+        self._after_torch()  # the zero fill runs on torch's stream
         check(_lib.lib().mre_set_trace(self._h, self._trace.data_ptr(), nenv, max_steps),
               "mre_set_trace")
         return self._trace
@@ -258,6 +277,9 @@ class BatchedPhysics:
     def solver_stats(self) -> np.ndarray:
         st = np.empty((self.num_envs, 4), np.int32)
         check(_lib.lib().mre_get_solver_stats(self._h, _ptr(st)), "mre_get_solver_stats")
+        # column 2 = solver iterations of the last step | Hessian factorisations << 8 (Newton only)
+        self.last_factorizations = st[:, 2] >> 8
+        st[:, 2] &= 0xFF
         return st
 
     # ---------------------------------------------------------- measurement

@@ -387,6 +387,12 @@ double mro_solver_cost(const mro_data* d) { return d->solver_cost; }
 int mro_solver_iters(const mro_data* d) { return d->solver_iters; }
 int mro_ncon(const mro_data* d) { return d->ncon; }
 int mro_nefc(const mro_data* d) { return d->nefc; }
+int mro_nl(const mro_data* d) { return d->nl; }
+int mro_limit_mask(const mro_data* d) {
+  int mask = 0;
+  for (int i = 0; i < d->nefc; i++) if (d->efc_type[i] == EFC_LIMIT) mask |= 1 << (d->efc_id[i] - 1);
+  return mask;
+}
 void mro_contact(const mro_data* d, int i, double* out) {
   const mro_contact_t* c = &d->contact[i];
   memcpy(out, c->pos, 24); memcpy(out + 3, c->frame, 72);

@@ -27,7 +27,9 @@ def _oracle_envs(oracle_model, nprops, sizes):
 
 
 def _rollout_both(compiled_model, oracle_model, N, T, flags, scale, seed=0, no_constraints=False,
-                  control_steps=5, z_extra=0.0, gravity_comp=False, yaw=False, solver=None):
+                  control_steps=5, z_extra=0.0, gravity_comp=False, yaw=False, solver=None, census=False):
+    """census=True also returns, per step and env, the constraint census the solve of that step saw
+    (active contacts + 64 * bit mask of the joints at a limit), device and oracle."""
     import torch
     from mujoco_robot_environments_amd import rng
     A, _ = compiled_model
@@ -63,15 +65,21 @@ def _rollout_both(compiled_model, oracle_model, N, T, flags, scale, seed=0, no_c
     seq = torch.tensor(acts, dtype=torch.float32, device=phys.device).contiguous()
     phys.rollout(seq, control_steps=control_steps, flags=flags)
     phys.sync()
-    gq = trace.cpu().numpy()[:, :, :43]
+    tr = trace.cpu().numpy()
+    gq = tr[:, :, :43]
+    gcen = tr[:, :, 43].astype(np.int64)
     oq = np.zeros_like(gq, dtype=np.float64)
+    ocen = np.zeros(gq.shape[:2], np.int64)
     acts32 = acts.astype(np.float32).astype(np.float64)  # the device sees fp32 controls
     for i, e in enumerate(envs):
         for t in range(T):
             e.arr("ctrl")[:] = acts32[t, i]
             for k in range(control_steps):
+                ocen[t * control_steps + k, i] = e.census   # the rows the coming solve will see
                 e.step(1)
                 oq[t * control_steps + k, i] = e.arr("qpos")[:43]
+    if census:
+        return gq, oq, nprops, phys, gcen, ocen
     return gq, oq, nprops, phys
 
 
