@@ -25,9 +25,10 @@ def main():
     ap.add_argument("--num-envs", type=int, default=8192)
     ap.add_argument("--max-steps", type=int, default=None, help="pick/place pairs per episode (config: dataset.max_steps)")
     ap.add_argument("--gains", type=float, nargs=6, default=None, metavar=("KP_POS", "KD_POS", "KP_ORI", "KD_ORI", "KP_NULL", "KD_NULL"),
-                    help="OSC gains instead of osc.yaml's (e.g. the tuned 221.2 59.5 543.0 169.6 81.6 36.2)")
+                    help="OSC gains instead of osc.yaml's (config.TUNED_OSC_GAINS: 525.4 215.2 766.6 158.6 22.6 7.2)")
     ap.add_argument("--tuned-gains", action="store_true", help="config.apply_tuned_osc_gains (CMA-ES result for this arm model)")
     ap.add_argument("--render", action="store_true", help="overhead-camera observations (depth + RGB, CUDA tensors) instead of zero images")
+    ap.add_argument("--solver", choices=["Newton", "PGS"], default="Newton", help="constraint solver (the reference's MuJoCo runs Newton)")
     args = ap.parse_args()
     cfg = colour_separator_task_config()
     if args.tuned_gains:
@@ -37,7 +38,7 @@ def main():
         g = cfg.robots.arm.controller_config.controller_params.gains
         g.position.kp, g.position.kd, g.orientation.kp, g.orientation.kd, g.nullspace.kp, g.nullspace.kd = args.gains
     max_steps = args.max_steps or cfg.dataset.max_steps
-    env = BatchedRearrangementEnv(cfg=cfg, num_envs=args.num_envs, render=args.render)
+    env = BatchedRearrangementEnv(cfg=cfg, num_envs=args.num_envs, render=args.render, solver=args.solver)
     cam = "overhead_camera/overhead_camera"
     t0 = time.time()
     _, _, _, obs = env.reset()
@@ -60,7 +61,7 @@ def main():
         nsim = 2 * 9000
         print(f"pair {step}: {in_progress.sum()} envs in progress, all phases converged in "
               f"{int(env.last_converged.sum())}/{args.num_envs} envs, "
-              f"{args.num_envs * nsim / (time.time() - t0):.3g} env-steps/s so far")
+              f"{args.num_envs * (step + 1) * nsim / (time.time() - t0):.3g} env-steps/s so far (reset included)")
     done = ~env.sort_colours()[0]
     print(f"{int(done.sum())}/{args.num_envs} envs have every cube in its colour's target after {len(episodes)} pairs; "
           f"intrinsics fx={metadata['intrinsics']['fx']:.1f}; wall {time.time() - t0:.1f} s")

@@ -124,6 +124,11 @@ int mre_gripper_set(mre_env*, const uint8_t* closed);
  * (uint8, device or host, may be NULL) = arm_converged flag. */
 int mre_run_controller(mre_env*, int nticks, int control_steps, uint8_t* converged_out);
 
+/* OSC.compute_control_output() and MinMax.compute_control_output() (models/robot_arm.py:71,73)
+ * on the CURRENT state, without stepping: tau[N][7] arm torques (host or device, may be NULL),
+ * grip[N] gripper command (may be NULL).  The commands are also left in the ctrl rows. */
+int mre_osc_compute(mre_env*, float* tau, float* grip);
+
 /* physics.data.site_xpos[pinch] (models/robot_arm.py:55-58), controller site pose,
  * prop poses (props_info, tasks/rearrangement.py:245-246): rows [N][3], [N][7], [N][4][7] */
 int mre_get_sites(mre_env*, float* tcp_pos, float* eef_pose, float* prop_pose);

@@ -67,6 +67,13 @@ class OSC:
                                     velocity=self.eef_target_velocity,
                                     angular_velocity=self.eef_target_angular_velocity)
 
+    def compute_control_output(self):
+        """Arm torques [N, 7] (or [7] for a batch of one) of the law on the current state
+        (models/robot_arm.py:71): evaluated by the step kernel's OSC phase in a zero-step launch."""
+        tau, _ = self.physics.osc_compute()
+        tau = tau.astype(np.float64)
+        return tau[0] if self.physics.num_envs == 1 else tau
+
     def current_position_error(self):
         _, eef, _ = self.physics.sites()
         return self.eef_target_position - eef[:, :3]

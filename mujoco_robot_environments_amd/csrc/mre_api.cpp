@@ -1008,6 +1008,31 @@ extern "C" int mre_run_controller(mre_env* e, int nticks, int control_steps, uin
   return MRE_OK;
 }
 
+// OSC.compute_control_output() + MinMax.compute_control_output() on the current state, no stepping
+// (models/robot_arm.py:71-73): tau[N][7] arm torques, grip[N] gripper command (either may be NULL)
+extern "C" int mre_osc_compute(mre_env* e, float* tau, float* grip) {
+  if (!e) return fail(MRE_ERR_ARG, "null handle");
+  StepArgs a;
+  fill_args(e, a);
+  a.nsteps = 0; a.control_steps = 1; a.mode = CTRL_OSC; a.flags = F_OSC_EVAL; a.trace = nullptr;
+  HIPCHK(hipSetDevice(e->device));
+  launch_compact(e, a, e->stream);
+  HIPCHK(hipGetLastError());
+  const size_t N = (size_t)e->N;
+  std::vector<float> h(N * NU);
+  int rc = copy_out(e, h.data(), e->ctrl, N * NU * 4);
+  if (rc) return rc;
+  std::vector<float> ht(N * 7), hg(N);
+  for (size_t i = 0; i < N; i++) {
+    for (int k = 0; k < 7; k++) ht[i * 7 + k] = h[i * NU + k];
+    hg[i] = h[i * NU + 7];
+  }
+  // (copy_out synchronises: the staging vectors die with this frame)
+  if (tau) { rc = copy_out(e, tau, ht.data(), N * 7 * 4); if (rc) return rc; }
+  if (grip) { rc = copy_out(e, grip, hg.data(), N * 4); if (rc) return rc; }
+  return MRE_OK;
+}
+
 // ---- PropPlacer.__call__ (environment/prop_initializer.py:164-283), batched.
 // Same counter-based stream and rejection rule as mujoco_robot_environments_amd/placement.py
 // (splitmix64 keyed by (seed, GLOBAL env id, attempt, channel)): sample position ~ U(workspace),

@@ -41,7 +41,15 @@ static_assert(robot_dof_madr(NRV) == NMR, "robot mass-matrix size");
 // covers cubes resting / sliding on the table; the large one (6 per CU) covers grasps and piles.
 // mre_api.cpp runs every env on the compact kernel and re-runs, from the saved pre-launch state, the
 // envs that report an overflow on the large kernel, so results never depend on the compact caps.
-#ifdef MRE_LARGE_CAPS
+#if defined(MRE_LARGE_CAPS) && defined(MRE_NEWTON)
+// the Newton kernels carry no M^-1 J' pool and no block records: the same LDS (6 workgroups per CU)
+// holds more rows
+constexpr int NCON_MAX = 50;
+constexpr int NEFC_MAX = 166;
+constexpr int NRROW_MAX = 100;
+constexpr int NPP_MAX = 16;
+constexpr int MAXBLK = 58;
+#elif defined(MRE_LARGE_CAPS)
 constexpr int NCON_MAX = 44;   // active contacts kept per env
 constexpr int NEFC_MAX = 148;  // constraint rows per env (7 equality + limits + 3 per contact)
 constexpr int NRROW_MAX = 83;  // rows with a robot part (7 equality + limits + 3 per robot contact)
@@ -117,7 +125,10 @@ struct OscConfig {
 
 // F_CONV_CONTINUE: this launch continues a run_controller call cut into several launches (the
 // converged flag carries over); F_CONV_OPEN: more launches follow (NOT_CONVERGED is not judged yet)
-enum StepFlags : unsigned { F_NO_CONSTRAINTS = 1u, F_FREEZE_ROBOT = 2u, F_CONV_CONTINUE = 4u, F_CONV_OPEN = 8u };
+// F_OSC_EVAL (zero-step launch): evaluate the controller on the current state and store the command
+// (OSC.compute_control_output + MinMax.compute_control_output) in ctrl without stepping
+enum StepFlags : unsigned { F_NO_CONSTRAINTS = 1u, F_FREEZE_ROBOT = 2u, F_CONV_CONTINUE = 4u, F_CONV_OPEN = 8u,
+                            F_OSC_EVAL = 16u };
 enum CtrlMode : int { CTRL_HELD = 0, CTRL_SEQ = 1, CTRL_OSC = 2 };
 
 struct StepArgs {

@@ -751,7 +751,9 @@ MRE_DEV void step_body(const StepArgs& a, Sm& s) {
     const bool clamped = smooth_forces(M, s, l);
     MRE_STAMP(5);
     if (constrained) {
-#ifdef MRE_NEWTON
+#if defined(MRE_NEWTON) && defined(MRE_PHASE_STAMPS)
+      newton_solve(M, s, l, stamp_acc, stamp_t);
+#elif defined(MRE_NEWTON)
       newton_solve(M, s, l);
 #else
       solve_constraints(M, s, l);
@@ -781,6 +783,18 @@ MRE_DEV void step_body(const StepArgs& a, Sm& s) {
     }
   }
   MRE_STAMP(7);
+  if (a.nsteps == 0 && (a.flags & F_OSC_EVAL) != 0 && a.mode == CTRL_OSC) {
+    // OSC.compute_control_output() on the current state (models/robot_arm.py:71): the position and
+    // velocity stages the trailing mj_step1 would have left behind, then the torque law
+    position_stage(M, s, l);
+    crb_mass_matrix(M, s, l);
+    __syncthreads();
+    velocity_stage(M, s, l);
+    __syncthreads();
+    osc_compute(M, s, osc, oscp, s.osc_tgt, l);
+    if (l == 0) s.ctrl[NU - 1] = grip_cmd;
+    __syncthreads();
+  }
   // ---- final kinematics for site queries
   kinematics_only(M, s, l);
   if (a.mode == CTRL_OSC && a.nsteps > 0) {

@@ -580,7 +580,18 @@ MRE_PHASE_FN float nw_search_move(const DevModel* M, Sm& s, int l) {
 // difference left residual forces of ~3e-5 N m on the finger links, whose inertia is 1e-5 kg m^2:
 // a drift of 1e-4 .. 3e-3 rad over 1000 steps against the oracle.)  The check costs one more
 // direction, which re-uses the factor when the active set did not change.
+#ifdef MRE_PHASE_STAMPS
+#define NW_STAMP(k)                                                          \
+  do {                                                                       \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();            \
+    if ((8 + (k)) / 4 == MRE_PHASE_STAMPS) stamp_acc[(k) % 4] += now_ - stamp_t; \
+    stamp_t = now_;                                                          \
+  } while (0)
+MRE_DEV void newton_solve(const DevModel* M, Sm& s, int l, unsigned long long* stamp_acc, unsigned long long& stamp_t) {
+#else
+#define NW_STAMP(k) do {} while (0)
 MRE_DEV void newton_solve(const DevModel* M, Sm& s, int l) {
+#endif
   const float tol = M->tolerance;
   const int max_iter = M->iterations;
   const int nscalar = 7 + s.nl, ncon = s.ncon;
@@ -589,6 +600,7 @@ MRE_DEV void newton_solve(const DevModel* M, Sm& s, int l) {
     msum += 3.f * s.prop_mass[p] + s.prop_inertia[p][0] + s.prop_inertia[p][1] + s.prop_inertia[p][2];
   const float scale = 1.0f / msum;
   nw_setup(M, s, l);
+  NW_STAMP(0);
   // fp32 runs the decrement test a decade below MuJoCo's tolerance: the reference's Newton
   // converges quadratically in fp64 and so ends far below its own threshold, while a solve that
   // stops AT the threshold keeps a residual force of the threshold's size (2e-5 N m on the finger
@@ -604,9 +616,11 @@ MRE_DEV void newton_solve(const DevModel* M, Sm& s, int l) {
     const bool reuse = have_factor && !force_full && mk == mf;
     if (reuse) {
       nw_direction_reuse(M, s, l);
+      NW_STAMP(2);
     } else {
       nw_direction(M, s, l);
       mf = mk; have_factor = true; nfull++;
+      NW_STAMP(1);
     }
     const float dec = s.scratch[2];
     if (!(dec == dec)) break;                          // non-finite: keep the last iterate
@@ -620,6 +634,7 @@ MRE_DEV void newton_solve(const DevModel* M, Sm& s, int l) {
     }
     prev_dec = dec; mprev = mk; force_full = false;
     nw_search_move(M, s, l);
+    NW_STAMP(3);
     const float alpha = s.scratch[0];
     if (alpha == 0.f) {
       if (reuse) { force_full = true; continue; }

@@ -250,6 +250,14 @@ class BatchedPhysics:
         check(_lib.lib().mre_osc_set_target(self._h, _ptr(p), _ptr(q), _ptr(v), _ptr(w), _ptr(m)),
               "mre_osc_set_target")
 
+    def osc_compute(self):
+        """(tau [N, 7], gripper command [N]) of the controllers on the current state, no stepping:
+        OSC.compute_control_output() / MinMax.compute_control_output() (models/robot_arm.py:71,73)."""
+        tau = np.empty((self.num_envs, 7), np.float32)
+        grip = np.empty(self.num_envs, np.float32)
+        check(_lib.lib().mre_osc_compute(self._h, _ptr(tau), _ptr(grip)), "mre_osc_compute")
+        return tau, grip
+
     def gripper_set(self, closed) -> None:
         c = np.ascontiguousarray(np.broadcast_to(np.asarray(closed, np.uint8), (self.num_envs,)))
         check(_lib.lib().mre_gripper_set(self._h, _ptr(c)), "mre_gripper_set")

@@ -9,9 +9,15 @@ observation shapes, ``pick`` / ``place`` scripted macros, ``sort_colours`` / ``p
 axis on every array; ``RearrangementEnv`` is the batch of one with reference shapes and
 reference error behaviour (RuntimeError when a phase does not converge).
 
-Rendering is out of scope: observations are zero images of
-the reference shapes; pixel/world conversions use the analytic pinhole model and the table
-plane for depth.
+Observations: with ``render=True`` the batched overhead camera (csrc/mre_render.hip) renders
+depth + RGB of every env and ``props_info`` boxes / ``pixel_2_world``
+read the rendered segmentation / depth; with ``render=False`` (BASELINE configs[4]: "render
+stubbed") they are zero images of the reference shapes and the pixel/world conversions use the
+analytic pinhole model with the table plane for depth.
+
+Solver: the reference sets timestep / gravity / nconmax / njmax only (tasks/rearrangement.py:77-80),
+so its MuJoCo runs the default Newton solver -- the env's default here too (``solver="Newton"``);
+``solver="PGS"`` selects the solver BASELINE.json's north_star prescribes for the bench.
 """
 from __future__ import annotations
 
@@ -77,7 +83,8 @@ class BatchedRearrangementEnv:
     """num_envs independent RearrangementEnv instances stepped in lockstep on one GPU."""
 
     def __init__(self, cfg: Optional[Cfg] = None, num_envs: int = 1, viewer=None, device: int = 0,
-                 seed: Optional[int] = None, env_id_offset: int = 0, env_ids=None, render: bool = False):
+                 seed: Optional[int] = None, env_id_offset: int = 0, env_ids=None, render: bool = False,
+                 solver: str = "Newton"):
         self._cfg = cfg if cfg is not None else DEFAULT_CONFIG
         cfg = self._cfg
         self.num_envs = int(num_envs)
@@ -90,7 +97,7 @@ class BatchedRearrangementEnv:
         ac = cfg.robots.arm.actuator_config
         lim = [float(ac[ac.joint_actuator_mapping[f"joint{i + 1}"]].ctrlrange.split()[1]) for i in range(7)]
         scene = _spec.default_scene(dict(physics_dt=cfg.physics_dt, gravity=cfg.gravity, motor_ctrlrange=lim,
-                                         home=cfg.robots.arm.default_configurations.home))
+                                         home=cfg.robots.arm.default_configurations.home, solver=solver))
         self._model = _compile.compile_scene(scene)
         self._physics = BatchedPhysics(self.num_envs, model=self._model, device=device)
         # ---- props: count / size / colour per env (environment/props.py:583-639)
@@ -467,8 +474,9 @@ class RearrangementEnv(BatchedRearrangementEnv):
     """Batch of one with the reference's shapes and error behaviour
     (signature: tasks/rearrangement.py:54-58)."""
 
-    def __init__(self, viewer=None, cfg: Optional[Cfg] = None, device: int = 0, render: bool = True):
-        super().__init__(cfg=cfg, num_envs=1, viewer=viewer, device=device, render=render)
+    def __init__(self, viewer=None, cfg: Optional[Cfg] = None, device: int = 0, render: bool = True,
+                 solver: str = "Newton"):
+        super().__init__(cfg=cfg, num_envs=1, viewer=viewer, device=device, render=render, solver=solver)
 
     def _compute_observation(self):
         o = super()._compute_observation()

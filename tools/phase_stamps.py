@@ -8,15 +8,19 @@ import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "mujoco_robot_environments_amd", "csrc")
 DIAG = os.path.join(ROOT, "tools", "_diag")
-NAMES = ["position+crb+factor", "velocity", "collide", "assemble", "control", "smooth", "solve", "integrate+io"]
+NAMES = ["position+crb+factor", "velocity", "collide", "assemble", "control", "smooth", "solve", "integrate+io",
+         "newton: setup", "newton: direction (H, factor, solves)", "newton: direction (factor re-used)", "newton: line search + move + update"]
 
 if sys.argv[1] == "build":
     os.makedirs(DIAG, exist_ok=True)
-    for k in (0, 1):
+    for k in (0, 1, 2):
         base = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
         objs = []
         for name, src, flags in (("k", "mre_kernels.hip", [f"-DMRE_PHASE_STAMPS={k}"]),
-                                 ("kl", "mre_kernels.hip", ["-DMRE_LARGE_CAPS", f"-DMRE_PHASE_STAMPS={k}"]), ("r", "mre_render.hip", []),
+                                 ("kl", "mre_kernels.hip", ["-DMRE_LARGE_CAPS", f"-DMRE_PHASE_STAMPS={k}"]),
+                                 ("kn", "mre_kernels.hip", ["-DMRE_NEWTON", f"-DMRE_PHASE_STAMPS={k}"]),
+                                 ("kln", "mre_kernels.hip", ["-DMRE_LARGE_CAPS", "-DMRE_NEWTON", f"-DMRE_PHASE_STAMPS={k}"]),
+                                 ("r", "mre_render.hip", []),
                                  ("api", "mre_api.cpp", [])):
             objs.append(os.path.join(DIAG, f"{name}{k}.o"))
             subprocess.check_call(base + flags + ["-c", os.path.join(CSRC, src), "-o", objs[-1]])
@@ -24,14 +28,16 @@ if sys.argv[1] == "build":
                                os.path.join(DIAG, f"libmre_stamps{k}.so")] + objs)
 elif sys.argv[1] == "run":
     if "MRE_LIB" not in os.environ:
+        solver = sys.argv[3] if len(sys.argv) > 3 else "PGS"
         tot = []
-        for k in (0, 1):
+        for k in ((0, 1, 2) if solver == "Newton" else (0, 1)):
             env = dict(os.environ, MRE_LIB=os.path.join(DIAG, f"libmre_stamps{k}.so"))
             out = subprocess.check_output([sys.executable, __file__, "run"] + sys.argv[2:], env=env, text=True)
             tot += [float(x) for x in out.split()[-4:]]
-        s = sum(tot)
+        s = sum(tot[:8])
+        print(f"solver {solver}: cycles / 16 per env and tick (5 steps), share of the tick")
         for n, v in zip(NAMES, tot):
-            print(f"{n:22s} {v:12.0f}  {100 * v / s:5.1f} %")
+            print(f"{n:48s} {v:12.0f}  {100 * v / s:5.1f} %")
     else:
         sys.path.insert(0, ROOT)
         import numpy as np, torch
@@ -39,11 +45,16 @@ elif sys.argv[1] == "run":
         from mujoco_robot_environments_amd import rng
         from mujoco_robot_environments_amd.physics import BatchedPhysics
         N = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
-        phys = BatchedPhysics(N); ids = np.arange(N)
+        solver = sys.argv[3] if len(sys.argv) > 3 else "PGS"
+        nticks = int(sys.argv[4]) if len(sys.argv) > 4 else 20
+        phys = BatchedPhysics(N, solver=solver); ids = np.arange(N)
         bench.setup_envs(phys, 0, ids)
-        seq = torch.from_numpy(rng.random_actions(0, ids, np.arange(20)).astype(np.float32)).to(phys.device).contiguous()
+        seq = torch.from_numpy(rng.random_actions(0, ids, np.arange(nticks)).astype(np.float32)).to(phys.device).contiguous()
         acc = np.zeros(4)
-        for t in range(20):
+        for t in range(nticks):
             phys.rollout(seq[t:t + 1], control_steps=5)
-            acc += phys.solver_stats().astype(np.float64).mean(axis=0)
-        print(*(acc / 20))
+            st = np.empty((N, 4), np.int32)
+            from mujoco_robot_environments_amd import lib as _lib
+            _lib.check(_lib.lib().mre_get_solver_stats(phys._h, st.ctypes.data), "stats")
+            acc += st.astype(np.float64).mean(axis=0)
+        print(*(acc / nticks))
