@@ -134,10 +134,72 @@ def cpu_baseline(seed, budget_s=12.0, nenv=64):
         O.batch_step(m, envs[:4], acts, CONTROL_STEPS, 1)
         ticks1 += 1
     dt1 = time.perf_counter() - t1
+    # the oracle's Newton (what the reference's MuJoCo runs), same envs, a few seconds
+    for e in envs:
+        e.set_solver("Newton")
+    t2, ticks2 = time.perf_counter(), 0
+    while time.perf_counter() - t2 < 4.0:
+        acts = rng.random_actions(seed, ids, [ticks + ticks1 + ticks2])[0]
+        O.batch_step(m, envs, acts, CONTROL_STEPS, threads)
+        ticks2 += 1
+    dt2 = time.perf_counter() - t2
     return {"finite_envs": finite, "value": nenv * ticks * CONTROL_STEPS / dt, "unit": "env-steps/s", "cores": threads,
+            "newton_value": nenv * ticks2 * CONTROL_STEPS / dt2,
             "kind": "port", "sample": f"{nenv} envs x {ticks} ticks x {CONTROL_STEPS} steps, fp64 oracle "
             f"(PGS, same scene/actions), OpenMP {threads} threads, {dt:.1f} s",
             "single_thread_value": 4 * ticks1 * CONTROL_STEPS / dt1}
+
+
+def mujoco_probe(seed, budget_s=6.0, nenv=4):
+    """if ``import mujoco`` happens to succeed on this host, run genuine
+    mj_step on the MJCF this repo emits from its own spec (tools/emit_mjcf.py) -- same scenes, same action
+    law -- time it and report how far the oracle is from it.  Never a dependency: absent -> {"mujoco": None}."""
+    try:
+        import mujoco
+    except Exception as e:  # ModuleNotFoundError on this image
+        return {"mujoco": None, "reason": f"{type(e).__name__}: {e}"}
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import emit_mjcf
+    from mujoco_robot_environments_amd import placement, rng
+    from mujoco_robot_environments_amd.model import compile as MC
+    from oracle import oracle as O
+    A = MC.compile_scene()
+    om = O.Model(MC.to_blob(A))
+    ids = np.arange(nenv)
+    nprops, sizes = rng.prop_params(seed, ids)
+    pose, _ = placement.sample_poses(seed, ids, nprops, sizes, WS_MIN, WS_MAX)
+    out = {"mujoco": mujoco.__version__}
+    for solver in ("Newton", "PGS"):
+        worst, steps, t_mj = 0.0, 0, 0.0
+        for i in range(nenv):
+            n = int(nprops[i])
+            m = mujoco.MjModel.from_xml_string(emit_mjcf.emit(nprops=n, prop_sizes=sizes[i], solver=solver))
+            d = mujoco.MjData(m)
+            e = O.Env(om, n, sizes[i])
+            e.set_solver(solver)
+            q = e.arr("qpos")
+            q[:7] = A["home_qpos"]
+            for p in range(n):
+                q[15 + 7 * p: 22 + 7 * p] = pose[i, p]
+            d.qpos[:] = q[:15 + 7 * n]
+            e.forward()
+            mujoco.mj_forward(m, d)
+            for t in range(200):
+                a = rng.random_actions(seed, ids[i:i + 1], [t])[0, 0]
+                d.ctrl[:] = a
+                e.arr("ctrl")[:] = a
+                t0 = time.perf_counter()
+                for _ in range(CONTROL_STEPS):
+                    mujoco.mj_step(m, d)
+                t_mj += time.perf_counter() - t0
+                e.step(CONTROL_STEPS)
+                steps += CONTROL_STEPS
+                worst = max(worst, float(np.abs(d.qpos - e.arr("qpos")[:15 + 7 * n]).max()))
+                if t_mj > budget_s:
+                    break
+        out[solver] = {"oracle_vs_mujoco_max_dqpos": worst, "mujoco_steps_per_s_1_thread": steps / max(t_mj, 1e-9),
+                       "sample": f"{nenv} envs, {steps} steps"}
+    return out
 
 
 def spawn_ranks(args) -> int:
@@ -299,8 +361,12 @@ def main():
         res["newton"] = runs["Newton"]
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(args.seed)
+        probe = mujoco_probe(args.seed)
+        res["mujoco"] = probe["mujoco"]          # version string, or null: MuJoCo is not on this host
+        res["mujoco_probe"] = probe
     elif rank == 0:
         res["cpu_baseline"] = None
+        res["mujoco"] = None
     if rank == 0:
         print(json.dumps(res))
     if world > 1:

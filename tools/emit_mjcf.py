@@ -1,0 +1,154 @@
+"""MJCF of this repo's scene spec (model/spec.py) -- the pinning hook of SURVEY.md section 8(c)/(d).
+
+The reference's arithmetic is MuJoCo 3.2.7's (pyproject.toml:42), which is absent from this image and
+cannot travel to the GPU box; the oracle is therefore "parity unpinned".  This module emits the
+SAME model the oracle and the kernels consume (same body tree before fusing, inertials, hull boxes,
+contact filters, equality / tendon / actuators, options) as an MJCF string, so that wherever
+``import mujoco`` happens to succeed (bench.py's cpu_baseline leg and tests/test_mujoco_probe.py try
+it at run time) genuine ``mj_step`` can be run on it and compared with the oracle.  Never a
+dependency, never installed; nothing of the reference is read.
+
+    python tools/emit_mjcf.py [--nprops 4] [--solver Newton] > scene.xml
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+from typing import Optional, Sequence
+from xml.sax.saxutils import quoteattr
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from mujoco_robot_environments_amd.model import spec as S  # noqa: E402
+
+# contype / conaffinity bit masks reproducing compile.py's static pair filter: robot x robot and
+# robot x ground never collide; props collide with everything; table and ground are static
+_MASKS = {"robot": (1, 0), "pad": (1, 0), "prop": (2, 3), "table": (0, 3), "ground": (0, 2)}
+
+
+def _v(x) -> str:
+    return " ".join(repr(float(t)) for t in x)
+
+
+def _geom(g: dict, size=None) -> str:
+    ct, ca = _MASKS[g["group"]]
+    a = [f"name={quoteattr(g['name'])}", f'contype="{ct}"', f'conaffinity="{ca}"',
+         f'friction="{_v(g["friction"])}"', f'priority="{int(g["priority"])}"', f'condim="{int(g["condim"])}"',
+         f'margin="{float(g["margin"])!r}"', f'gap="{float(g["gap"])!r}"', f'solref="{_v(g["solref"])}"',
+         f'solimp="{_v(g["solimp"])}"']
+    if g["type"] == "plane":
+        a += ['type="plane"', 'size="2 2 2"']
+    else:
+        a += ['type="box"', f'size="{_v(size if size is not None else g["size"])}"', f'pos="{_v(g["pos"])}"',
+              f'quat="{_v(g["quat"])}"']
+        if g["mass"] is not None:
+            a.append(f'mass="{float(g["mass"])!r}"')
+    return "<geom " + " ".join(a) + "/>"
+
+
+def _joint(j: dict) -> str:
+    if j["type"] == "free":
+        return f"<freejoint name={quoteattr(j['name'])}/>"
+    return (f"<joint name={quoteattr(j['name'])} type=\"hinge\" axis=\"{_v(j['axis'])}\" pos=\"{_v(j['pos'])}\" "
+            f"range=\"{_v(j['range'])}\" limited=\"true\" armature=\"{float(j['armature'])!r}\" "
+            f"damping=\"{float(j['damping'])!r}\" stiffness=\"{float(j['stiffness'])!r}\" "
+            f"springref=\"{float(j['springref'])!r}\" solreflimit=\"{_v(j['solreflimit'])}\" "
+            f"solimplimit=\"{_v(j['solimplimit'])}\"/>")
+
+
+def _inertial(i: dict) -> str:
+    if i["fullinertia"] is not None:
+        return (f"<inertial mass=\"{float(i['mass'])!r}\" pos=\"{_v(i['pos'])}\" "
+                f"fullinertia=\"{_v(i['fullinertia'])}\"/>")
+    return (f"<inertial mass=\"{float(i['mass'])!r}\" pos=\"{_v(i['pos'])}\" quat=\"{_v(i['quat'])}\" "
+            f"diaginertia=\"{_v(i['diaginertia'])}\"/>")
+
+
+def _body(node: dict, out: list, depth: int, prop_sizes, nprops: int) -> None:
+    name = node["name"]
+    if name.startswith("prop_"):
+        p = int(name.split("_")[1])
+        if p >= nprops:
+            return
+    pad = "  " * depth
+    if name == "world":
+        for g in node["geoms"]:
+            out.append(pad + _geom(g))
+        for ch in node["children"]:
+            _body(ch, out, depth, prop_sizes, nprops)
+        return
+    out.append(f"{pad}<body name={quoteattr(name)} pos=\"{_v(node['pos'])}\" quat=\"{_v(node['quat'])}\">")
+    if node["joint"] is not None:
+        out.append(pad + "  " + _joint(node["joint"]))
+    if node["inertial"] is not None:
+        out.append(pad + "  " + _inertial(node["inertial"]))
+    for g in node["geoms"]:
+        size = None
+        if name.startswith("prop_") and prop_sizes is not None:
+            size = prop_sizes[int(name.split("_")[1])]
+        out.append(pad + "  " + _geom(g, size))   # (a body with <inertial> ignores its geoms' masses)
+    for s in node["sites"]:
+        out.append(f"{pad}  <site name={quoteattr(s['name'])} pos=\"{_v(s['pos'])}\" quat=\"{_v(s['quat'])}\"/>")
+    for ch in node["children"]:
+        _body(ch, out, depth + 1, prop_sizes, nprops)
+    out.append(f"{pad}</body>")
+
+
+def emit(scene: Optional[dict] = None, nprops: int = 4, prop_sizes: Optional[Sequence] = None,
+         solver: Optional[str] = None) -> str:
+    """MJCF string of ``scene`` (default: spec.default_scene()) with the first ``nprops`` cube slots and
+    optional per-cube half sizes [4][3]."""
+    scene = scene or S.default_scene()
+    o = scene["option"]
+    out = ['<mujoco model="rearrangement_amd_spec">',
+           '  <compiler angle="radian" autolimits="true" inertiafromgeom="auto"/>',
+           f'  <option timestep="{float(o["timestep"])!r}" gravity="{_v(o["gravity"])}" integrator="{o["integrator"]}" '
+           f'cone="{o["cone"]}" impratio="{float(o["impratio"])!r}" solver="{solver or o["solver"]}" '
+           f'iterations="{int(o["iterations"])}" tolerance="{float(o["tolerance"])!r}" '
+           f'ls_iterations="{int(o.get("ls_iterations", 50))}" ls_tolerance="{float(o.get("ls_tolerance", 0.01))!r}"/>',
+           '  <worldbody>']
+    _body(scene["world"], out, 2, prop_sizes, nprops)
+    out.append('  </worldbody>')
+    out.append('  <equality>')
+    for e in scene["equality"]:
+        if e["type"] == "connect":
+            out.append(f'    <connect body1={quoteattr(e["body1"])} body2={quoteattr(e["body2"])} anchor="{_v(e["anchor"])}" '
+                       f'solref="{_v(e["solref"])}" solimp="{_v(e["solimp"])}"/>')
+        else:
+            out.append(f'    <joint joint1={quoteattr(e["joint1"])} joint2={quoteattr(e["joint2"])} polycoef="{_v(e["polycoef"])}" '
+                       f'solref="{_v(e["solref"])}" solimp="{_v(e["solimp"])}"/>')
+    out.append('  </equality>')
+    t = scene["tendon"]
+    out.append('  <tendon>')
+    out.append(f'    <fixed name={quoteattr(t["name"])}>')
+    for j, c in zip(t["joints"], t["coef"]):
+        out.append(f'      <joint joint={quoteattr(j)} coef="{float(c)!r}"/>')
+    out.append('    </fixed>')
+    out.append('  </tendon>')
+    out.append('  <actuator>')
+    for a in scene["actuators"]:
+        if a["kind"] == "motor":
+            out.append(f'    <motor name={quoteattr(a["name"])} joint={quoteattr(a["joint"])} gear="1" '
+                       f'ctrlrange="{_v(a["ctrlrange"])}" ctrllimited="true"/>')
+        else:
+            out.append(f'    <general name={quoteattr(a["name"])} tendon={quoteattr(a["tendon"])} gaintype="fixed" biastype="affine" '
+                       f'gainprm="{float(a["gainprm"])!r} 0 0" biasprm="{_v(a["biasprm"])}" ctrlrange="{_v(a["ctrlrange"])}" '
+                       f'ctrllimited="true" forcerange="{_v(a["forcerange"])}" forcelimited="true"/>')
+    out.append('  </actuator>')
+    out.append('</mujoco>')
+    return "\n".join(out) + "\n"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--nprops", type=int, default=4)
+    ap.add_argument("--solver", choices=["PGS", "Newton"], default=None)
+    args = ap.parse_args()
+    sys.stdout.write(emit(nprops=args.nprops, solver=args.solver))
+
+
+if __name__ == "__main__":
+    main()
