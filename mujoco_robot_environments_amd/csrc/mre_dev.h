@@ -10,6 +10,7 @@ namespace mre {
 // in mre_create; mismatch -> MRE_ERR_MODEL).
 constexpr int NB = 20;     // bodies incl. world: 7 arm + 8 gripper + 4 cubes
 constexpr int NRB = 16;    // world + robot bodies (ids 0..15)
+constexpr int GRIP_BODY0 = 8;  // first finger body (8..15: two four-bar fingers below arm link 7)
 constexpr int NV = 39;
 constexpr int NRV = 15;    // robot dofs (ids 0..14), cube p owns dofs 15+6p..
 constexpr int NQ = 43;

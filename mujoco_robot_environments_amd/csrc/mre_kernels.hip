@@ -96,7 +96,10 @@ struct Sm {
   // Its head doubles as the home of what only S1a / S1b need (dead before the collision):
   union {
     float JpA[3 * NCON_MAX][6];          // prop part A of every contact row
-    struct { float cinert[NB][10], crb[NRB][10]; };  // spatial inertias (S1a/S1b)
+    struct {  // spatial inertias (S1a/S1b); gP / gC: per gripper dof, the momentum map crb * cdof and the
+              // cdof about the pinch site in the frame of the arm's last link (gripper_local)
+      float cinert[NB][10], crb[NRB][10], gP[NRB - GRIP_BODY0][6], gC[NRB - GRIP_BODY0][6];
+    };
   };
   float JpB[3 * NPP_MAX][6];             // prop part B (cube-cube contacts only)
   union {
@@ -281,6 +284,130 @@ MRE_DEV void prop_cdof(const Sm& s, int b, int j, float* c) {
   }
 }
 
+// ---- fp64 helpers for the finger linkage (gripper_local here, connect_residuals in mre_solver.h)
+// The finger links weigh a few grams and sit 0.5 m from the robot's centre of mass: in the c-frame
+// (spatial quantities about that centre, fp32) their inertias are differences of 1e-3-sized terms
+// that leave 1e-5 kg m^2 -- 2e-5 of relative error in the finger rows of M (measured against the
+// oracle: 2e-3 rad/s^2 of systematic error on finger accelerations of 50..130 rad/s^2, i.e. a drift
+// of 1e-4 .. 3e-3 rad over 1000 steps).  Everything below the arm's last link is a function of the
+// eight finger joint angles alone, so it is evaluated in THAT link's frame, about the pinch site, in
+// fp64 (sin / cos by Taylor polynomials, |half angle| < 1), and only the results are rounded.
+MRE_DEV void sincos_poly_d(double x, double& sn, double& cs) {
+  const double z = x * x;
+  sn = x * (1.0 - z / 6.0 * (1.0 - z / 20.0 * (1.0 - z / 42.0 * (1.0 - z / 72.0 * (1.0 - z / 110.0 *
+       (1.0 - z / 156.0 * (1.0 - z / 210.0)))))));
+  cs = 1.0 - z / 2.0 * (1.0 - z / 12.0 * (1.0 - z / 30.0 * (1.0 - z / 56.0 * (1.0 - z / 90.0 *
+       (1.0 - z / 132.0 * (1.0 - z / 182.0 * (1.0 - z / 240.0)))))));
+}
+MRE_DEV void dq_mul(double* r, const double* a, const double* b) {
+  const double w = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+  const double x = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+  const double y = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
+  const double z = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+  r[0] = w; r[1] = x; r[2] = y; r[3] = z;
+}
+MRE_DEV void dq_rot(double* r, const double* q, const double* v) {
+  // v + 2 w (u x v) + 2 u x (u x v)
+  const double ux = q[1], uy = q[2], uz = q[3], w = q[0];
+  const double cx = uy * v[2] - uz * v[1], cy = uz * v[0] - ux * v[2], cz = ux * v[1] - uy * v[0];
+  const double dx = uy * cz - uz * cy, dy = uz * cx - ux * cz, dz = ux * cy - uy * cx;
+  r[0] = v[0] + 2.0 * (w * cx + dx); r[1] = v[1] + 2.0 * (w * cy + dy); r[2] = v[2] + 2.0 * (w * cz + dz);
+}
+// pose of hinge body b in its parent's frame (mj_kinematics, one body): position p, rotation q
+MRE_DEV void hinge_local_d(const DevModel* M, const Sm& s, int b, double* p, double* q) {
+  double q0[4], ql[4], ax[3], jp[3], t0[3], t1[3];
+  for (int k = 0; k < 4; k++) q0[k] = (double)M->body_quat[b][k];
+  for (int k = 0; k < 3; k++) { ax[k] = (double)M->jnt_axis[b][k]; jp[k] = (double)M->jnt_pos[b][k]; }
+  const int qa = M->body_qposadr[b];
+  double sn, cs;
+  sincos_poly_d(0.5 * ((double)s.qpos[qa] - (double)M->qpos0[qa]), sn, cs);
+  ql[0] = cs; ql[1] = ax[0] * sn; ql[2] = ax[1] * sn; ql[3] = ax[2] * sn;
+  dq_mul(q, q0, ql);
+  const double n = 1.0 / sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  for (int k = 0; k < 4; k++) q[k] *= n;
+  dq_rot(t0, q0, jp);
+  dq_rot(t1, q, jp);
+  for (int k = 0; k < 3; k++) p[k] = (double)M->body_pos[b][k] + t0[k] - t1[k];
+}
+// spatial inertia (10) of body c about point O, axes of the frame its pose (p, q) is given in
+MRE_DEV void inert_about_d(const DevModel* M, int c, const double* p, const double* q, const double* O, double* ci) {
+  double ip[3] = {(double)M->body_ipos[c][0], (double)M->body_ipos[c][1], (double)M->body_ipos[c][2]}, t[3], qi[4];
+  double iq[4] = {(double)M->body_iquat[c][0], (double)M->body_iquat[c][1], (double)M->body_iquat[c][2], (double)M->body_iquat[c][3]};
+  dq_rot(t, q, ip);
+  const double d[3] = {p[0] + t[0] - O[0], p[1] + t[1] - O[1], p[2] + t[2] - O[2]};
+  dq_mul(qi, q, iq);
+  // rotation matrix columns of qi
+  double R[9];
+  {
+    const double w = qi[0], x = qi[1], y = qi[2], z = qi[3];
+    R[0] = w * w + x * x - y * y - z * z; R[1] = 2 * (x * y - w * z); R[2] = 2 * (x * z + w * y);
+    R[3] = 2 * (x * y + w * z); R[4] = w * w - x * x + y * y - z * z; R[5] = 2 * (y * z - w * x);
+    R[6] = 2 * (x * z - w * y); R[7] = 2 * (y * z + w * x); R[8] = w * w - x * x - y * y + z * z;
+  }
+  const double m = (double)M->body_mass[c];
+  const double in[3] = {(double)M->body_inertia[c][0], (double)M->body_inertia[c][1], (double)M->body_inertia[c][2]};
+  double T[9];
+  for (int r = 0; r < 3; r++)
+    for (int k = 0; k < 3; k++)
+      T[3 * r + k] = R[3 * r] * in[0] * R[3 * k] + R[3 * r + 1] * in[1] * R[3 * k + 1] + R[3 * r + 2] * in[2] * R[3 * k + 2];
+  ci[0] += T[0] + m * (d[1] * d[1] + d[2] * d[2]);
+  ci[1] += T[4] + m * (d[0] * d[0] + d[2] * d[2]);
+  ci[2] += T[8] + m * (d[0] * d[0] + d[1] * d[1]);
+  ci[3] += T[1] - m * d[0] * d[1];
+  ci[4] += T[2] - m * d[0] * d[2];
+  ci[5] += T[5] - m * d[1] * d[2];
+  ci[6] += m * d[0]; ci[7] += m * d[1]; ci[8] += m * d[2]; ci[9] += m;
+}
+
+// lane = finger body: its subtree's spatial inertia and its cdof about the pinch site, in the frame
+// of the arm's last link, and the momentum map P = crb * cdof that the finger rows of M are built
+// from (crb_mass_matrix).  Chains below the arm are at most two bodies deep (checked in mre_create).
+MRE_PHASE_FN void gripper_local(const DevModel* M, Sm& s, int l) {
+  if (l >= GRIP_BODY0 && l < NRB) {
+    const int b = l;
+    double p[3], q[4];
+    hinge_local_d(M, s, b, p, q);
+    const int par = M->body_parent[b];
+    if (par >= GRIP_BODY0) {
+      double pp[3], pq[4], t[3], q2[4];
+      hinge_local_d(M, s, par, pp, pq);
+      dq_rot(t, pq, p);
+      for (int k = 0; k < 3; k++) p[k] = pp[k] + t[k];
+      dq_mul(q2, pq, q);
+      for (int k = 0; k < 4; k++) q[k] = q2[k];
+    }
+    const int ts = M->tcp_site;
+    const double O[3] = {(double)M->site_pos[ts][0], (double)M->site_pos[ts][1], (double)M->site_pos[ts][2]};
+    double ci[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    inert_about_d(M, b, p, q, O, ci);
+    for (int c = b + 1; c < NRB; c++) {
+      if (M->body_parent[c] != b) continue;
+      double cp[3], cq[4], t[3], q2[4];
+      hinge_local_d(M, s, c, cp, cq);
+      dq_rot(t, q, cp);
+      for (int k = 0; k < 3; k++) cp[k] = p[k] + t[k];
+      dq_mul(q2, q, cq);
+      inert_about_d(M, c, cp, q2, O, ci);
+    }
+    double ax[3] = {(double)M->jnt_axis[b][0], (double)M->jnt_axis[b][1], (double)M->jnt_axis[b][2]};
+    double jp[3] = {(double)M->jnt_pos[b][0], (double)M->jnt_pos[b][1], (double)M->jnt_pos[b][2]};
+    double u[3], a[3];
+    dq_rot(u, q, ax);
+    dq_rot(a, q, jp);
+    const double r[3] = {O[0] - p[0] - a[0], O[1] - p[1] - a[1], O[2] - p[2] - a[2]};
+    const double cd[6] = {u[0], u[1], u[2], u[1] * r[2] - u[2] * r[1], u[2] * r[0] - u[0] * r[2], u[0] * r[1] - u[1] * r[0]};
+    double P[6];
+    P[0] = ci[0] * cd[0] + ci[3] * cd[1] + ci[4] * cd[2] - ci[8] * cd[4] + ci[7] * cd[5];
+    P[1] = ci[3] * cd[0] + ci[1] * cd[1] + ci[5] * cd[2] + ci[8] * cd[3] - ci[6] * cd[5];
+    P[2] = ci[4] * cd[0] + ci[5] * cd[1] + ci[2] * cd[2] - ci[7] * cd[3] + ci[6] * cd[4];
+    P[3] = ci[8] * cd[1] - ci[7] * cd[2] + ci[9] * cd[3];
+    P[4] = ci[6] * cd[2] - ci[8] * cd[0] + ci[9] * cd[4];
+    P[5] = ci[7] * cd[0] - ci[6] * cd[1] + ci[9] * cd[5];
+    for (int k = 0; k < 6; k++) { s.gC[b - GRIP_BODY0][k] = (float)cd[k]; s.gP[b - GRIP_BODY0][k] = (float)P[k]; }
+  }
+  __syncthreads();
+}
+
 // ------------------------------------------------------- mj_crb (robot block)
 MRE_DEV void crb_mass_matrix(const DevModel* M, Sm& s, int l) {
   if (l >= 1 && l < NRB) {
@@ -299,9 +426,28 @@ MRE_DEV void crb_mass_matrix(const DevModel* M, Sm& s, int l) {
   __syncthreads();
   for (int e = l; e < NMR; e += 64) {
     const int i = M->M_i[e], j = M->M_j[e];
-    float buf[6];
-    mul_inert_vec(buf, s.crb[M->dof_body[i]], s.cdof[i]);
-    float v = dot6(s.cdof[j], buf);
+    float v;
+    if (i >= GRIP_BODY0 - 1) {
+      // rows of the finger dofs: momentum map of the finger subtree from gripper_local (fp64, frame
+      // of the arm's last link, about the pinch site); an arm dof j is moved to the same point / axes
+      const int root = GRIP_BODY0 - 1;   // body id of the arm's last link = dof id of the first finger dof
+      float cj[6];
+      if (j >= GRIP_BODY0 - 1) {
+        for (int k = 0; k < 6; k++) cj[k] = s.gC[j - (GRIP_BODY0 - 1)][k];
+      } else {
+        float off[3], t[3], lin[3];
+        v3sub(off, s.site_xpos[M->tcp_site], s.com_robot);
+        v3cross(t, s.cdof[j], off);
+        v3add(lin, s.cdof[j] + 3, t);
+        m3tmulv(cj, s.xmat[root], s.cdof[j]);
+        m3tmulv(cj + 3, s.xmat[root], lin);
+      }
+      v = dot6(cj, s.gP[i - (GRIP_BODY0 - 1)]);
+    } else {
+      float buf[6];
+      mul_inert_vec(buf, s.crb[M->dof_body[i]], s.cdof[i]);
+      v = dot6(s.cdof[j], buf);
+    }
     if (i == j) v += M->dof_armature[i];
     s.qM[e] = v;
   }
@@ -703,6 +849,7 @@ MRE_DEV void step_body(const StepArgs& a, Sm& s) {
     // ------------------------------------------------ S1: position stage
     MRE_STAMP(7);
     position_stage(M, s, l);
+    gripper_local(M, s, l);
     crb_mass_matrix(M, s, l);
     __syncthreads();
     factor_robot_regs(s.qM, s.qLD, s.qLDinv);
@@ -719,7 +866,7 @@ MRE_DEV void step_body(const StepArgs& a, Sm& s) {
 
       collide(M, s, l);
       MRE_STAMP(2);
-      connect_residuals(M, s, l);
+      connect_rows_local(M, s, l);
       assemble_constraints(M, s, l);
 #ifdef MRE_NEWTON
       nw_build_lists(s, l);
@@ -787,6 +934,7 @@ MRE_DEV void step_body(const StepArgs& a, Sm& s) {
     // OSC.compute_control_output() on the current state (models/robot_arm.py:71): the position and
     // velocity stages the trailing mj_step1 would have left behind, then the torque law
     position_stage(M, s, l);
+    gripper_local(M, s, l);
     crb_mass_matrix(M, s, l);
     __syncthreads();
     velocity_stage(M, s, l);

@@ -243,67 +243,66 @@ MRE_PHASE_FN void solve_robot_rows(Sm& s, int l) {
 // noise injected into the fp64 oracle reproduces it; 1e-9 m does not).  Both anchors hang off the
 // same arm link, so the residual is evaluated in THAT link's frame from the four joint angles alone,
 // in fp64 (sin / cos by Taylor polynomials, |half angle| < 1), and only then rotated to the world.
-MRE_DEV void sincos_poly_d(double x, double& sn, double& cs) {
-  const double z = x * x;
-  sn = x * (1.0 - z / 6.0 * (1.0 - z / 20.0 * (1.0 - z / 42.0 * (1.0 - z / 72.0 * (1.0 - z / 110.0 *
-       (1.0 - z / 156.0 * (1.0 - z / 210.0)))))));
-  cs = 1.0 - z / 2.0 * (1.0 - z / 12.0 * (1.0 - z / 30.0 * (1.0 - z / 56.0 * (1.0 - z / 90.0 *
-       (1.0 - z / 132.0 * (1.0 - z / 182.0 * (1.0 - z / 240.0)))))));
-}
-MRE_DEV void dq_mul(double* r, const double* a, const double* b) {
-  const double w = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
-  const double x = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
-  const double y = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
-  const double z = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
-  r[0] = w; r[1] = x; r[2] = y; r[3] = z;
-}
-MRE_DEV void dq_rot(double* r, const double* q, const double* v) {
-  // v + 2 w (u x v) + 2 u x (u x v)
-  const double ux = q[1], uy = q[2], uz = q[3], w = q[0];
-  const double cx = uy * v[2] - uz * v[1], cy = uz * v[0] - ux * v[2], cz = ux * v[1] - uy * v[0];
-  const double dx = uy * cz - uz * cy, dy = uz * cx - ux * cz, dz = ux * cy - uy * cx;
-  r[0] = v[0] + 2.0 * (w * cx + dx); r[1] = v[1] + 2.0 * (w * cy + dy); r[2] = v[2] + 2.0 * (w * cz + dz);
-}
-// pose of hinge body b in its parent's frame (mj_kinematics, one body): position p, rotation q
-MRE_DEV void hinge_local_d(const DevModel* M, const Sm& s, int b, double* p, double* q) {
-  double q0[4], ql[4], ax[3], jp[3], t0[3], t1[3];
-  for (int k = 0; k < 4; k++) q0[k] = (double)M->body_quat[b][k];
-  for (int k = 0; k < 3; k++) { ax[k] = (double)M->jnt_axis[b][k]; jp[k] = (double)M->jnt_pos[b][k]; }
-  const int qa = M->body_qposadr[b];
-  double sn, cs;
-  sincos_poly_d(0.5 * ((double)s.qpos[qa] - (double)M->qpos0[qa]), sn, cs);
-  ql[0] = cs; ql[1] = ax[0] * sn; ql[2] = ax[1] * sn; ql[3] = ax[2] * sn;
-  dq_mul(q, q0, ql);
-  const double n = 1.0 / sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-  for (int k = 0; k < 4; k++) q[k] *= n;
-  dq_rot(t0, q0, jp);
-  dq_rot(t1, q, jp);
-  for (int k = 0; k < 3; k++) p[k] = (double)M->body_pos[b][k] + t0[k] - t1[k];
-}
-// point a (in the frame of body b) expressed in the frame of the first ancestor of b that is an arm
-// link (id < first gripper body GRIP0); chains are at most two bodies long (mre_create checks)
-constexpr int GRIP0 = 8;
-MRE_DEV int anchor_in_arm_frame_d(const DevModel* M, const Sm& s, int b, const float* a, double* out) {
-  double p[3], q[4], x[3] = {(double)a[0], (double)a[1], (double)a[2]}, t[3];
-  int cur = b;
-  for (int hop = 0; hop < 2 && cur >= GRIP0; hop++) {
-    hinge_local_d(M, s, cur, p, q);
-    dq_rot(t, q, x);
-    for (int k = 0; k < 3; k++) x[k] = p[k] + t[k];
-    cur = M->body_parent[cur];
+constexpr int GRIP0 = GRIP_BODY0;
+// One side of a `connect` constraint in the frame of the arm's last link: the anchor point x of body
+// b (two bodies below the arm at most, checked in mre_create) and, for the finger dofs on the way
+// up, the lever vectors u_c x (x - a_c) (axis u_c, joint anchor a_c), times `sign`.
+MRE_DEV void connect_side_d(const DevModel* M, const Sm& s, int b, const float* a, double sign, double* x,
+                            double (*vec)[3]) {
+  double p[2][3], q[2][4];
+  hinge_local_d(M, s, b, p[0], q[0]);
+  const int par = M->body_parent[b];
+  const bool two = par >= GRIP0;
+  if (two) {
+    // pose of b in the arm link's frame = pose(parent) o local(b)
+    double t[3], q2[4];
+    hinge_local_d(M, s, par, p[1], q[1]);
+    dq_rot(t, q[1], p[0]);
+    for (int k = 0; k < 3; k++) p[0][k] = p[1][k] + t[k];
+    dq_mul(q2, q[1], q[0]);
+    for (int k = 0; k < 4; k++) q[0][k] = q2[k];
   }
-  for (int k = 0; k < 3; k++) out[k] = x[k];
-  return cur;
+  const double al[3] = {(double)a[0], (double)a[1], (double)a[2]};
+  double t[3];
+  dq_rot(t, q[0], al);
+  for (int k = 0; k < 3; k++) x[k] = p[0][k] + t[k];
+  for (int m = 0; m < 2; m++) {
+    vec[m][0] = vec[m][1] = vec[m][2] = 0.0;
+    if (m == 1 && !two) break;
+    const int c = m == 0 ? b : par;
+    const double ax[3] = {(double)M->jnt_axis[c][0], (double)M->jnt_axis[c][1], (double)M->jnt_axis[c][2]};
+    const double jp[3] = {(double)M->jnt_pos[c][0], (double)M->jnt_pos[c][1], (double)M->jnt_pos[c][2]};
+    double u[3], ja[3];
+    dq_rot(u, q[m], ax);
+    dq_rot(ja, q[m], jp);
+    const double r[3] = {x[0] - p[m][0] - ja[0], x[1] - p[m][1] - ja[1], x[2] - p[m][2] - ja[2]};
+    vec[m][0] = sign * (u[1] * r[2] - u[2] * r[1]);
+    vec[m][1] = sign * (u[2] * r[0] - u[0] * r[2]);
+    vec[m][2] = sign * (u[0] * r[1] - u[1] * r[0]);
+  }
 }
 
-// a phase of its own (lanes 0, 1 = the two connect constraints): fp64 register pressure stays
-// out of the row assembly
-MRE_PHASE_FN void connect_residuals(const DevModel* M, Sm& s, int l) {
+// The two `connect` rows of the finger linkage, evaluated in the frame of the arm's last link in
+// fp64 (lanes 0, 1 = the two constraints; a phase of its own so that the fp64 register pressure stays
+// out of the row assembly).  Their residual is a 1e-5 m difference of two anchor positions and their
+// Jacobian entries are 0.03 m levers: taken from the fp32 world poses (|x| ~ 0.8 m) both carry
+// 3..6e-8 m of rounding, which the stiff reference acceleration (K = 4e4 1/s^2) and the 25 N the rows
+// transmit turn into torque noise on links of a few grams (measured: finger joints 1e-4 .. 3e-2 rad
+// away from the fp64 oracle after 1000 steps; the same noise injected into the oracle reproduces it).
+// Results go to the head of qfrc_con (dead between integrate and the next solve), 16 floats per
+// constraint: [0:3] residual, [4 + 3 m : 7 + 3 m] lever vector of finger dof m (body1, its parent,
+// body2, its parent; zero where the chain is shorter), all in the arm link's axes.
+MRE_PHASE_FN void connect_rows_local(const DevModel* M, Sm& s, int l) {
   if (l < 2 && M->eq_type[l] == 0) {
-    double l1[3], l2[3];
-    anchor_in_arm_frame_d(M, s, M->eq_obj[l][0], M->eq_data[l], l1);
-    anchor_in_arm_frame_d(M, s, M->eq_obj[l][1], M->eq_data[l] + 3, l2);
-    for (int k = 0; k < 3; k++) s.qfrc_con[3 * l + k] = (float)(l1[k] - l2[k]);
+    double x1[3], x2[3], v1[2][3], v2[2][3];
+    connect_side_d(M, s, M->eq_obj[l][0], M->eq_data[l], 1.0, x1, v1);
+    connect_side_d(M, s, M->eq_obj[l][1], M->eq_data[l] + 3, -1.0, x2, v2);
+    float* o = &s.qfrc_con[16 * l];
+    for (int k = 0; k < 3; k++) {
+      o[k] = (float)(x1[k] - x2[k]);
+      o[4 + k] = (float)v1[0][k]; o[7 + k] = (float)v1[1][k];
+      o[10 + k] = (float)v2[0][k]; o[13 + k] = (float)v2[1][k];
+    }
   }
   __syncthreads();
 }
@@ -382,18 +381,29 @@ MRE_PHASE_FN void assemble_constraints(const DevModel* M, Sm& s, int l) {
       solref = M->eq_solref[e]; solimp = M->eq_solimp[e];
       if (e < 2) {
         const int b1 = M->eq_obj[e][0], b2 = M->eq_obj[e][1], k = i % 3;
-        float p1[3], p2[3], cp[3];
-        const float ax[3] = {k == 0 ? 1.f : 0.f, k == 1 ? 1.f : 0.f, k == 2 ? 1.f : 0.f};
-        m3mulv(p1, s.xmat[b1], M->eq_data[e]); v3add(p1, p1, s.xpos[b1]);
-        m3mulv(p2, s.xmat[b2], M->eq_data[e] + 3); v3add(p2, p2, s.xpos[b2]);
+        // residual and finger-dof levers from connect_rows_local (arm link's frame, fp64): rotate to
+        // the world.  Arm dofs move both anchors alike: their entry is axis x (p1 - p2), tiny.
+        int root = b1;
+        while (root >= GRIP0) root = M->body_parent[root];
+        const float* loc = &s.qfrc_con[16 * e];
+        const float* R = s.xmat[root];
+        float cp[3];
+        m3mulv(cp, R, loc);
+        const float rk[3] = {R[3 * k], R[3 * k + 1], R[3 * k + 2]};   // e_k' R: world component k of a local vector
+        const int pb1 = M->body_parent[b1], pb2 = M->body_parent[b2];
+        s.Jr[rs][b1 - 1] += v3dot(rk, loc + 4);
+        if (pb1 >= GRIP0) s.Jr[rs][pb1 - 1] += v3dot(rk, loc + 7);
+        s.Jr[rs][b2 - 1] += v3dot(rk, loc + 10);
+        if (pb2 >= GRIP0) s.Jr[rs][pb2 - 1] += v3dot(rk, loc + 13);
         {
-          // residual evaluated in the common arm link's frame in fp64 (connect_residuals)
-          int root = b1;
-          while (root >= GRIP0) root = M->body_parent[root];
-          m3mulv(cp, s.xmat[root], &s.qfrc_con[3 * e]);
+          const int n = M->chain_len[root];
+          for (int c = 0; c < n; c++) {
+            const int j = M->chain_dof[root][c];
+            float t[3];
+            v3cross(t, s.cdof[j], cp);
+            s.Jr[rs][j] += sel3(t, k);
+          }
         }
-        jac_robot(M, s, rs, b1, p1, ax, 1.f);
-        jac_robot(M, s, rs, b2, p2, ax, -1.f);
         pos = sel3(cp, k);
         imp_pos = v3norm(cp);
         diag = M->body_invweight0[b1][0] + M->body_invweight0[b2][0];

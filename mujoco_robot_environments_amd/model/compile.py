@@ -565,6 +565,15 @@ def compile_scene(scene: dict = None) -> Dict[str, np.ndarray]:
              eq_solref=eq_solref, eq_solimp=eq_solimp)
     A["_names"] = dict(bodies=[b.name for b in bodies], geoms=[g["name"] for g in geoms],
                        sites=site_names)  # python-side only, not in blob
+    # The model IS its fp32-representable form: every geometric / inertial / contact constant is
+    # rounded to the nearest float32 here, so that the fp64 oracle and the fp32 kernels consume
+    # bit-identical parameters.  (A link length of 0.0315 m held as 0.0315 by one side and as
+    # float32(0.0315) = 0.031500000506... by the other differs by 5e-10 m: through the stiff `connect`
+    # rows (K ~ 4e4 1/s^2) of the finger linkage that alone was a systematic 2e-3 rad/s^2 on the finger
+    # accelerations.)  Solver / integrator options (opt_*) stay as specified.
+    for k, v in A.items():
+        if not k.startswith("_") and not k.startswith("opt_") and isinstance(v, np.ndarray) and v.dtype.kind == "f":
+            A[k] = v.astype(np.float32).astype(np.float64)
     return A
 
 

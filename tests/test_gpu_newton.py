@@ -71,13 +71,13 @@ def test_newton_long_rollout_1000_steps_all_coordinates(compiled_model, oracle_m
                                                      solver="Newton", census=True)
     under, switched, unexplained, cmax = _divergence_report("newton 1000 steps", gq, oq, nprops, gcen, ocen)
     assert (phys.status() == 0).all()
-    # cube and arm coordinates meet the bar in every env whose constraint set never switched; the
-    # finger linkage (links of a few grams on 1e-5 kg m^2) meets it in >= 80 % of the envs and drifts by
-    # < 5e-3 rad in the rest (fp32 cancellation in the c-frame inertias of the finger links)
+    # arm and cube coordinates meet the bar in every env whose constraint set never switched; the
+    # finger linkage (links of a few grams, inertias of 1e-5 kg m^2, closed by stiff soft constraints)
+    # meets it in >= 80 % of the envs and stays within 1e-3 rad in the rest
     err = np.abs(gq - oq)
     clean = [i for i in range(gq.shape[1]) if not np.any(gcen[:, i] != ocen[:, i])]
     assert err[:, clean, :7].max() < TOL and err[:, clean][:, :, 15:].max() < TOL
-    assert len(under) >= 51 and cmax < 5e-3
+    assert len(under) >= 52 and cmax < 1e-3
 
 
 def test_newton_bench_action_law_1000_steps(compiled_model, oracle_model):
@@ -98,8 +98,8 @@ def test_newton_bench_action_law_1000_steps(compiled_model, oracle_model):
     assert np.isfinite(gq).all()
     clean = [i for i in range(gq.shape[1]) if not np.any(gcen[:, i] != ocen[:, i])]
     assert err[:, clean, :7].max() < TOL and err[:, clean][:, :, 15:].max() < TOL   # arm and cubes: the bar
-    assert (first >= 500).mean() >= 0.95 and (first >= 1000).mean() >= 0.7          # all 43 coordinates
-    assert cmax < 5e-3                                                               # finger drift bounded
+    assert (first >= 500).mean() >= 0.95 and (first >= 1000).mean() >= 0.8          # all 43 coordinates
+    assert cmax < 1e-3                                                               # finger drift bounded
 
 
 def test_newton_run_controller_parity(compiled_model, oracle_model):

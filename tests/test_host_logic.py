@@ -22,9 +22,9 @@ def test_fused_inertias_are_physical(compiled_model):
     I = A["body_inertia"][1:]
     assert (I > 0).all()
     s = np.sort(I, axis=1)
-    assert (s[:, 2] <= (s[:, 0] + s[:, 1]) * (1 + 1e-9)).all(), "triangle inequality (MuJoCo compiler check)"
+    assert (s[:, 2] <= (s[:, 0] + s[:, 1]) * (1 + 1e-6)).all(), "triangle inequality (MuJoCo compiler check)"
     # link7 carries the fused attachment + gripper base (0.735522 + 0.777441 kg)
-    assert abs(A["body_mass"][7] - (0.735522 + 0.777441)) < 1e-9
+    assert abs(A["body_mass"][7] - (0.735522 + 0.777441)) < 1e-7   # (constants are rounded to float32)
 
 
 def test_home_kinematics_known_answer(compiled_model):

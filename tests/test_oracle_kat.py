@@ -70,7 +70,10 @@ def test_crb_mass_matrix_matches_jacobian_formula(compiled_model, oracle_model):
         e.forward()
         M = _dense_M(A, e)
         Md = MC.dense_mass_matrix(A, q[:43].copy())
-        assert np.abs(M - Md).max() < 1e-12
+        # (1e-6: the model constants are float32-rounded, so the constant quaternions are unit only to
+        #  6e-8; the oracle renormalises the composed body quaternion like mj_kinematics, the numpy
+        #  cross-check does not)
+        assert np.abs(M - Md).max() < 1e-6
         assert np.linalg.eigvalsh(M).min() > 0
         # sparse L'DL solve round trip
         y = rs.randn(39)

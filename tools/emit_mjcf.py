@@ -29,8 +29,14 @@ from mujoco_robot_environments_amd.model import spec as S  # noqa: E402
 _MASKS = {"robot": (1, 0), "pad": (1, 0), "prop": (2, 3), "table": (0, 3), "ground": (0, 2)}
 
 
+def _r(t) -> float:
+    """Model constants are defined as their nearest float32 (model/compile.py)."""
+    import numpy as np
+    return float(np.float32(t))
+
+
 def _v(x) -> str:
-    return " ".join(repr(float(t)) for t in x)
+    return " ".join(repr(_r(t)) for t in x)
 
 
 def _geom(g: dict, size=None) -> str:
