@@ -99,6 +99,7 @@ struct Sm {
     struct {  // spatial inertias (S1a/S1b); gP / gC: per gripper dof, the momentum map crb * cdof and the
               // cdof about the pinch site in the frame of the arm's last link (gripper_local)
       float cinert[NB][10], crb[NRB][10], gP[NRB - GRIP_BODY0][6], gC[NRB - GRIP_BODY0][6];
+      double gpose[NRB - GRIP_BODY0][7];   // pose (p, q) of every finger body in the arm link's frame (gripper_pose)
     };
   };
   float JpB[3 * NPP_MAX][6];             // prop part B (cube-cube contacts only)
@@ -362,7 +363,8 @@ MRE_DEV void inert_about_d(const DevModel* M, int c, const double* p, const doub
 // lane = finger body: its subtree's spatial inertia and its cdof about the pinch site, in the frame
 // of the arm's last link, and the momentum map P = crb * cdof that the finger rows of M are built
 // from (crb_mass_matrix).  Chains below the arm are at most two bodies deep (checked in mre_create).
-MRE_PHASE_FN void gripper_local(const DevModel* M, Sm& s, int l) {
+// lane = finger body: its pose in the arm link's frame (composition with its parent's joint included)
+MRE_PHASE_FN void gripper_pose(const DevModel* M, Sm& s, int l) {
   if (l >= GRIP_BODY0 && l < NRB) {
     const int b = l;
     double p[3], q[4];
@@ -376,18 +378,24 @@ MRE_PHASE_FN void gripper_local(const DevModel* M, Sm& s, int l) {
       dq_mul(q2, pq, q);
       for (int k = 0; k < 4; k++) q[k] = q2[k];
     }
+    for (int k = 0; k < 3; k++) s.gpose[b - GRIP_BODY0][k] = p[k];
+    for (int k = 0; k < 4; k++) s.gpose[b - GRIP_BODY0][3 + k] = q[k];
+  }
+  __syncthreads();
+}
+MRE_PHASE_FN void gripper_local(const DevModel* M, Sm& s, int l) {
+  if (l >= GRIP_BODY0 && l < NRB) {
+    const int b = l;
+    const double* pose = s.gpose[b - GRIP_BODY0];
+    const double p[3] = {pose[0], pose[1], pose[2]}, q[4] = {pose[3], pose[4], pose[5], pose[6]};
     const int ts = M->tcp_site;
     const double O[3] = {(double)M->site_pos[ts][0], (double)M->site_pos[ts][1], (double)M->site_pos[ts][2]};
     double ci[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     inert_about_d(M, b, p, q, O, ci);
     for (int c = b + 1; c < NRB; c++) {
       if (M->body_parent[c] != b) continue;
-      double cp[3], cq[4], t[3], q2[4];
-      hinge_local_d(M, s, c, cp, cq);
-      dq_rot(t, q, cp);
-      for (int k = 0; k < 3; k++) cp[k] = p[k] + t[k];
-      dq_mul(q2, q, cq);
-      inert_about_d(M, c, cp, q2, O, ci);
+      const double* cp = s.gpose[c - GRIP_BODY0];
+      inert_about_d(M, c, cp, cp + 3, O, ci);
     }
     double ax[3] = {(double)M->jnt_axis[b][0], (double)M->jnt_axis[b][1], (double)M->jnt_axis[b][2]};
     double jp[3] = {(double)M->jnt_pos[b][0], (double)M->jnt_pos[b][1], (double)M->jnt_pos[b][2]};
@@ -404,6 +412,59 @@ MRE_PHASE_FN void gripper_local(const DevModel* M, Sm& s, int l) {
     P[4] = ci[6] * cd[2] - ci[8] * cd[0] + ci[9] * cd[4];
     P[5] = ci[7] * cd[0] - ci[6] * cd[1] + ci[9] * cd[5];
     for (int k = 0; k < 6; k++) { s.gC[b - GRIP_BODY0][k] = (float)cd[k]; s.gP[b - GRIP_BODY0][k] = (float)P[k]; }
+  }
+  __syncthreads();
+}
+
+// One side of a `connect` constraint in the frame of the arm's last link: the anchor point x of body
+// b and, for the finger dofs on the way up (b, then its parent if that is a finger body), the lever
+// vectors u_c x (x - a_c) (axis u_c, joint anchor a_c), times `sign`.
+MRE_DEV void connect_side_d(const DevModel* M, const Sm& s, int b, const float* a, double sign, double* x,
+                            double (*vec)[3]) {
+  const double* pose = s.gpose[b - GRIP_BODY0];
+  const double al[3] = {(double)a[0], (double)a[1], (double)a[2]};
+  double t[3];
+  dq_rot(t, pose + 3, al);
+  for (int k = 0; k < 3; k++) x[k] = pose[k] + t[k];
+  const int par = M->body_parent[b];
+  for (int m = 0; m < 2; m++) {
+    vec[m][0] = vec[m][1] = vec[m][2] = 0.0;
+    const int c = m == 0 ? b : par;
+    if (c < GRIP_BODY0) break;
+    const double* cp = s.gpose[c - GRIP_BODY0];
+    const double ax[3] = {(double)M->jnt_axis[c][0], (double)M->jnt_axis[c][1], (double)M->jnt_axis[c][2]};
+    const double jp[3] = {(double)M->jnt_pos[c][0], (double)M->jnt_pos[c][1], (double)M->jnt_pos[c][2]};
+    double u[3], ja[3];
+    dq_rot(u, cp + 3, ax);
+    dq_rot(ja, cp + 3, jp);
+    const double r[3] = {x[0] - cp[0] - ja[0], x[1] - cp[1] - ja[1], x[2] - cp[2] - ja[2]};
+    vec[m][0] = sign * (u[1] * r[2] - u[2] * r[1]);
+    vec[m][1] = sign * (u[2] * r[0] - u[0] * r[2]);
+    vec[m][2] = sign * (u[0] * r[1] - u[1] * r[0]);
+  }
+}
+
+// The two `connect` rows of the finger linkage, evaluated in the frame of the arm's last link in
+// fp64 (lanes 0, 1 = the two constraints).  Their residual is a 1e-5 m difference of two anchor
+// positions and their Jacobian entries are 0.03 m levers: taken from the fp32 world poses
+// (|x| ~ 0.8 m) both carry 3..6e-8 m of rounding, which the stiff reference acceleration
+// (K = 4e4 1/s^2) and the 25 N the rows transmit turn into torque noise on links of a few grams
+// (measured: finger accelerations 3e-3 rad/s^2 off the fp64 oracle per step, finger joints
+// 1e-4 .. 3e-2 rad off after 1000 steps; the same noise injected into the oracle reproduces it).
+// Results go to the head of qfrc_con (dead between integrate and the next solve), 16 floats per
+// constraint: [0:3] residual, [4 + 3 m : 7 + 3 m] lever vector of finger dof m (body1, its parent,
+// body2, its parent; zero where the chain is shorter), all in the arm link's axes.
+MRE_PHASE_FN void connect_rows_local(const DevModel* M, Sm& s, int l) {
+  if (l < 2 && M->eq_type[l] == 0) {
+    double x1[3], x2[3], v1[2][3], v2[2][3];
+    connect_side_d(M, s, M->eq_obj[l][0], M->eq_data[l], 1.0, x1, v1);
+    connect_side_d(M, s, M->eq_obj[l][1], M->eq_data[l] + 3, -1.0, x2, v2);
+    float* o = &s.qfrc_con[16 * l];
+    for (int k = 0; k < 3; k++) {
+      o[k] = (float)(x1[k] - x2[k]);
+      o[4 + k] = (float)v1[0][k]; o[7 + k] = (float)v1[1][k];
+      o[10 + k] = (float)v2[0][k]; o[13 + k] = (float)v2[1][k];
+    }
   }
   __syncthreads();
 }
@@ -849,7 +910,9 @@ MRE_DEV void step_body(const StepArgs& a, Sm& s) {
     // ------------------------------------------------ S1: position stage
     MRE_STAMP(7);
     position_stage(M, s, l);
+    gripper_pose(M, s, l);
     gripper_local(M, s, l);
+    if ((a.flags & F_NO_CONSTRAINTS) == 0) connect_rows_local(M, s, l);
     crb_mass_matrix(M, s, l);
     __syncthreads();
     factor_robot_regs(s.qM, s.qLD, s.qLDinv);
@@ -866,7 +929,6 @@ MRE_DEV void step_body(const StepArgs& a, Sm& s) {
 
       collide(M, s, l);
       MRE_STAMP(2);
-      connect_rows_local(M, s, l);
       assemble_constraints(M, s, l);
 #ifdef MRE_NEWTON
       nw_build_lists(s, l);
@@ -934,6 +996,7 @@ MRE_DEV void step_body(const StepArgs& a, Sm& s) {
     // OSC.compute_control_output() on the current state (models/robot_arm.py:71): the position and
     // velocity stages the trailing mj_step1 would have left behind, then the torque law
     position_stage(M, s, l);
+    gripper_pose(M, s, l);
     gripper_local(M, s, l);
     crb_mass_matrix(M, s, l);
     __syncthreads();

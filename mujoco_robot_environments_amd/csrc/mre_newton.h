@@ -339,33 +339,64 @@ MRE_PHASE_FN void nw_direction(const DevModel* M, Sm& s, int l) {
     else if (l == k) v = c.lact ? c.mdiag : 1.0f;
     hh[k] = v;
   }
-  for (int i = 0; i < nefc;) {
-    const int st = uni(s.rstate[i]);
-    const bool contact = i >= nscalar;
-    if (st == NW_SAT) { i += contact ? 3 : 1; continue; }
+  // Row metadata goes to registers first (lane r of chunk k = row 64 k + r): the pass over the rows
+  // then takes header and 1 / R by v_readlane instead of two dependent LDS round trips per row, and
+  // visits only the rows in the quadratic state (ballot masks).  The Jacobian entry of the NEXT row
+  // is loaded while the rank-1 update of the current one runs.
+  constexpr int NCH = (NEFC_MAX + 63) / 64;
+  int meta[NCH];
+  float dv[NCH];
+  unsigned long long mq[NCH];
+#pragma unroll
+  for (int k = 0; k < NCH; k++) {
+    const int i = 64 * k + l;
+    const bool on = i < nefc;
+    const int st = on ? (int)s.rstate[i] : NW_SAT;
+    meta[k] = on ? (int)s.hdr[i] : 0;
+    dv[k] = on ? 1.0f / s.efc_R[i] : 0.f;
+    mq[k] = __ballot(st == NW_QUAD);
+  }
+  const unsigned long long mcone = __ballot(l < s.ncon && s.rstate[nscalar + 3 * (l < s.ncon ? l : 0)] == NW_CONE);
+#pragma unroll
+  for (int k = 0; k < NCH; k++) {
+    unsigned long long m = mq[k];
+    if (m == 0ull) continue;
+    int r = __builtin_ctzll(m);
+    m &= m - 1ull;
+    int h = __builtin_amdgcn_readlane(meta[k], r);
+    float J = nw_Jl(s, 64 * k + r, h, l, lp, lk);
+    while (true) {
+      const float D = rdlane(dv[k], r);
+      const int hc = h;
+      const float Jc = J;
+      const bool more = m != 0ull;
+      if (more) {
+        r = __builtin_ctzll(m);
+        m &= m - 1ull;
+        h = __builtin_amdgcn_readlane(meta[k], r);
+        J = nw_Jl(s, 64 * k + r, h, l, lp, lk);
+      }
+      nw_rank1(hh, Jc * D, Jc, (hc & 0xFF) != HDR_NONE, (hc >> 8) & 0xF, (hc >> 12) & 0xF);
+      if (!more) break;
+    }
+  }
+  // contacts in the middle zone: J_c' H_c J_c with the 3 x 3 cone Hessian
+  for (unsigned long long m = mcone; m != 0ull; m &= m - 1ull) {
+    const int cc = __builtin_ctzll(m);
+    const int i = nscalar + 3 * cc;
     const int h = uni(s.hdr[i]);
     const int rs = h & 0xFF, pa = (h >> 8) & 0xF, pb = (h >> 12) & 0xF;
     const bool has_r = rs != HDR_NONE;
-    if (st == NW_QUAD) {
-      const float J = nw_Jl(s, i, h, l, lp, lk);
-      const float t = J * (1.0f / s.efc_R[i]);
-      nw_rank1(hh, t, J, has_r, pa, pb);
-      i += 1;
-    } else {
-      // contact in the middle zone: J_c' H_c J_c with the 3 x 3 cone Hessian
-      const int cc = (i - nscalar) / 3;
-      const int h1 = has_r ? h + 1 : h, h2 = has_r ? h + 2 : h;  // robot slots of rows 1, 2
-      const float J0 = nw_Jl(s, i, h, l, lp, lk), J1 = nw_Jl(s, i + 1, h1, l, lp, lk),
-                  J2 = nw_Jl(s, i + 2, h2, l, lp, lk);
-      const float H00 = s.hc[cc][0], H01 = s.hc[cc][1], H02 = s.hc[cc][2], H11 = s.hc[cc][3],
-                  H12 = s.hc[cc][4], H22 = s.hc[cc][5];
-      const float t0 = H00 * J0 + H01 * J1 + H02 * J2, t1 = H01 * J0 + H11 * J1 + H12 * J2,
-                  t2 = H02 * J0 + H12 * J1 + H22 * J2;
-      nw_rank1(hh, t0, J0, has_r, pa, pb);
-      nw_rank1(hh, t1, J1, has_r, pa, pb);
-      nw_rank1(hh, t2, J2, has_r, pa, pb);
-      i += 3;
-    }
+    const int h1 = has_r ? h + 1 : h, h2 = has_r ? h + 2 : h;  // robot slots of rows 1, 2
+    const float J0 = nw_Jl(s, i, h, l, lp, lk), J1 = nw_Jl(s, i + 1, h1, l, lp, lk),
+                J2 = nw_Jl(s, i + 2, h2, l, lp, lk);
+    const float H00 = s.hc[cc][0], H01 = s.hc[cc][1], H02 = s.hc[cc][2], H11 = s.hc[cc][3],
+                H12 = s.hc[cc][4], H22 = s.hc[cc][5];
+    const float t0 = H00 * J0 + H01 * J1 + H02 * J2, t1 = H01 * J0 + H11 * J1 + H12 * J2,
+                t2 = H02 * J0 + H12 * J1 + H22 * J2;
+    nw_rank1(hh, t0, J0, has_r, pa, pb);
+    nw_rank1(hh, t1, J1, has_r, pa, pb);
+    nw_rank1(hh, t2, J2, has_r, pa, pb);
   }
   // symbolic elimination over the blocks (node 0 robot, node 1 + p cube p), cubes last to first
   unsigned adj[5];
@@ -641,6 +672,10 @@ MRE_DEV void newton_solve(const DevModel* M, Sm& s, int l) {
       break;
     }
     iter++;
+    // A full Newton step (alpha = 1) with an exact Hessian that lands in the same active set has
+    // minimised the very quadratic piece the new point lies in: converged, no check needed.  (Cone
+    // contacts make H depend on the iterate; with them the decrement decides.)
+    if (!reuse && mk.cc == 0ull && fabsf(alpha - 1.0f) < 1e-4f && nw_masks(s, l, nscalar, ncon) == mk) break;
   }
   if (l < NVP && !(l < NV)) s.qacc[l] = 0.f;
   if (l == 0) s.solver_iters = iter | (nfull << 8);

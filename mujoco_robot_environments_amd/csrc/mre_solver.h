@@ -244,68 +244,7 @@ MRE_PHASE_FN void solve_robot_rows(Sm& s, int l) {
 // same arm link, so the residual is evaluated in THAT link's frame from the four joint angles alone,
 // in fp64 (sin / cos by Taylor polynomials, |half angle| < 1), and only then rotated to the world.
 constexpr int GRIP0 = GRIP_BODY0;
-// One side of a `connect` constraint in the frame of the arm's last link: the anchor point x of body
-// b (two bodies below the arm at most, checked in mre_create) and, for the finger dofs on the way
-// up, the lever vectors u_c x (x - a_c) (axis u_c, joint anchor a_c), times `sign`.
-MRE_DEV void connect_side_d(const DevModel* M, const Sm& s, int b, const float* a, double sign, double* x,
-                            double (*vec)[3]) {
-  double p[2][3], q[2][4];
-  hinge_local_d(M, s, b, p[0], q[0]);
-  const int par = M->body_parent[b];
-  const bool two = par >= GRIP0;
-  if (two) {
-    // pose of b in the arm link's frame = pose(parent) o local(b)
-    double t[3], q2[4];
-    hinge_local_d(M, s, par, p[1], q[1]);
-    dq_rot(t, q[1], p[0]);
-    for (int k = 0; k < 3; k++) p[0][k] = p[1][k] + t[k];
-    dq_mul(q2, q[1], q[0]);
-    for (int k = 0; k < 4; k++) q[0][k] = q2[k];
-  }
-  const double al[3] = {(double)a[0], (double)a[1], (double)a[2]};
-  double t[3];
-  dq_rot(t, q[0], al);
-  for (int k = 0; k < 3; k++) x[k] = p[0][k] + t[k];
-  for (int m = 0; m < 2; m++) {
-    vec[m][0] = vec[m][1] = vec[m][2] = 0.0;
-    if (m == 1 && !two) break;
-    const int c = m == 0 ? b : par;
-    const double ax[3] = {(double)M->jnt_axis[c][0], (double)M->jnt_axis[c][1], (double)M->jnt_axis[c][2]};
-    const double jp[3] = {(double)M->jnt_pos[c][0], (double)M->jnt_pos[c][1], (double)M->jnt_pos[c][2]};
-    double u[3], ja[3];
-    dq_rot(u, q[m], ax);
-    dq_rot(ja, q[m], jp);
-    const double r[3] = {x[0] - p[m][0] - ja[0], x[1] - p[m][1] - ja[1], x[2] - p[m][2] - ja[2]};
-    vec[m][0] = sign * (u[1] * r[2] - u[2] * r[1]);
-    vec[m][1] = sign * (u[2] * r[0] - u[0] * r[2]);
-    vec[m][2] = sign * (u[0] * r[1] - u[1] * r[0]);
-  }
-}
-
-// The two `connect` rows of the finger linkage, evaluated in the frame of the arm's last link in
-// fp64 (lanes 0, 1 = the two constraints; a phase of its own so that the fp64 register pressure stays
-// out of the row assembly).  Their residual is a 1e-5 m difference of two anchor positions and their
-// Jacobian entries are 0.03 m levers: taken from the fp32 world poses (|x| ~ 0.8 m) both carry
-// 3..6e-8 m of rounding, which the stiff reference acceleration (K = 4e4 1/s^2) and the 25 N the rows
-// transmit turn into torque noise on links of a few grams (measured: finger joints 1e-4 .. 3e-2 rad
-// away from the fp64 oracle after 1000 steps; the same noise injected into the oracle reproduces it).
-// Results go to the head of qfrc_con (dead between integrate and the next solve), 16 floats per
-// constraint: [0:3] residual, [4 + 3 m : 7 + 3 m] lever vector of finger dof m (body1, its parent,
-// body2, its parent; zero where the chain is shorter), all in the arm link's axes.
-MRE_PHASE_FN void connect_rows_local(const DevModel* M, Sm& s, int l) {
-  if (l < 2 && M->eq_type[l] == 0) {
-    double x1[3], x2[3], v1[2][3], v2[2][3];
-    connect_side_d(M, s, M->eq_obj[l][0], M->eq_data[l], 1.0, x1, v1);
-    connect_side_d(M, s, M->eq_obj[l][1], M->eq_data[l] + 3, -1.0, x2, v2);
-    float* o = &s.qfrc_con[16 * l];
-    for (int k = 0; k < 3; k++) {
-      o[k] = (float)(x1[k] - x2[k]);
-      o[4 + k] = (float)v1[0][k]; o[7 + k] = (float)v1[1][k];
-      o[10 + k] = (float)v2[0][k]; o[13 + k] = (float)v2[1][k];
-    }
-  }
-  __syncthreads();
-}
+// (the fp64 evaluation of the two `connect` rows lives next to gripper_local in mre_kernels.hip)
 
 // ------------------------- mj_makeConstraint + mj_makeImpedance + reference + project
 MRE_PHASE_FN void assemble_constraints(const DevModel* M, Sm& s, int l) {
