@@ -51,6 +51,7 @@ typedef enum {
 #define MRE_ST_NOT_CONVERGED 1u   /* arm outside OSC thresholds after run_controller */
 #define MRE_ST_NAN 2u             /* non-finite state detected */
 #define MRE_ST_CONTACT_OVERFLOW 4u /* contact / constraint-row capacity exceeded */
+#define MRE_ST_NOT_SETTLED 8u     /* PropPlacer: cubes still moving after max_settle_physics_time (2 s) */
 
 typedef struct mre_env mre_env;
 
@@ -73,10 +74,23 @@ int mre_set_props(mre_env*, const int32_t* nprops, const float* prop_half_size);
  * mask [N] (host or device, may be NULL = all). Props are parked; use
  * mre_place_props() for PropPlacer. */
 int mre_reset(mre_env*, const uint8_t* mask);
-/* PropPlacer.__call__ (environment/prop_initializer.py:164-283): rejection
- * sampling of cube poses in the workspace + settle with the robot frozen. */
+/* PropPlacer.__call__ (environment/prop_initializer.py:164-283).  Props are placed one index at a
+ * time over the batch: pose ~ U(workspace), yaw = pi U(0,1), rejected while the prop has ANY detected
+ * contact (physics.data.contact: dist < margin) with a geom other than the table -- placed props
+ * and robot geoms alike (:121-140), at most max_attempts draws per prop (error beyond, like the
+ * reference's RuntimeError).  Then the physics settles with the robot frozen; every env stops by
+ * itself once max|qvel| < 1e-3 and max|qacc| < 1e-2 after at least settle_steps steps (:240-258:
+ * 0.3 s), at most 2 s (then MRE_ST_NOT_SETTLED).  mre_get_settle_steps: steps each env took
+ * (negative: not settled). */
 int mre_place_props(mre_env*, const uint8_t* mask, uint64_t seed, const float* ws_min,
                     const float* ws_max, int max_attempts, int settle_steps);
+int mre_get_settle_steps(mre_env*, int32_t* steps);
+/* physics.forward() + physics.data.contact (prop_initializer.py:123-139, tasks/rearrangement.py:
+ * 612-627): every contact the narrow phase DETECTS on the current poses (dist < margin; the solver
+ * only uses those with dist < margin - gap).  count[N] (negative: list cut at -count),
+ * contacts[N][MRE_MAX_CONTACTS][3] = (geom1, geom2, dist), host or device pointers. */
+#define MRE_MAX_CONTACTS 32
+int mre_get_contacts(mre_env*, int32_t* count, float* contacts);
 /* global id of env 0 of this handle (rank r of a sharded batch: r * num_envs); random
  * draws are keyed by global id so results do not depend on the sharding */
 int mre_set_env_id_offset(mre_env*, long long offset);

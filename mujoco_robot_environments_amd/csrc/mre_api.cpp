@@ -96,10 +96,14 @@ struct mre_env {
   float *sv_qpos = nullptr, *sv_qvel = nullptr, *sv_qacc_ws = nullptr, *sv_ctrl = nullptr;
   uint32_t* sv_status = nullptr;
   uint8_t* sv_converged = nullptr;
+  float* contacts = nullptr;     // device [N][1 + 3 * CONTACT_EXPORT] (detect launches), allocated on first use
+  int* settle_steps = nullptr;   // device [N]
   int* launch_info = nullptr;    // device [N][4]
   int* h_launch_info = nullptr;  // pinned host mirror
   std::vector<uint8_t> h_large, h_rerun;
   int n_large = 0;
+  int prop_geom0 = 12;           // geom id of cube 0 (cubes are the last NPROP geoms)
+  int last_settle_max = 0;
   long long n_reruns = 0, n_promotions = 0, n_demotions = 0;
 };
 
@@ -503,6 +507,12 @@ extern "C" int mre_create(const void* blob, size_t nbytes, int num_envs, int dev
   int rc = build_model(blob, nbytes, e->hM);
   if (rc != MRE_OK) { delete e; return rc; }
   if (const char* it = getenv("MRE_DEBUG_ITERS")) e->hM.iterations = atoi(it);  // profiling knob only
+  e->prop_geom0 = -1;
+  for (int g = 0; g < NG; g++) if (e->hM.geom_propid[g] == 0) e->prop_geom0 = g;
+  if (e->prop_geom0 < 0 || e->hM.geom_type[1] != 1 || e->hM.geom_body[1] != 0) {
+    delete e;
+    return fail(MRE_ERR_MODEL, "mre_create: expected geom 1 = the table (static box) and one geom per cube slot");
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
     delete e;
@@ -532,7 +542,7 @@ extern "C" int mre_destroy(mre_env* e) {
                   e->grip_closed, e->converged, e->mask, e->sites, e->status, e->stats, e->d_osc, e->d_osc_env, e->order,
                   e->geoms, e->prop_rgb, e->bg_depth, e->bg_rgb, e->bg_seg,
                   e->d_large, e->mask_c, e->mask_l, e->mask_r, e->sv_qpos, e->sv_qvel, e->sv_qacc_ws, e->sv_ctrl,
-                  e->sv_status, e->launch_info, e->auto_order, e->sv_converged};
+                  e->sv_status, e->launch_info, e->auto_order, e->sv_converged, e->contacts, e->settle_steps};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (e->h_launch_info) (void)hipHostFree(e->h_launch_info);
   if (e->h_auto_order) (void)hipHostFree(e->h_auto_order);
@@ -1054,58 +1064,108 @@ inline double uniform01(uint64_t seed, uint64_t env, uint64_t tick, uint64_t ch)
 }
 }  // namespace
 
+// physics.forward() + physics.data.contact on the current poses: one zero-step launch that runs the
+// kinematics and the narrow phase and exports every DETECTED contact (dist < margin), per env
+// [count, (geom1, geom2, dist) x CONTACT_EXPORT]; count < 0: the list was cut at -count.
+static int detect_contacts(mre_env* e, const uint8_t* dmask) {
+  const size_t N = (size_t)e->N, row = 1 + 3 * CONTACT_EXPORT;
+  if (!e->contacts) HIPCHK(hipMalloc(&e->contacts, N * row * 4));
+  StepArgs a;
+  fill_args(e, a);
+  a.nsteps = 0; a.flags = F_DETECT; a.trace = nullptr; a.env_mask = dmask; a.contacts = e->contacts;
+  a.sites = nullptr; a.geoms = nullptr;
+  launch_compact(e, a, e->stream);
+  HIPCHK(hipGetLastError());
+  return MRE_OK;
+}
+
+extern "C" int mre_get_contacts(mre_env* e, int32_t* count, float* contacts) {
+  if (!e || !count || !contacts) return fail(MRE_ERR_ARG, "mre_get_contacts: null");
+  HIPCHK(hipSetDevice(e->device));
+  int rc = detect_contacts(e, nullptr);
+  if (rc) return rc;
+  const size_t N = (size_t)e->N, row = 1 + 3 * CONTACT_EXPORT;
+  std::vector<float> h(N * row);
+  rc = copy_out(e, h.data(), e->contacts, h.size() * 4);
+  if (rc) return rc;
+  std::vector<int32_t> hc(N);
+  std::vector<float> ho(N * 3 * CONTACT_EXPORT);
+  for (size_t i = 0; i < N; i++) {
+    hc[i] = (int32_t)h[i * row];
+    memcpy(&ho[i * 3 * CONTACT_EXPORT], &h[i * row + 1], 3 * CONTACT_EXPORT * 4);
+  }
+  if ((rc = copy_out(e, count, hc.data(), N * 4))) return rc;
+  return copy_out(e, contacts, ho.data(), ho.size() * 4);
+}
+
+// ---- PropPlacer.__call__ (environment/prop_initializer.py:164-283), batched.
+// Props are placed one index at a time over the whole batch, as the reference places them one
+// after the other: every env that still needs prop p draws a pose (position ~ U(workspace), yaw =
+// pi U(0,1); counter RNG keyed by (seed, GLOBAL env id, p * max_attempts + attempt, channel)), a
+// detect launch evaluates physics.forward() for the batch, and the pose is rejected while prop p
+// has any detected contact (dist < margin 0.15) with a geom other than the table -- placed props and
+// robot geoms alike (_has_collisions_with_prop, :121-140; props not yet placed are parked out of
+// reach, the reference disables their contacts).  Then the physics settles with the robot frozen;
+// every env leaves the loop by itself once max |qvel| < 1e-3 and max |qacc| < 1e-2 after at least
+// `settle_steps` steps (:240-258), at most 2 s; envs that never settle get MRE_ST_NOT_SETTLED.
 extern "C" int mre_place_props(mre_env* e, const uint8_t* mask, uint64_t seed, const float* ws_min,
                                const float* ws_max, int max_attempts, int settle_steps) {
   if (!e || !ws_min || !ws_max || max_attempts < 1) return fail(MRE_ERR_ARG, "mre_place_props: bad argument");
-  const size_t N = (size_t)e->N;
+  const size_t N = (size_t)e->N, row = 1 + 3 * CONTACT_EXPORT;
   std::vector<uint8_t> hm(N, 1);
   int rc;
   if (mask) { rc = copy_out(e, hm.data(), mask, N); if (rc) return rc; }
   std::vector<int> np(N);
-  std::vector<float> ps(N * NPROP * 3), qp(N * NQP);
-  if ((rc = copy_out(e, np.data(), e->nprops, N * 4)) || (rc = copy_out(e, ps.data(), e->prop_size, ps.size() * 4)) ||
-      (rc = copy_out(e, qp.data(), e->qpos, qp.size() * 4)))
+  std::vector<float> qp(N * NQP), hc(N * row);
+  if ((rc = copy_out(e, np.data(), e->nprops, N * 4)) || (rc = copy_out(e, qp.data(), e->qpos, qp.size() * 4)))
     return rc;
-  const double kPi = 3.14159265358979323846, margin = 0.15;
+  const double kPi = 3.14159265358979323846;
   double lo[3], hi[3];
   for (int k = 0; k < 3; k++) { lo[k] = ws_min[k]; hi[k] = ws_max[k]; }
-  for (size_t i = 0; i < N; i++) {
-    if (!hm[i]) continue;
-    const uint64_t gid = (uint64_t)(e->env_ids.empty() ? e->env_id_offset + (long long)i : e->env_ids[i]);
-    double rb[NPROP], pose[NPROP][7];
-    for (int p = 0; p < NPROP; p++) {
-      const float* z = &ps[(i * NPROP + p) * 3];
-      rb[p] = std::sqrt((double)z[0] * z[0] + (double)z[1] * z[1] + (double)z[2] * z[2]);
-    }
-    bool ok = false;
-    for (int rnd = 0; rnd < 50 && !ok; rnd++) {
-      const uint64_t sr = seed + 7919ull * (uint64_t)rnd;
-      ok = true;
-      for (int p = 0; p < np[i] && ok; p++) {
-        bool placed = false;
-        for (int att = 0; att < max_attempts && !placed; att++) {
-          const uint64_t tick = (uint64_t)p * (uint64_t)max_attempts + (uint64_t)att;
-          double u[4];
-          for (int c = 0; c < 4; c++) u[c] = uniform01(sr, gid, tick, (uint64_t)c);
-          double pos[3];
-          for (int k = 0; k < 3; k++) pos[k] = lo[k] + (hi[k] - lo[k]) * u[k];
-          bool good = true;
-          for (int o = 0; o < p && good; o++) {
-            const double dx = pos[0] - pose[o][0], dy = pos[1] - pose[o][1], dz = pos[2] - pose[o][2];
-            if (std::sqrt(dx * dx + dy * dy + dz * dz) <= rb[p] + rb[o] + margin) good = false;
-          }
-          if (!good) continue;
-          const double yaw = kPi * u[3];
-          pose[p][0] = pos[0]; pose[p][1] = pos[1]; pose[p][2] = pos[2];
-          pose[p][3] = std::cos(yaw / 2); pose[p][4] = 0; pose[p][5] = 0; pose[p][6] = std::sin(yaw / 2);
-          placed = true;
+  // props that are about to be placed start from their parking pose
+  for (size_t i = 0; i < N; i++)
+    if (hm[i])
+      for (int p = 0; p < NPROP; p++) {
+        float* q = &qp[i * NQP + NRV + 7 * p];
+        for (int k = 0; k < 3; k++) q[k] = e->hM.park_pos[p][k];
+        q[3] = 1.f; q[4] = q[5] = q[6] = 0.f;
+      }
+  std::vector<uint8_t> pending(N);
+  const int table_geom = 1;  // geom ids of the compiled scene: 0 ground plane, 1 table (checked in mre_create)
+  for (int p = 0; p < NPROP; p++) {
+    size_t npend = 0;
+    for (size_t i = 0; i < N; i++) { pending[i] = hm[i] && p < np[i]; npend += pending[i]; }
+    for (int att = 0; att < max_attempts && npend > 0; att++) {
+      for (size_t i = 0; i < N; i++) {
+        if (!pending[i]) continue;
+        const uint64_t gid = (uint64_t)(e->env_ids.empty() ? e->env_id_offset + (long long)i : e->env_ids[i]);
+        const uint64_t tick = (uint64_t)p * (uint64_t)max_attempts + (uint64_t)att;
+        double u[4];
+        for (int c = 0; c < 4; c++) u[c] = uniform01(seed, gid, tick, (uint64_t)c);
+        const double yaw = kPi * u[3];
+        float* q = &qp[i * NQP + NRV + 7 * p];
+        for (int k = 0; k < 3; k++) q[k] = (float)(lo[k] + (hi[k] - lo[k]) * u[k]);
+        q[3] = (float)std::cos(yaw / 2); q[4] = 0.f; q[5] = 0.f; q[6] = (float)std::sin(yaw / 2);
+      }
+      if ((rc = copy_in(e, e->qpos, qp.data(), qp.size() * 4)) || (rc = copy_in(e, e->mask, pending.data(), N))) return rc;
+      if ((rc = detect_contacts(e, e->mask))) return rc;
+      if ((rc = copy_out(e, hc.data(), e->contacts, hc.size() * 4))) return rc;
+      const int geom_p = e->prop_geom0 + p;
+      for (size_t i = 0; i < N; i++) {
+        if (!pending[i]) continue;
+        const float* c = &hc[i * row];
+        bool hit = c[0] < 0.f;  // cut list: cannot rule a contact out
+        const int n = (int)std::fabs(c[0]) < CONTACT_EXPORT ? (int)std::fabs(c[0]) : CONTACT_EXPORT;
+        for (int k = 0; k < n && !hit; k++) {
+          const int g1 = (int)c[1 + 3 * k], g2 = (int)c[2 + 3 * k];
+          if (g1 == table_geom || g2 == table_geom) continue;
+          if (g1 == geom_p || g2 == geom_p) hit = true;
         }
-        if (!placed) ok = false;
+        if (!hit) { pending[i] = 0; npend--; }
       }
     }
-    if (!ok) return fail(MRE_ERR_ARG, "mre_place_props: failed to find a non-colliding pose (workspace too small)");
-    for (int p = 0; p < np[i]; p++)
-      for (int k = 0; k < 7; k++) qp[i * NQP + NRV + 7 * p + k] = (float)pose[p][k];
+    if (npend > 0)
+      return fail(MRE_ERR_ARG, "mre_place_props: failed to find a non-colliding pose within max_attempts (_REJECTION_SAMPLING_FAILED)");
   }
   rc = copy_in(e, e->qpos, qp.data(), qp.size() * 4);
   if (rc) return rc;
@@ -1113,18 +1173,43 @@ extern "C" int mre_place_props(mre_env* e, const uint8_t* mask, uint64_t seed, c
   if (settle_steps > 0) {
     const uint8_t* dmask = nullptr;
     if (mask) { rc = copy_in(e, e->mask, hm.data(), N); if (rc) return rc; dmask = e->mask; }
+    if (!e->settle_steps) HIPCHK(hipMalloc(&e->settle_steps, N * 4));
+    HIPCHK(hipMemsetAsync(e->settle_steps, 0, N * 4, e->stream));
     StepArgs a;
     fill_args(e, a);
     a.trace = nullptr;
-    a.nsteps = settle_steps; a.flags = F_FREEZE_ROBOT; a.env_mask = dmask;
+    // _max_settle_physics_time = 2 s; min time = settle_steps * dt (0.3 s in the reference)
+    a.nsteps = (int)std::lround(2.0 / e->hM.timestep);
+    if (a.nsteps < settle_steps) a.nsteps = settle_steps;
+    a.flags = F_FREEZE_ROBOT | F_SETTLE_EXIT; a.env_mask = dmask;
+    a.settle_steps = e->settle_steps; a.min_settle_steps = settle_steps;
     const bool prof = e->profiling;
     e->profiling = false;  // setup, not a control tick
     rc = launch_step(e, a, /*settle=*/true);
     e->profiling = prof;
     if (rc) return rc;
+    std::vector<int> hs(N);
+    if ((rc = copy_out(e, hs.data(), e->settle_steps, N * 4))) return rc;
+    std::vector<uint32_t> st(N);
+    if ((rc = copy_out(e, st.data(), e->status, N * 4))) return rc;
+    bool any = false;
+    e->last_settle_max = 0;
+    for (size_t i = 0; i < N; i++) {
+      if (!hm[i]) continue;
+      if (hs[i] < 0) { st[i] |= MRE_ST_NOT_SETTLED; any = true; }
+      const int n = hs[i] < 0 ? -hs[i] : hs[i];
+      if (n > e->last_settle_max) e->last_settle_max = n;
+    }
+    if (any && (rc = copy_in(e, e->status, st.data(), N * 4))) return rc;
     HIPCHK(hipStreamSynchronize(e->stream));
   }
   return MRE_OK;
+}
+
+extern "C" int mre_get_settle_steps(mre_env* e, int32_t* steps) {
+  if (!e || !steps) return fail(MRE_ERR_ARG, "mre_get_settle_steps: null");
+  if (!e->settle_steps) return fail(MRE_ERR_ARG, "mre_get_settle_steps: no settle has run");
+  return copy_out(e, steps, e->settle_steps, (size_t)e->N * 4);
 }
 
 extern "C" int mre_set_env_ids(mre_env* e, const long long* ids) {

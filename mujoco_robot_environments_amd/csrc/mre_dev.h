@@ -23,6 +23,7 @@ constexpr int NPAIR = 64;  // static collision pair table: one lane per pair
 constexpr int NMR = 96;    // entries of the robot block of the sparse mass matrix
 constexpr int NSITE = 2;
 constexpr int NEQ = 3;
+constexpr int CONTACT_EXPORT = 32;  // contacts per env exported by a detect launch (mre_get_contacts)
 constexpr int MAXCHAIN = 9;   // longest dof chain root->leaf (7 arm + 2 finger)
 constexpr int MAXFAC = 45;    // (i,j) ancestor pairs touched by one elimination step
 // dof tree of the robot block (arm chain 0..6, four two-dof finger branches off dof 6); the
@@ -129,7 +130,11 @@ struct OscConfig {
 // F_OSC_EVAL (zero-step launch): evaluate the controller on the current state and store the command
 // (OSC.compute_control_output + MinMax.compute_control_output) in ctrl without stepping
 enum StepFlags : unsigned { F_NO_CONSTRAINTS = 1u, F_FREEZE_ROBOT = 2u, F_CONV_CONTINUE = 4u, F_CONV_OPEN = 8u,
-                            F_OSC_EVAL = 16u };
+                            F_OSC_EVAL = 16u, F_DETECT = 32u, F_SETTLE_EXIT = 64u };
+// F_DETECT (zero-step launch): narrow phase on the current poses, every detected contact (dist < margin)
+//   exported to `contacts` -- physics.forward() + physics.data.contact of the reference's PropPlacer
+// F_SETTLE_EXIT: an env leaves the step loop once its cubes have settled (max |qvel| < 1e-3, max |qacc| <
+//   1e-2, time > min_settle_steps * dt: environment/prop_initializer.py:240-258); steps taken -> settle_steps
 enum CtrlMode : int { CTRL_HELD = 0, CTRL_SEQ = 1, CTRL_OSC = 2 };
 
 struct StepArgs {
@@ -160,6 +165,9 @@ struct StepArgs {
   const int* env_order;      // [N] or null: workgroup b steps env env_order[b] (heavy-first dispatch)
   float* geoms;              // [N][NG][16] or null: world pose of every geom for the renderer
                              //  (pos3, rotation 9 row-major geom->world, half sizes 3, type)
+  float* contacts;           // [N][1 + 3 * CONTACT_EXPORT] or null (F_DETECT): count, then (geom1, geom2, dist) each
+  int* settle_steps;         // [N] or null (F_SETTLE_EXIT): physics steps the env took in this launch
+  int min_settle_steps;
   int* launch_info;          // [N][4] or null: {overflowed in this launch, max ncon | max schedule
                              //  length << 16, max nefc, max robot rows | max cube-cube contacts << 16}
                              //  over the launch's steps

@@ -906,6 +906,8 @@ MRE_DEV void step_body(const StepArgs& a, Sm& s) {
     grip_cmd = a.grip_closed[env] ? M->act_ctrlrange[NU - 1][1] : M->act_ctrlrange[NU - 1][0];
     __syncthreads();
   }
+  int steps_done = 0;
+  bool settled = false;
   for (int step = 0; step < a.nsteps; ++step) {
     // ------------------------------------------------ S1: position stage
     MRE_STAMP(7);
@@ -927,7 +929,7 @@ MRE_DEV void step_body(const StepArgs& a, Sm& s) {
     const bool constrained = (a.flags & F_NO_CONSTRAINTS) == 0;
     if (constrained) {
 
-      collide(M, s, l);
+      collide(M, s, l, false);
       MRE_STAMP(2);
       assemble_constraints(M, s, l);
 #ifdef MRE_NEWTON
@@ -977,6 +979,14 @@ MRE_DEV void step_body(const StepArgs& a, Sm& s) {
     factor_robot_regs(s.qLD, s.qLD, s.qLDinv);
     solve_robot_par(M, s.qLD, s.qLDinv, s.scratch, 0, 1, l);
     integrate(M, s, l, a.flags);
+    steps_done = step + 1;
+    if ((a.flags & F_SETTLE_EXIT) != 0) {
+      // PropPlacer's settle test on this env's own cubes (prop_initializer.py:247-258)
+      float mv = 0.f, ma = 0.f;
+      if (l >= NRV && l < NRV + 6 * s.nprops) { mv = fabsf(s.qvel[l]); ma = fabsf(s.qacc[l]); }
+      mv = wave_max(mv); ma = wave_max(ma);
+      settled = mv < 1e-3f && ma < 1e-2f && step + 1 > a.min_settle_steps;
+    }
     if (a.trace != nullptr && env < a.trace_nenv && (a.trace_base + step) < a.trace_max) {
       // the pad element of the row carries the step's constraint census (an integer < 2^24, exact
       // in fp32): active contacts + 64 * (bit b - 1 set: the joint of robot body b is at a limit)
@@ -990,8 +1000,10 @@ MRE_DEV void step_body(const StepArgs& a, Sm& s) {
         a.trace[((size_t)(a.trace_base + step) * a.trace_nenv + env) * NQP + l] = v;
       }
     }
+    if (settled) break;
   }
   MRE_STAMP(7);
+  if (a.settle_steps != nullptr && l == 0) a.settle_steps[env] = settled ? steps_done : -steps_done;
   if (a.nsteps == 0 && (a.flags & F_OSC_EVAL) != 0 && a.mode == CTRL_OSC) {
     // OSC.compute_control_output() on the current state (models/robot_arm.py:71): the position and
     // velocity stages the trailing mj_step1 would have left behind, then the torque law
@@ -1005,6 +1017,20 @@ MRE_DEV void step_body(const StepArgs& a, Sm& s) {
     osc_compute(M, s, osc, oscp, s.osc_tgt, l);
     if (l == 0) s.ctrl[NU - 1] = grip_cmd;
     __syncthreads();
+  }
+  if (a.nsteps == 0 && (a.flags & F_DETECT) != 0 && a.contacts != nullptr) {
+    // physics.forward() + physics.data.contact: kinematics, then every detected contact
+    position_stage(M, s, l);
+    collide(M, s, l, true);
+    float* o = a.contacts + (size_t)env * (1 + 3 * CONTACT_EXPORT);
+    const int n = s.ncon < CONTACT_EXPORT ? s.ncon : CONTACT_EXPORT;
+    if (l == 0) o[0] = s.overflow ? -(float)s.ncon : (float)s.ncon;   // negative: the list is cut
+    if (l < n) {
+      const int pr = s.con_pair[l];
+      o[1 + 3 * l] = (float)M->pair_g1[pr]; o[2 + 3 * l] = (float)M->pair_g2[pr]; o[3 + 3 * l] = s.con_dist[l];
+    }
+    __syncthreads();
+    if (l == 0) s.overflow = 0;   // a cut detection list is reported in the count, not as a status bit
   }
   // ---- final kinematics for site queries
   kinematics_only(M, s, l);

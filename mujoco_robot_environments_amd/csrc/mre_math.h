@@ -135,6 +135,21 @@ MRE_DEV float wave_sum(float v) {
   v = dpp_add<0x143, 0xC>(v);  // row_bcast31 -> rows 2,3
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
+template <int CTRL, int ROW_MASK>
+MRE_DEV float dpp_max(float v) {
+  const int t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false);
+  return fmaxf(v, __builtin_bit_cast(float, t));
+}
+// wave64 maximum of non-negative values (lanes a DPP step does not reach contribute 0), uniform result
+MRE_DEV float wave_max(float v) {
+  v = dpp_max<0xB1, 0xF>(v);
+  v = dpp_max<0x4E, 0xF>(v);
+  v = dpp_max<0x141, 0xF>(v);
+  v = dpp_max<0x140, 0xF>(v);
+  v = dpp_max<0x142, 0xA>(v);
+  v = dpp_max<0x143, 0xC>(v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
 MRE_DEV float clampf(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
 }  // namespace mre

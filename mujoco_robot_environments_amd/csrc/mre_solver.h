@@ -64,7 +64,9 @@ MRE_DEV void geom_pose(const DevModel* M, const Sm& s, int g, float* p, float* R
 // ------------------------------------------------------------------ mj_collision
 // lane = entry of the static pair table; keeps ACTIVE contacts only
 // (dist < margin - gap), in pair order, capped at NCON_MAX.
-MRE_PHASE_FN void collide(const DevModel* M, Sm& s, int l) {
+// detect: keep every DETECTED contact (dist < margin: what physics.data.contact lists,
+// environment/prop_initializer.py:121-140) instead of the active ones (dist < margin - gap)
+MRE_PHASE_FN void collide(const DevModel* M, Sm& s, int l, bool detect) {
   // per-lane clip buffers alias the Jacobian pools (contiguous Jp|Jr|Br, unused until assembly)
   // [JpA .. sched] is one contiguous block of arrays that are only written after collision
   static_assert(offsetof(Sm, hdr) + sizeof(((Sm*)0)->hdr) - offsetof(Sm, JpA) >= sizeof(float) * 64 * COLL_BUF,
@@ -79,7 +81,7 @@ MRE_PHASE_FN void collide(const DevModel* M, Sm& s, int l) {
       float p1[3], R1[9], s1[3], rb1, p2[3], R2[9], s2[3], rb2;
       geom_pose(M, s, g1, p1, R1, s1, &rb1);
       geom_pose(M, s, g2, p2, R2, s2, &rb2);
-      const float inc = M->pair_margin[l] - M->pair_gap[l];
+      const float inc = detect ? M->pair_margin[l] : M->pair_margin[l] - M->pair_gap[l];
       float df[3];
       v3sub(df, p2, p1);
       if (M->geom_type[g1] == 0) {

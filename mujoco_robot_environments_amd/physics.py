@@ -277,6 +277,20 @@ class BatchedPhysics:
         check(_lib.lib().mre_get_sites(self._h, _ptr(tcp), _ptr(eef), _ptr(props)), "mre_get_sites")
         return tcp, eef, props
 
+    def contacts(self):
+        """physics.data.contact of every env on the current poses: (count [N] (negative: list cut),
+        contacts [N, 32, 3] = geom1, geom2, dist) -- every DETECTED contact (dist < margin)."""
+        cnt = np.empty(self.num_envs, np.int32)
+        con = np.empty((self.num_envs, 32, 3), np.float32)
+        check(_lib.lib().mre_get_contacts(self._h, _ptr(cnt), _ptr(con)), "mre_get_contacts")
+        return cnt, con
+
+    def settle_steps(self) -> np.ndarray:
+        """Physics steps every env took in the last place_props() settle (negative: not settled in 2 s)."""
+        st = np.empty(self.num_envs, np.int32)
+        check(_lib.lib().mre_get_settle_steps(self._h, _ptr(st)), "mre_get_settle_steps")
+        return st
+
     def status(self) -> np.ndarray:
         st = np.empty(self.num_envs, np.uint32)
         check(_lib.lib().mre_get_status(self._h, _ptr(st)), "mre_get_status")

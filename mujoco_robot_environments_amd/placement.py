@@ -1,5 +1,9 @@
-"""Batched cube placement: host-side mirror of ``PropPlacer.__call__``
-(reference environment/prop_initializer.py:164-283) for thousands of envs.
+"""Batched cube placement on the HOST: a conservative closed-form sampler for scenes that must be
+identical on the oracle and on the device without a device (tests, __graft_entry__.smoke, the
+bench's cpu_baseline leg).  It is NOT what the library does any more: ``mre_place_props`` follows
+``PropPlacer.__call__`` (reference environment/prop_initializer.py:164-283) through the narrow phase
+on the device -- reject while the prop has a detected contact with any geom but the table, robot geoms
+included (tests/test_gpu_env.py checks it against the oracle draw for draw).
 
 Reference semantics per prop: sample position ~ U(workspace), yaw = pi*U(0,1) about z
 (tasks/rearrangement.py:190-206), ``physics.forward()``, reject when any non-table

@@ -217,20 +217,15 @@ class BatchedRearrangementEnv:
             self._physics.set_env_ids(self.env_ids)
         else:
             self._physics.set_env_id_offset(int(self.env_ids[0]))
-        # settle with the robot frozen: >= 0.3 s, <= 2 s, until max|qvel| of the cubes < 1e-3
-        steps, done = 300, False
+        # PropPlacer: contact-based rejection sampling, then settle with the robot frozen; every env
+        # stops by itself (>= 0.3 s, <= 2 s, max|qvel| < 1e-3 and max|qacc| < 1e-2) inside the kernel
         try:
             self._physics.place_props(self.seed + 104729 * self._reset_count, ws.min_pose, ws.max_pose,
-                                      settle_steps=steps)
+                                      settle_steps=300)
         except Exception as e:  # reference: RuntimeError(_REJECTION_SAMPLING_FAILED)
             raise RuntimeError("Failed to find a non-colliding pose for some props") from e
         self._reset_count += 1
-        while not done and steps < 2000:
-            qv = self._physics.qvel()[:, 15:]
-            done = bool(np.abs(qv).max() < 1e-3)
-            if not done:
-                self._physics.step(100, flags=2)
-                steps += 100
+        steps = int(np.abs(self._physics.settle_steps()).max())
         cp = self._cfg.robots.arm.controller_config.controller_params
         mm = self._cfg.robots.end_effector.controller_config.controller
         self._robot = RobotArm(self._physics, controller_params=cp, gripper_cfg=mm)
