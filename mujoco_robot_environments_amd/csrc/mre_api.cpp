@@ -509,7 +509,7 @@ extern "C" int mre_create(const void* blob, size_t nbytes, int num_envs, int dev
   if (const char* it = getenv("MRE_DEBUG_ITERS")) e->hM.iterations = atoi(it);  // profiling knob only
   e->prop_geom0 = -1;
   for (int g = 0; g < NG; g++) if (e->hM.geom_propid[g] == 0) e->prop_geom0 = g;
-  if (e->prop_geom0 < 0 || e->hM.geom_type[1] != 1 || e->hM.geom_body[1] != 0) {
+  if (e->prop_geom0 != PROP_GEOM0 || e->hM.geom_type[1] != 1 || e->hM.geom_body[1] != 0) {
     delete e;
     return fail(MRE_ERR_MODEL, "mre_create: expected geom 1 = the table (static box) and one geom per cube slot");
   }

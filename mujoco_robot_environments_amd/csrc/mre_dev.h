@@ -18,8 +18,9 @@ constexpr int NQP = 44;    // padded qpos row
 constexpr int NVP = 40;    // padded qvel row
 constexpr int NU = 8;
 constexpr int NPROP = 4;
-constexpr int NG = 16;     // geoms
-constexpr int NPAIR = 64;  // static collision pair table: one lane per pair
+constexpr int NG = 20;     // geoms: ground, table, robot hulls + pads, 4 cubes, then the hulls of arm links 1..4
+constexpr int PROP_GEOM0 = 12;  // geom id of cube 0 (cubes 12..15; checked against the blob in mre_create)
+constexpr int NPAIR = 128; // static collision pair table: one lane per pair, two passes (84 pairs in use)
 constexpr int NMR = 96;    // entries of the robot block of the sparse mass matrix
 constexpr int NSITE = 2;
 constexpr int NEQ = 3;

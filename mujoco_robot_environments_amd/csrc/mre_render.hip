@@ -68,7 +68,7 @@ __global__ __launch_bounds__(RENDER_THREADS) void k_render(RenderArgs a) {
       for (int i = 0; i < 3; i++) v.Lg[i] = g[3 + i] * lr[0] + g[6 + i] * lr[1] + g[9 + i] * lr[2];
     }
     v.type = (int)g[15];
-    const int pid = t - (NG - NPROP);  // cubes are the last NPROP geoms
+    const int pid = (t >= PROP_GEOM0 && t < PROP_GEOM0 + NPROP) ? t - PROP_GEOM0 : -1;  // cube geoms
     for (int k = 0; k < 3; k++)
       v.rgb[k] = (pid >= 0) ? a.prop_rgb[((size_t)env * NPROP + pid) * 3 + k] * (1.0f / 255.0f) : a.geom_rgb[t][k];
   }

@@ -62,8 +62,8 @@ MRE_DEV void geom_pose(const DevModel* M, const Sm& s, int g, float* p, float* R
 }
 
 // ------------------------------------------------------------------ mj_collision
-// lane = entry of the static pair table; keeps ACTIVE contacts only
-// (dist < margin - gap), in pair order, capped at NCON_MAX.
+// lane = entry of the static pair table, one wave-wide pass per 64 pairs; keeps ACTIVE contacts
+// only (dist < margin - gap), in pair order, capped at NCON_MAX.
 // detect: keep every DETECTED contact (dist < margin: what physics.data.contact lists,
 // environment/prop_initializer.py:121-140) instead of the active ones (dist < margin - gap)
 MRE_PHASE_FN void collide(const DevModel* M, Sm& s, int l, bool detect) {
@@ -72,72 +72,78 @@ MRE_PHASE_FN void collide(const DevModel* M, Sm& s, int l, bool detect) {
   static_assert(offsetof(Sm, hdr) + sizeof(((Sm*)0)->hdr) - offsetof(Sm, JpA) >= sizeof(float) * 64 * COLL_BUF,
                 "clip buffers do not fit");
   float* buf = &s.JpA[0][0] + l * COLL_BUF;
-  float normal[3] = {0.f, 0.f, 1.f};
-  int n = 0;
-  const int g1 = M->pair_g1[l], g2 = M->pair_g2[l];
-  if (g1 >= 0) {
-    const int b1 = M->geom_body[g1], b2 = M->geom_body[g2];
-    if (body_is_active(M, s, b1) && body_is_active(M, s, b2)) {
-      float p1[3], R1[9], s1[3], rb1, p2[3], R2[9], s2[3], rb2;
-      geom_pose(M, s, g1, p1, R1, s1, &rb1);
-      geom_pose(M, s, g2, p2, R2, s2, &rb2);
-      const float inc = detect ? M->pair_margin[l] : M->pair_margin[l] - M->pair_gap[l];
-      float df[3];
-      v3sub(df, p2, p1);
-      if (M->geom_type[g1] == 0) {
-        float nn[3] = {R1[2], R1[5], R1[8]};
-        if (v3dot(df, nn) - rb2 <= inc) n = plane_box(p1, R1, p2, R2, s2, inc, normal, buf);
-      } else {
-        const float r = rb1 + rb2 + inc;
-        if (v3dot(df, df) <= r * r) n = box_box(p1, R1, s1, p2, R2, s2, inc, normal, buf);
-      }
-      // mesh stand-in pairs keep one contact (deepest point), like MuJoCo's convex-mesh test
-      if (M->pair_single[l] && n > 1) {
-        int best = 0;
-        for (int c = 1; c < n; c++) if (cand_dist(buf, c) < cand_dist(buf, best)) best = c;
-        if (best != 0) {
-          for (int k = 0; k < 3; k++) cand_xyz(buf, 0)[k] = cand_xyz(buf, best)[k];
-          cand_dist(buf, 0) = cand_dist(buf, best);
+  int base = 0;  // contacts kept by the earlier passes (the pair table is two waves long)
+  for (int pass = 0; pass < NPAIR / 64; pass++) {
+    const int pr = l + 64 * pass;
+    float normal[3] = {0.f, 0.f, 1.f};
+    int n = 0;
+    const int g1 = M->pair_g1[pr], g2 = M->pair_g2[pr];
+    if (g1 >= 0) {
+      const int b1 = M->geom_body[g1], b2 = M->geom_body[g2];
+      if (body_is_active(M, s, b1) && body_is_active(M, s, b2)) {
+        float p1[3], R1[9], s1[3], rb1, p2[3], R2[9], s2[3], rb2;
+        geom_pose(M, s, g1, p1, R1, s1, &rb1);
+        geom_pose(M, s, g2, p2, R2, s2, &rb2);
+        const float inc = detect ? M->pair_margin[pr] : M->pair_margin[pr] - M->pair_gap[pr];
+        float df[3];
+        v3sub(df, p2, p1);
+        if (M->geom_type[g1] == 0) {
+          float nn[3] = {R1[2], R1[5], R1[8]};
+          if (v3dot(df, nn) - rb2 <= inc) n = plane_box(p1, R1, p2, R2, s2, inc, normal, buf);
+        } else {
+          const float r = rb1 + rb2 + inc;
+          if (v3dot(df, df) <= r * r) n = box_box(p1, R1, s1, p2, R2, s2, inc, normal, buf);
         }
-        n = 1;
-      }
-      // instantiate only contacts with dist < includemargin
-      int m = 0;
-      for (int c = 0; c < n; c++)
-        if (cand_dist(buf, c) < inc) {
-          if (m != c) {
-            for (int k = 0; k < 3; k++) cand_xyz(buf, m)[k] = cand_xyz(buf, c)[k];
-            cand_dist(buf, m) = cand_dist(buf, c);
+        // mesh stand-in pairs keep one contact (deepest point), like MuJoCo's convex-mesh test
+        if (M->pair_single[pr] && n > 1) {
+          int best = 0;
+          for (int c = 1; c < n; c++) if (cand_dist(buf, c) < cand_dist(buf, best)) best = c;
+          if (best != 0) {
+            for (int k = 0; k < 3; k++) cand_xyz(buf, 0)[k] = cand_xyz(buf, best)[k];
+            cand_dist(buf, 0) = cand_dist(buf, best);
           }
-          m++;
+          n = 1;
         }
-      n = m;
+        // instantiate only contacts with dist < includemargin
+        int m = 0;
+        for (int c = 0; c < n; c++)
+          if (cand_dist(buf, c) < inc) {
+            if (m != c) {
+              for (int k = 0; k < 3; k++) cand_xyz(buf, m)[k] = cand_xyz(buf, c)[k];
+              cand_dist(buf, m) = cand_dist(buf, c);
+            }
+            m++;
+          }
+        n = m;
+      }
     }
-  }
-  s.iscr[l] = n;
-  __syncthreads();
-  int off = 0;
-  for (int k = 0; k < l; k++) off += s.iscr[k];
-  if (l == 63) {
-    const int tot = off + n;
-    s.ncon = tot < NCON_MAX ? tot : NCON_MAX;
-    if (tot > NCON_MAX) s.overflow = 1;
-  }
-  if (n > 0) {
-    float f[9];
-    v3copy(f, normal);
-    make_frame(f);
-    for (int c = 0; c < n; c++) {
-      const int id = off + c;
-      if (id >= NCON_MAX) break;
-      const float cx0 = cand_xyz(buf, c)[0], cx1 = cand_xyz(buf, c)[1], cx2 = cand_xyz(buf, c)[2];
-      s.con_pos[id][0] = cx0; s.con_pos[id][1] = cx1; s.con_pos[id][2] = cx2;
-      for (int k = 0; k < 9; k++) s.con_frame[id][k] = f[k];
-      s.con_dist[id] = cand_dist(buf, c);
-      s.con_pair[id] = l;
+    s.iscr[l] = n;
+    __syncthreads();
+    int off = base;
+    for (int k = 0; k < l; k++) off += s.iscr[k];
+    if (l == 63) {
+      const int tot = off + n;
+      s.ncon = tot < NCON_MAX ? tot : NCON_MAX;
+      if (tot > NCON_MAX) s.overflow = 1;
     }
+    if (n > 0) {
+      float f[9];
+      v3copy(f, normal);
+      make_frame(f);
+      for (int c = 0; c < n; c++) {
+        const int id = off + c;
+        if (id >= NCON_MAX) break;
+        const float cx0 = cand_xyz(buf, c)[0], cx1 = cand_xyz(buf, c)[1], cx2 = cand_xyz(buf, c)[2];
+        s.con_pos[id][0] = cx0; s.con_pos[id][1] = cx1; s.con_pos[id][2] = cx2;
+        for (int k = 0; k < 9; k++) s.con_frame[id][k] = f[k];
+        s.con_dist[id] = cand_dist(buf, c);
+        s.con_pair[id] = (uint8_t)pr;
+      }
+    }
+    __syncthreads();
+    base = s.ncon;   // (capped: once the list is full the later passes add nothing)
+    if (s.overflow) break;
   }
-  __syncthreads();
 }
 
 // getimpedance (MuJoCo engine_core_constraint.c)

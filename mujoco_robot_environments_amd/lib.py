@@ -50,7 +50,10 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return _SO
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    base = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
+    # -ffp-contract=on: a * b + c is fused where the SOURCE expression says so, not wherever the optimiser
+    # finds one after unrolling -- the compact and the large instantiation of the step kernel must round
+    # identically (the capacity fallback re-runs an env on the other one and promises the same bits)
+    base = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-ffp-contract=on"]
     if verbose:
         base.insert(1, "-Rpass-analysis=kernel-resource-usage")
     bdir = os.path.join(_CSRC, "_build")

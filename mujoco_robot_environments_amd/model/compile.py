@@ -390,13 +390,17 @@ def compile_scene(scene: dict = None) -> Dict[str, np.ndarray]:
     # geoms / sites
     geoms, geom_body = [], []
     sites, site_body = [], []
+    for late in (False, True):   # ``late`` geoms (spec.py: hulls of arm links 1..4) take the last ids
+        for i, b in enumerate(bodies):
+            for g in b.geoms:
+                if bool(g.get("late", False)) == late:
+                    geoms.append(g)
+                    geom_body.append(i)
     for i, b in enumerate(bodies):
-        for g in b.geoms:
-            geoms.append(g)
-            geom_body.append(i)
         for s in b.sites:
             sites.append(s)
             site_body.append(i)
+    n_early = sum(1 for g in geoms if not g.get("late", False))
     # MuJoCo sorts nothing; keep spec order but put the plane first for pair typing
     ng = len(geoms)
     gtype = np.array([GEOM_PLANE if g["type"] == "plane" else GEOM_BOX for g in geoms], np.int32)
@@ -415,8 +419,12 @@ def compile_scene(scene: dict = None) -> Dict[str, np.ndarray]:
     # collision pairs with MuJoCo's static filters (engine_collision_driver.c:
     # contype/conaffinity, same body, filterparent, both bodies welded to world)
     pairs = []
-    for a in range(ng):
-        for c in range(a + 1, ng):
+    # pairs among the early geoms first, then the pairs that involve a late geom: the table keeps its
+    # first entries (the kernels walk it 64 pairs per pass, contacts are listed in this order)
+    order = [(a, c) for a in range(n_early) for c in range(a + 1, n_early)]
+    order += [(a, c) for a in range(ng) for c in range(max(a + 1, n_early), ng)]
+    for a, c in order:
+        if True:
             ga, gc = geoms[a], geoms[c]
             ba, bc = geom_body[a], geom_body[c]
             if not ((ga["contype"] & gc["conaffinity"]) or (gc["contype"] & ga["conaffinity"])):

@@ -110,6 +110,13 @@ _PANDA_LINKS = [
 
 # box hulls standing in for the link collision meshes (deviation, see header)
 _PANDA_HULLS = {
+    # links 1..4 (the reference loads their menagerie meshes too, models/arms/franka_emika.py:7-11): the
+    # elbow can reach the table and the cubes.  ``late``: these geoms get the ids AFTER the cubes so that
+    # the ids of the geoms that existed before them (segmentation images, pair order) stay what they were.
+    "link1": dict(size=(0.055, 0.065, 0.10), pos=(0.0, -0.02, -0.09), late=True),
+    "link2": dict(size=(0.055, 0.10, 0.065), pos=(0.0, -0.07, 0.02), late=True),
+    "link3": dict(size=(0.06, 0.065, 0.09), pos=(0.03, 0.02, -0.07), late=True),
+    "link4": dict(size=(0.065, 0.085, 0.06), pos=(-0.045, 0.06, 0.0), late=True),
     "link5": dict(size=(0.055, 0.07, 0.11), pos=(0.0, 0.04, -0.12)),
     "link6": dict(size=(0.065, 0.055, 0.06), pos=(0.045, 0.0, 0.0)),
     "link7": dict(size=(0.05, 0.05, 0.04), pos=(0.0, 0.0, 0.07)),
@@ -128,7 +135,9 @@ def panda_spec(gripper: Optional[dict] = None) -> dict:
         geoms = []
         if name in _PANDA_HULLS:
             h = _PANDA_HULLS[name]
-            geoms.append(box(f"{name}_hull", h["size"], pos=h["pos"], hull=True))
+            g = box(f"{name}_hull", h["size"], pos=h["pos"], hull=True)
+            g["late"] = bool(h.get("late", False))
+            geoms.append(g)
         child = body(name, pos=pos, quat=quat,
                      inertial=inertial(mass, com, fullinertia=full),
                      joint=hinge(f"joint{i + 1}", (0, 0, 1), _PANDA_RANGES[i],

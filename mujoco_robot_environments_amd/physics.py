@@ -307,9 +307,9 @@ class BatchedPhysics:
     # ---------------------------------------------------------- measurement
     # ------------------------------------------------------------------ camera
     def set_render_colours(self, prop_rgb=None, geom_rgb=None) -> None:
-        """prop_rgb [N, 4, 3] uint8 cube albedo; geom_rgb [16, 3] float albedo of the static geoms."""
+        """prop_rgb [N, 4, 3] uint8 cube albedo; geom_rgb [ngeom, 3] float albedo of the other geoms."""
         p = None if prop_rgb is None else np.ascontiguousarray(prop_rgb, np.uint8).reshape(self.num_envs, MRE_MAX_PROPS, 3)
-        g = None if geom_rgb is None else np.ascontiguousarray(geom_rgb, np.float32).reshape(16, 3)
+        g = None if geom_rgb is None else np.ascontiguousarray(geom_rgb, np.float32).reshape(int(self.model["ngeom"][0]), 3)
         check(_lib.lib().mre_set_render_colours(self._h, _ptr(p), _ptr(g)), "mre_set_render_colours")
 
     def render(self, cam_pos, cam_mat, fovy: float, height: int, width: int, rgb: bool = True, depth: bool = True,

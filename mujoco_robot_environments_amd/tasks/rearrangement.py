@@ -137,7 +137,7 @@ class BatchedRearrangementEnv:
                 rgbf = np.clip(np.asarray(COLOURS.get(c, (0.5, 0.5, 0.5))) + COLOUR_NOISE * (2 * un[i, p] - 1), 0.0, 1.0)
                 self.prop_rgba[i, p, :3] = rgbf
                 self.prop_rgb[i, p] = np.round(rgbf * 255)
-        geom_rgb = np.full((16, 3), 0.25, np.float32)
+        geom_rgb = np.full((int(self._model["ngeom"][0]), 3), 0.25, np.float32)
         geom_rgb[1] = 0.5
         self._physics.set_render_colours(self.prop_rgb, geom_rgb)
         self._reset_count = 0
@@ -166,7 +166,7 @@ class BatchedRearrangementEnv:
 
     def render(self, rgb: bool = True, depth: bool = True, seg: bool = True, camera: str = OVERHEAD):
         """Overhead camera images of every env's current state as CUDA tensors (rgb uint8 [N,H,W,3],
-        depth float32 [N,H,W], seg uint8 [N,H,W]: 12 + p = cube p, 1 table, 2..11 robot, 255 nothing):
+        depth float32 [N,H,W], seg uint8 [N,H,W]: 12 + p = cube p, 1 table, 2..11 and 16..19 robot, 255 nothing):
         the batched form of the reference's renderer / depth_renderer / seg_renderer passes
         (tasks/rearrangement.py:254-280, 460-478)."""
         cam = self._cameras[camera]

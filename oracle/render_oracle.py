@@ -84,7 +84,7 @@ def render(A, qpos, nprops, half_sizes, prop_rgb, geom_rgb, cam_pos, cam_mat, fo
         m = seg == g
         if not m.any():
             continue
-        pid = g - (ng - 4)
+        pid = int(A["geom_propid"][g])   # cube slot of the geom, -1 for every other geom
         if typ[g] == 0:
             loc = (p[m] - pos[g]) @ mat[g]
             par = (np.floor(loc[:, 0] / CHECKER_SIZE) + np.floor(loc[:, 1] / CHECKER_SIZE)).astype(int) & 1

@@ -20,7 +20,7 @@ def _scene(N, seed=0):
     nprops, sizes = bench.setup_envs(phys, seed, ids)
     u = rng.uniform(seed + 77, ids, [0], 12)[0]
     prop_rgb = (u.reshape(N, 4, 3) * 255).astype(np.uint8)
-    geom_rgb = np.linspace(0.2, 0.9, 48).reshape(16, 3).astype(np.float32)
+    geom_rgb = np.linspace(0.2, 0.9, 60).reshape(20, 3).astype(np.float32)
     phys.set_render_colours(prop_rgb, geom_rgb)
     return phys, nprops, sizes, prop_rgb, geom_rgb
 

@@ -10,7 +10,7 @@ from mujoco_robot_environments_amd.model import compile as MC
 def test_scene_dimensions(compiled_model):
     A, blob = compiled_model
     assert int(A["nbody"][0]) == 20 and int(A["nv"][0]) == 39 and int(A["nq"][0]) == 43
-    assert int(A["nu"][0]) == 8 and int(A["npair"][0]) == 64 and int(A["neq"][0]) == 3
+    assert int(A["nu"][0]) == 8 and int(A["npair"][0]) == 84 and int(A["neq"][0]) == 3
     # robot dofs precede the cubes, arm dofs are 0..6 (kernel assumption)
     assert list(A["arm_dof"]) == list(range(7))
     assert list(A["body_dofadr"][16:20]) == [15, 21, 27, 33]

@@ -23,7 +23,7 @@ def scene():
     Rc = MC.q2m(CAM_QUAT / np.linalg.norm(CAM_QUAT))
     half = np.full((4, 3), 0.0155)
     prop_rgb = np.array([[0, 255, 0], [0, 0, 255], [255, 0, 0], [255, 255, 0]], np.uint8)
-    geom_rgb = np.full((16, 3), 0.5)
+    geom_rgb = np.full((20, 3), 0.5)
     rgb, depth, seg = RO.render(A, q, 2, half, prop_rgb, geom_rgb, CAM_POS, Rc, FOVY, H, W)
     return A, q, Rc, rgb, depth, seg, cubes
 

@@ -14,7 +14,7 @@ NAMES = ["position+crb+factor", "velocity", "collide", "assemble", "control", "s
 if sys.argv[1] == "build":
     os.makedirs(DIAG, exist_ok=True)
     for k in (0, 1, 2):
-        base = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
+        base = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-ffp-contract=on"]
         objs = []
         for name, src, flags in (("k", "mre_kernels.hip", [f"-DMRE_PHASE_STAMPS={k}"]),
                                  ("kl", "mre_kernels.hip", ["-DMRE_LARGE_CAPS", f"-DMRE_PHASE_STAMPS={k}"]),
