@@ -151,3 +151,62 @@ def test_newton_run_controller_parity(compiled_model, oracle_model):
     print("newton run_controller: max err per env", np.round(worst, 6).tolist(), "converged", conv.tolist())
     assert (conv == oconv).all()
     assert np.median(worst) < TOL and (worst < TOL).mean() >= 0.8
+
+
+def test_arm_link_hulls_collide_with_cubes(compiled_model, oracle_model):
+    """Collision hulls of arm links 1..4 (the reference loads the menagerie meshes of every link,
+    models/arms/franka_emika.py:7-11).  With the base at table height the elbow stays >= 0.55 m above
+    the table top, so these hulls only ever meet cubes: one cube is dropped onto the hull of link 4
+    (arm held by gravity compensation), one rests on the table.  Device vs oracle (Newton): the cube
+    lands on the link in both, same touching geom pairs while it sits there, cube position at the bar."""
+    from mujoco_robot_environments_amd.physics import BatchedPhysics
+    from oracle import oracle as O
+    A, _ = compiled_model
+    names = A["_names"]["geoms"]
+    N = 8
+    nprops = np.full(N, 2, np.int32)
+    sizes = np.full((N, 4, 3), 0.0155)
+    g4 = names.index("link4_hull")
+    envs, qp = [], np.zeros((N, 43), np.float32)
+    for i in range(N):
+        e = O.Env(oracle_model, 2, sizes[i])
+        e.set_solver("Newton")
+        q = e.arr("qpos")
+        q[:7] = [0.1 * i - 0.3, -0.3, 0.0, -1.9, 0.0, 1.6, 0.8]
+        e.forward()
+        c = e.arr("geom_xpos").reshape(-1, 3)[g4]
+        R = e.arr("geom_xmat").reshape(-1, 9)[g4].reshape(3, 3)
+        top = c[2] + np.abs(R[2] * A["geom_size"][g4]).sum()     # highest point of the hull box
+        q[15:22] = [c[0], c[1], top + 0.0155 + 0.01, 1, 0, 0, 0]  # 1 cm above it
+        q[22:29] = [0.5, 0.25, 0.4155, 1, 0, 0, 0]
+        q[:43] = q[:43].astype(np.float32)
+        e.forward()
+        qp[i] = q[:43]
+        envs.append(e)
+    phys = BatchedPhysics(N, model=A, solver="Newton")
+    phys.set_props(nprops, sizes)
+    phys.reset()
+    phys.set_state(qp, np.zeros((N, 39), np.float32))
+    ctrl = np.zeros((N, 8), np.float32)
+    for i, e in enumerate(envs):
+        ctrl[i, :7] = e.arr("qfrc_bias")[:7]
+    phys.set_control(ctrl)
+    T = 120
+    phys.step(T)
+    phys.sync()
+    gq = phys.qpos()
+    cnt, con = phys.contacts()
+    on_link, same_pairs, worst = 0, 0, 0.0
+    for i, e in enumerate(envs):
+        e.arr("ctrl")[:] = ctrl[i].astype(np.float64)
+        e.step(T)
+        opairs = sorted({(int(c[13]), int(c[14])) for c in e.contacts() if c[12] < 0})
+        gpairs = sorted({(int(con[i, k, 0]), int(con[i, k, 1])) for k in range(abs(int(cnt[i]))) if con[i, k, 2] < 0})
+        on_link += (12, g4) in gpairs and (12, g4) in opairs
+        same_pairs += opairs == gpairs
+        worst = max(worst, float(np.abs(gq[i, 15:18] - e.arr("qpos")[15:18]).max()))
+    print(f"cube on the link-4 hull in {on_link}/{N} envs (device and oracle), same touching pairs in {same_pairs}/{N}, "
+          f"cube |dx| max {worst:.1e}; status {np.unique(phys.status()).tolist()}")
+    assert (phys.status() & 6 == 0).all()
+    assert on_link >= N - 2 and same_pairs >= N - 1
+    assert worst < 1e-4
