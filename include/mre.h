@@ -194,6 +194,10 @@ int mre_set_fallback(mre_env*, int mode);
  * NULL = the legacy default stream).  The caller keeps the buffers alive until mre_sync. */
 int mre_wait_stream(mre_env*, void* stream);
 
+/* CRC-32C (Castagnoli) of a host buffer -- TFRecord framing of the episode shards
+ * (transporter_network_data_generation.py:103-111; mujoco_robot_environments_amd/dataset.py) */
+uint32_t mre_crc32c(const void* data, size_t nbytes);
+
 #define MRE_SOLVER_PGS 0
 #define MRE_SOLVER_NEWTON 2
 int mre_set_solver(mre_env*, int solver);

@@ -755,6 +755,35 @@ extern "C" int mre_set_fallback(mre_env* e, int mode) {
   return MRE_OK;
 }
 
+// CRC-32C (Castagnoli) of a host buffer: the checksum of TFRecord framing (dataset.py writes the
+// reference's RLDS episodes, transporter_network_data_generation.py:56-111); slicing-by-8 tables
+extern "C" uint32_t mre_crc32c(const void* data, size_t n) {
+  static uint32_t T[8][256];
+  static bool init = false;
+  if (!init) {
+    for (uint32_t i = 0; i < 256; i++) {
+      uint32_t c = i;
+      for (int k = 0; k < 8; k++) c = (c >> 1) ^ ((c & 1u) ? 0x82F63B78u : 0u);
+      T[0][i] = c;
+    }
+    for (int k = 1; k < 8; k++)
+      for (uint32_t i = 0; i < 256; i++) T[k][i] = (T[k - 1][i] >> 8) ^ T[0][T[k - 1][i] & 0xFFu];
+    init = true;
+  }
+  const unsigned char* p = (const unsigned char*)data;
+  uint32_t crc = 0xFFFFFFFFu;
+  while (n >= 8) {
+    uint32_t lo, hi;
+    memcpy(&lo, p, 4); memcpy(&hi, p + 4, 4);
+    lo ^= crc;
+    crc = T[7][lo & 0xFF] ^ T[6][(lo >> 8) & 0xFF] ^ T[5][(lo >> 16) & 0xFF] ^ T[4][lo >> 24] ^
+          T[3][hi & 0xFF] ^ T[2][(hi >> 8) & 0xFF] ^ T[1][(hi >> 16) & 0xFF] ^ T[0][hi >> 24];
+    p += 8; n -= 8;
+  }
+  while (n--) crc = T[0][(crc ^ *p++) & 0xFFu] ^ (crc >> 8);
+  return crc ^ 0xFFFFFFFFu;
+}
+
 extern "C" int mre_wait_stream(mre_env* e, void* stream) {
   if (!e) return fail(MRE_ERR_ARG, "null handle");
   HIPCHK(hipSetDevice(e->device));

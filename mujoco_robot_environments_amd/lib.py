@@ -26,7 +26,7 @@ EXPORTS = [
     "mre_set_trace", "mre_osc_set_target", "mre_osc_configure", "mre_gripper_set",
     "mre_run_controller", "mre_get_sites", "mre_get_status", "mre_get_solver_stats",
     "mre_profile_enable", "mre_profile_read", "mre_set_env_id_offset", "mre_set_env_order",
-    "mre_set_fallback", "mre_get_fallback_stats", "mre_set_solver", "mre_get_solver", "mre_wait_stream", "mre_osc_compute", "mre_get_contacts", "mre_get_settle_steps", "mre_osc_configure_env", "mre_set_env_ids", "mre_set_render_colours", "mre_render",
+    "mre_set_fallback", "mre_get_fallback_stats", "mre_set_solver", "mre_get_solver", "mre_wait_stream", "mre_osc_compute", "mre_get_contacts", "mre_get_settle_steps", "mre_crc32c", "mre_osc_configure_env", "mre_set_env_ids", "mre_set_render_colours", "mre_render",
 ]
 
 
@@ -132,7 +132,7 @@ def lib() -> C.CDLL:
     L.mre_osc_configure_env.argtypes = [vp, fp, fp, fp]
     L.mre_get_fallback_stats.argtypes = [vp, C.POINTER(C.c_longlong)]
     for name in EXPORTS:
-        if name not in ("mre_last_error", "mre_stream"):
+        if name not in ("mre_last_error", "mre_stream", "mre_crc32c"):
             getattr(L, name).restype = ci
     _LIB = L
     return L

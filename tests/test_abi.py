@@ -18,7 +18,7 @@ def libmre():
 
 def test_header_symbols_exported(libmre):
     hdr = open(os.path.join(ROOT, "include", "mre.h")).read()
-    names = set(re.findall(r"\b(mre_[a-z_]+)\s*\(", hdr))
+    names = set(re.findall(r"\b(mre_[a-z0-9_]+)\s*\(", hdr))
     assert len(names) >= 20
     for n in sorted(names):
         assert hasattr(libmre, n), f"{n} declared in include/mre.h but not exported"
@@ -27,7 +27,7 @@ def test_header_symbols_exported(libmre):
 def test_python_binding_lists_all(libmre):
     from mujoco_robot_environments_amd import lib
     hdr = open(os.path.join(ROOT, "include", "mre.h")).read()
-    names = set(re.findall(r"\b(mre_[a-z_]+)\s*\(", hdr))
+    names = set(re.findall(r"\b(mre_[a-z0-9_]+)\s*\(", hdr))
     assert names == set(lib.EXPORTS)
 
 
