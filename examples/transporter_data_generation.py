@@ -28,6 +28,9 @@ def main():
                     help="OSC gains instead of osc.yaml's (config.TUNED_OSC_GAINS: 525.4 215.2 766.6 158.6 22.6 7.2)")
     ap.add_argument("--tuned-gains", action="store_true", help="config.apply_tuned_osc_gains (CMA-ES result for this arm model)")
     ap.add_argument("--render", action="store_true", help="overhead-camera observations (depth + RGB, CUDA tensors) instead of zero images")
+    ap.add_argument("--out", default=None, help="write the episodes as RLDS shards (TFRecord, the reference ds_config's feature "
+                    "keys: mujoco_robot_environments_amd/dataset.py) into this directory")
+    ap.add_argument("--log-envs", type=int, default=64, help="with --out: episodes of the first K envs are written")
     ap.add_argument("--solver", choices=["Newton", "PGS"], default="Newton", help="constraint solver (the reference's MuJoCo runs Newton)")
     args = ap.parse_args()
     cfg = colour_separator_task_config()
@@ -41,9 +44,18 @@ def main():
     env = BatchedRearrangementEnv(cfg=cfg, num_envs=args.num_envs, render=args.render, solver=args.solver)
     cam = "overhead_camera/overhead_camera"
     t0 = time.time()
-    _, _, _, obs = env.reset()
+    ts = env.reset()
+    obs = ts.observation
     metadata = env.get_camera_metadata()  # episode metadata of the reference (calibration_metadata)
     episodes = []
+    logger = None
+    if args.out:
+        from mujoco_robot_environments_amd.dataset import BatchedEpisodeLogger, EpisodeWriter
+        writer = EpisodeWriter(args.out, f"{cfg.get('name', 'colour_splitter')}", env.overhead_camera_height, env.overhead_camera_width,
+                               max_episodes_per_file=cfg.dataset.max_episodes_per_file)
+        mask = np.arange(args.num_envs) < args.log_envs
+        logger = BatchedEpisodeLogger(env, writer, mask)
+        logger.reset(ts)
     for step in range(max_steps):
         in_progress, pick_pose, place_pose = env.sort_colours()
         if not in_progress.any():
@@ -51,8 +63,13 @@ def main():
             break
         pick_action = {"pose": pick_pose, "pixel_coords": env.world_2_pixel(cam, pick_pose[:, :3]), "gripper_rot": 0.0}
         place_action = {"pose": place_pose, "pixel_coords": env.world_2_pixel(cam, place_pose[:, :3]), "gripper_rot": 0.0}
-        _, _, _, obs = env.step(pick_action)
-        _, _, _, obs = env.step(place_action)
+        ts = env.step(pick_action)
+        if logger:
+            logger.step(pick_action, ts, in_progress)
+        ts = env.step(place_action)
+        if logger:
+            logger.step(place_action, ts, in_progress)
+        obs = ts.observation
         episodes.append((pick_action, place_action))
         if args.render and step == 0:
             d = obs["overhead_camera/depth"]
@@ -62,6 +79,9 @@ def main():
         print(f"pair {step}: {in_progress.sum()} envs in progress, all phases converged in "
               f"{int(env.last_converged.sum())}/{args.num_envs} envs, "
               f"{args.num_envs * (step + 1) * nsim / (time.time() - t0):.3g} env-steps/s so far (reset included)")
+    if logger:
+        logger.flush()
+        print("episode shards:", writer.close())
     done = ~env.sort_colours()[0]
     print(f"{int(done.sum())}/{args.num_envs} envs have every cube in its colour's target after {len(episodes)} pairs; "
           f"intrinsics fx={metadata['intrinsics']['fx']:.1f}; wall {time.time() - t0:.1f} s")
