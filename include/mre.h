@@ -85,6 +85,24 @@ int mre_reset(mre_env*, const uint8_t* mask);
 int mre_place_props(mre_env*, const uint8_t* mask, uint64_t seed, const float* ws_min,
                     const float* ws_max, int max_attempts, int settle_steps);
 int mre_get_settle_steps(mre_env*, int32_t* steps);
+
+/* prop_place (tasks/rearrangement.py:597-665), batched and on the device (one wave per env runs its
+ * own attempt loop; the physics state is left alone, the reference works on a deepcopy).  Env i looks
+ * for a pose of cube prop[i] (< 0: nothing asked) in [bounds[i][0:3], bounds[i][3:6]] (min_pose /
+ * max_pose) with orientation mju_mat2Quat(Ry(180 deg)); draw t is keyed by (seed, global env id,
+ * tick[i] + t); a pose is rejected while a detected contact (dist < margin) of the cube with a geom
+ * other than the table has dist <= max_dist (:623: 0.05).  pose [N][7] (xyz, quat wxyz, fp64),
+ * attempts [N]: draws used, 0 = nothing asked, < 0 = none accepted within max_attempts (the
+ * reference raises "Failed to find collision free place pose.").  All arrays host or device. */
+int mre_prop_place(mre_env*, uint64_t seed, const int32_t* prop, const double* bounds, const int32_t* tick,
+                   int max_attempts, float max_dist, double* pose, int32_t* attempts);
+/* sort_colours (tasks/rearrangement.py:700-751) for every env, on the device: the first cube (prop
+ * order) outside its colour's zone (zones [N][4][4]: lo x, lo y, hi x, hi y per cube), prop_pick for
+ * it (:579-595) and prop_place inside the zone at z = 0.4 (keys: seed + 1, ticks call_counts[i] * 10000
+ * + t).  which [N]: the selected cube or -1 (all sorted: pick / place rows unspecified); pick, place
+ * [N][7] fp64; attempts as in mre_prop_place. */
+int mre_sort_colours(mre_env*, uint64_t seed, const int32_t* call_counts, const double* zones, int max_attempts,
+                     float max_dist, int32_t* which, double* pick, double* place, int32_t* attempts);
 /* physics.forward() + physics.data.contact (prop_initializer.py:123-139, tasks/rearrangement.py:
  * 612-627): every contact the narrow phase DETECTS on the current poses (dist < margin; the solver
  * only uses those with dist < margin - gap).  count[N] (negative: list cut at -count),

@@ -32,6 +32,8 @@ extern "C" void mre_launch_restore_rows(const uint8_t* sel, int N, float* qpos, 
                                         const float* sv_qvel, float* qacc_ws, const float* sv_qacc_ws, float* ctrl,
                                         const float* sv_ctrl, uint32_t* status, const uint32_t* sv_status,
                                         uint8_t* converged, const uint8_t* sv_converged, hipStream_t stream);
+extern "C" void mre_launch_pose_search(const SearchArgs* args, hipStream_t stream);
+extern "C" void mre_launch_sort_select(const SortArgs* args, hipStream_t stream);
 extern "C" void mre_launch_reset(const DevModel* M, int N, float* qpos, float* qvel, float* qacc_ws,
                                  float* ctrl, uint32_t* status, const uint8_t* mask,
                                  hipStream_t stream);
@@ -102,6 +104,10 @@ struct mre_env {
   int* h_launch_info = nullptr;  // pinned host mirror
   std::vector<uint8_t> h_large, h_rerun;
   int n_large = 0;
+  long long* d_env_ids = nullptr; // device copy of env_ids (pose search), null = offset + index
+  // pose-search / sort_colours scratch (device, allocated on first use)
+  int *ps_attempts = nullptr, *ps_prop = nullptr, *ps_tick = nullptr, *ps_which = nullptr;
+  double *ps_bounds = nullptr, *ps_pose = nullptr, *ps_zones = nullptr, *ps_pick = nullptr;
   int prop_geom0 = 12;           // geom id of cube 0 (cubes are the last NPROP geoms)
   int last_settle_max = 0;
   long long n_reruns = 0, n_promotions = 0, n_demotions = 0;
@@ -542,7 +548,9 @@ extern "C" int mre_destroy(mre_env* e) {
                   e->grip_closed, e->converged, e->mask, e->sites, e->status, e->stats, e->d_osc, e->d_osc_env, e->order,
                   e->geoms, e->prop_rgb, e->bg_depth, e->bg_rgb, e->bg_seg,
                   e->d_large, e->mask_c, e->mask_l, e->mask_r, e->sv_qpos, e->sv_qvel, e->sv_qacc_ws, e->sv_ctrl,
-                  e->sv_status, e->launch_info, e->auto_order, e->sv_converged, e->contacts, e->settle_steps};
+                  e->sv_status, e->launch_info, e->auto_order, e->sv_converged, e->contacts, e->settle_steps,
+                  e->d_env_ids, e->ps_attempts, e->ps_prop, e->ps_tick, e->ps_which, e->ps_bounds, e->ps_pose, e->ps_zones,
+                  e->ps_pick};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (e->h_launch_info) (void)hipHostFree(e->h_launch_info);
   if (e->h_auto_order) (void)hipHostFree(e->h_auto_order);
@@ -1072,26 +1080,22 @@ extern "C" int mre_osc_compute(mre_env* e, float* tau, float* grip) {
   return MRE_OK;
 }
 
-// ---- PropPlacer.__call__ (environment/prop_initializer.py:164-283), batched.
-// Same counter-based stream and rejection rule as mujoco_robot_environments_amd/placement.py
-// (splitmix64 keyed by (seed, GLOBAL env id, attempt, channel)): sample position ~ U(workspace),
-// yaw = pi*U(0,1); reject while another placed cube is closer than the 0.15 m contact margin
-// (bounding-sphere form of "any non-table contact detected"); envs whose scene cannot be
-// completed re-draw it in a further round.  Then settle on the GPU with the robot frozen.
-namespace {
-inline uint64_t mix64(uint64_t x) {
-  x += 0x9E3779B97F4A7C15ull;
-  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-  return x ^ (x >> 31);
+// ---- device buffers and launch arguments of k_pose_search (mre_place_props, mre_prop_place, mre_sort_colours)
+static int search_buffers(mre_env* e) {
+  if (e->ps_attempts) return MRE_OK;
+  const size_t N = (size_t)e->N;
+  HIPCHK(hipMalloc(&e->ps_attempts, N * 4)); HIPCHK(hipMalloc(&e->ps_prop, N * 4));
+  HIPCHK(hipMalloc(&e->ps_tick, N * 4)); HIPCHK(hipMalloc(&e->ps_which, N * 4));
+  HIPCHK(hipMalloc(&e->ps_bounds, N * 6 * 8)); HIPCHK(hipMalloc(&e->ps_pose, N * 7 * 8));
+  HIPCHK(hipMalloc(&e->ps_zones, N * NPROP * 4 * 8)); HIPCHK(hipMalloc(&e->ps_pick, N * 7 * 8));
+  return MRE_OK;
 }
-inline double uniform01(uint64_t seed, uint64_t env, uint64_t tick, uint64_t ch) {
-  uint64_t k = mix64(seed + 0x9E3779B97F4A7C15ull * env);
-  k = mix64(k ^ (tick * 0xBF58476D1CE4E5B9ull));
-  k = mix64(k ^ (ch * 0x94D049BB133111EBull));
-  return (double)(k >> 11) * (1.0 / 9007199254740992.0);
+static void fill_search(mre_env* e, SearchArgs& sa) {
+  memset(&sa, 0, sizeof(sa));
+  sa.M = e->dM; sa.N = e->N; sa.qpos = e->qpos; sa.nprops = e->nprops; sa.prop_size = e->prop_size;
+  sa.env_ids = e->d_env_ids; sa.env_id_offset = e->env_id_offset;
+  sa.attempts = e->ps_attempts; sa.fixed_prop = -1;
 }
-}  // namespace
 
 // physics.forward() + physics.data.contact on the current poses: one zero-step launch that runs the
 // kinematics and the narrow phase and exports every DETECTED contact (dist < margin), per env
@@ -1130,8 +1134,9 @@ extern "C" int mre_get_contacts(mre_env* e, int32_t* count, float* contacts) {
 // ---- PropPlacer.__call__ (environment/prop_initializer.py:164-283), batched.
 // Props are placed one index at a time over the whole batch, as the reference places them one
 // after the other: every env that still needs prop p draws a pose (position ~ U(workspace), yaw =
-// pi U(0,1); counter RNG keyed by (seed, GLOBAL env id, p * max_attempts + attempt, channel)), a
-// detect launch evaluates physics.forward() for the batch, and the pose is rejected while prop p
+// pi U(0,1); counter RNG keyed by (seed, GLOBAL env id, p * max_attempts + attempt, channel)) in its
+// own attempt loop on the device (k_pose_search evaluates physics.forward() of the moved prop: its
+// frame and the narrow phase of its pairs), and the pose is rejected while prop p
 // has any detected contact (dist < margin 0.15) with a geom other than the table -- placed props and
 // robot geoms alike (_has_collisions_with_prop, :121-140; props not yet placed are parked out of
 // reach, the reference disables their contacts).  Then the physics settles with the robot frozen;
@@ -1140,15 +1145,14 @@ extern "C" int mre_get_contacts(mre_env* e, int32_t* count, float* contacts) {
 extern "C" int mre_place_props(mre_env* e, const uint8_t* mask, uint64_t seed, const float* ws_min,
                                const float* ws_max, int max_attempts, int settle_steps) {
   if (!e || !ws_min || !ws_max || max_attempts < 1) return fail(MRE_ERR_ARG, "mre_place_props: bad argument");
-  const size_t N = (size_t)e->N, row = 1 + 3 * CONTACT_EXPORT;
+  const size_t N = (size_t)e->N;
   std::vector<uint8_t> hm(N, 1);
   int rc;
   if (mask) { rc = copy_out(e, hm.data(), mask, N); if (rc) return rc; }
   std::vector<int> np(N);
-  std::vector<float> qp(N * NQP), hc(N * row);
+  std::vector<float> qp(N * NQP);
   if ((rc = copy_out(e, np.data(), e->nprops, N * 4)) || (rc = copy_out(e, qp.data(), e->qpos, qp.size() * 4)))
     return rc;
-  const double kPi = 3.14159265358979323846;
   double lo[3], hi[3];
   for (int k = 0; k < 3; k++) { lo[k] = ws_min[k]; hi[k] = ws_max[k]; }
   // props that are about to be placed start from their parking pose
@@ -1159,45 +1163,25 @@ extern "C" int mre_place_props(mre_env* e, const uint8_t* mask, uint64_t seed, c
         for (int k = 0; k < 3; k++) q[k] = e->hM.park_pos[p][k];
         q[3] = 1.f; q[4] = q[5] = q[6] = 0.f;
       }
-  std::vector<uint8_t> pending(N);
-  const int table_geom = 1;  // geom ids of the compiled scene: 0 ground plane, 1 table (checked in mre_create)
+  if ((rc = copy_in(e, e->qpos, qp.data(), qp.size() * 4)) || (rc = copy_in(e, e->mask, hm.data(), N))) return rc;
+  if ((rc = search_buffers(e))) return rc;
+  // one search launch per prop index: every env that still needs prop p runs its own attempt loop on
+  // the device (k_pose_search) and writes the accepted pose into its qpos row
+  std::vector<int> att(N);
   for (int p = 0; p < NPROP; p++) {
-    size_t npend = 0;
-    for (size_t i = 0; i < N; i++) { pending[i] = hm[i] && p < np[i]; npend += pending[i]; }
-    for (int att = 0; att < max_attempts && npend > 0; att++) {
-      for (size_t i = 0; i < N; i++) {
-        if (!pending[i]) continue;
-        const uint64_t gid = (uint64_t)(e->env_ids.empty() ? e->env_id_offset + (long long)i : e->env_ids[i]);
-        const uint64_t tick = (uint64_t)p * (uint64_t)max_attempts + (uint64_t)att;
-        double u[4];
-        for (int c = 0; c < 4; c++) u[c] = uniform01(seed, gid, tick, (uint64_t)c);
-        const double yaw = kPi * u[3];
-        float* q = &qp[i * NQP + NRV + 7 * p];
-        for (int k = 0; k < 3; k++) q[k] = (float)(lo[k] + (hi[k] - lo[k]) * u[k]);
-        q[3] = (float)std::cos(yaw / 2); q[4] = 0.f; q[5] = 0.f; q[6] = (float)std::sin(yaw / 2);
-      }
-      if ((rc = copy_in(e, e->qpos, qp.data(), qp.size() * 4)) || (rc = copy_in(e, e->mask, pending.data(), N))) return rc;
-      if ((rc = detect_contacts(e, e->mask))) return rc;
-      if ((rc = copy_out(e, hc.data(), e->contacts, hc.size() * 4))) return rc;
-      const int geom_p = e->prop_geom0 + p;
-      for (size_t i = 0; i < N; i++) {
-        if (!pending[i]) continue;
-        const float* c = &hc[i * row];
-        bool hit = c[0] < 0.f;  // cut list: cannot rule a contact out
-        const int n = (int)std::fabs(c[0]) < CONTACT_EXPORT ? (int)std::fabs(c[0]) : CONTACT_EXPORT;
-        for (int k = 0; k < n && !hit; k++) {
-          const int g1 = (int)c[1 + 3 * k], g2 = (int)c[2 + 3 * k];
-          if (g1 == table_geom || g2 == table_geom) continue;
-          if (g1 == geom_p || g2 == geom_p) hit = true;
-        }
-        if (!hit) { pending[i] = 0; npend--; }
-      }
-    }
-    if (npend > 0)
-      return fail(MRE_ERR_ARG, "mre_place_props: failed to find a non-colliding pose within max_attempts (_REJECTION_SAMPLING_FAILED)");
+    SearchArgs sa;
+    fill_search(e, sa);
+    sa.env_mask = e->mask; sa.seed = seed; sa.fixed_prop = p;
+    for (int k = 0; k < 3; k++) { sa.shared_bounds[k] = lo[k]; sa.shared_bounds[3 + k] = hi[k]; }
+    sa.tick0 = (long long)p * (long long)max_attempts;
+    sa.max_attempts = max_attempts; sa.yaw_mode = 1; sa.max_dist = INFINITY; sa.commit = 1;
+    mre_launch_pose_search(&sa, e->stream);
+    HIPCHK(hipGetLastError());
+    if ((rc = copy_out(e, att.data(), e->ps_attempts, N * 4))) return rc;
+    for (size_t i = 0; i < N; i++)
+      if (hm[i] && p < np[i] && att[i] <= 0)
+        return fail(MRE_ERR_ARG, "mre_place_props: failed to find a non-colliding pose within max_attempts (_REJECTION_SAMPLING_FAILED)");
   }
-  rc = copy_in(e, e->qpos, qp.data(), qp.size() * 4);
-  if (rc) return rc;
   HIPCHK(hipStreamSynchronize(e->stream));
   if (settle_steps > 0) {
     const uint8_t* dmask = nullptr;
@@ -1241,15 +1225,90 @@ extern "C" int mre_get_settle_steps(mre_env* e, int32_t* steps) {
   return copy_out(e, steps, e->settle_steps, (size_t)e->N * 4);
 }
 
+// ---- prop_place (tasks/rearrangement.py:597-665), batched: env i looks for a pose of cube prop[i] in
+// [bounds[i][0:3], bounds[i][3:6]] (the reference's min_pose / max_pose) with orientation Ry(180 deg),
+// rejected while a detected contact with a geom other than the table has dist <= max_dist (0.05 in the
+// reference).  Draw t of env i is keyed by (seed, global env id, tick[i] + t).  The physics state is not
+// touched (the reference works on a deepcopy).  attempts[i]: draws used, 0 = nothing asked (prop[i] < 0),
+// < 0 = no pose within max_attempts (the reference raises "Failed to find collision free place pose.").
+extern "C" int mre_prop_place(mre_env* e, uint64_t seed, const int32_t* prop, const double* bounds, const int32_t* tick,
+                              int max_attempts, float max_dist, double* pose, int32_t* attempts) {
+  if (!e || !prop || !bounds || !tick || !pose || !attempts || max_attempts < 1)
+    return fail(MRE_ERR_ARG, "mre_prop_place: bad argument");
+  HIPCHK(hipSetDevice(e->device));
+  const size_t N = (size_t)e->N;
+  int rc = search_buffers(e);
+  if (rc) return rc;
+  if ((rc = copy_in(e, e->ps_prop, prop, N * 4)) || (rc = copy_in(e, e->ps_bounds, bounds, N * 48)) ||
+      (rc = copy_in(e, e->ps_tick, tick, N * 4)))
+    return rc;
+  HIPCHK(hipMemsetAsync(e->ps_pose, 0, N * 56, e->stream));
+  SearchArgs sa;
+  fill_search(e, sa);
+  sa.seed = seed; sa.prop = e->ps_prop; sa.bounds = e->ps_bounds; sa.tick_base = e->ps_tick;
+  sa.max_attempts = max_attempts; sa.yaw_mode = 0;
+  sa.fixed_quat[0] = 0.0; sa.fixed_quat[1] = 0.0; sa.fixed_quat[2] = 1.0; sa.fixed_quat[3] = 0.0;  // mju_mat2Quat(Ry(180 deg))
+  sa.max_dist = max_dist; sa.commit = 0; sa.pose = e->ps_pose;
+  mre_launch_pose_search(&sa, e->stream);
+  HIPCHK(hipGetLastError());
+  if ((rc = copy_out(e, pose, e->ps_pose, N * 56))) return rc;
+  return copy_out(e, attempts, e->ps_attempts, N * 4);
+}
+
+// ---- sort_colours (tasks/rearrangement.py:700-751), batched and on the device: the first cube (prop
+// order) outside its colour's zone, prop_pick for it (:579-595) and prop_place inside the zone (z = 0.4).
+// zones [N][4][4]: lo x, lo y, hi x, hi y of every cube's zone; call_counts[i] * 10000 is the first tick of
+// env i's place draws (seed + 1 keys them, like the host restatement demo_logic.batched_place_pose).
+// which[i]: selected cube, -1 = every cube is in its zone (pick / place rows are then unspecified).
+extern "C" int mre_sort_colours(mre_env* e, uint64_t seed, const int32_t* call_counts, const double* zones,
+                                int max_attempts, float max_dist, int32_t* which, double* pick, double* place,
+                                int32_t* attempts) {
+  if (!e || !call_counts || !zones || !which || !pick || !place || !attempts || max_attempts < 1)
+    return fail(MRE_ERR_ARG, "mre_sort_colours: bad argument");
+  HIPCHK(hipSetDevice(e->device));
+  const size_t N = (size_t)e->N;
+  int rc = search_buffers(e);
+  if (rc) return rc;
+  std::vector<int32_t> ticks(N);
+  if ((rc = copy_out(e, ticks.data(), call_counts, N * 4))) return rc;
+  for (size_t i = 0; i < N; i++) ticks[i] *= 10000;   // MAX_PLACE_ATTEMPTS draws reserved per call
+  if ((rc = copy_in(e, e->ps_tick, ticks.data(), N * 4)) || (rc = copy_in(e, e->ps_zones, zones, N * NPROP * 32))) return rc;
+  SortArgs so;
+  so.M = e->dM; so.N = e->N; so.qpos = e->qpos; so.nprops = e->nprops; so.zones = e->ps_zones; so.place_z = 0.4;
+  so.which = e->ps_which; so.pick = e->ps_pick; so.bounds = e->ps_bounds;
+  mre_launch_sort_select(&so, e->stream);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemsetAsync(e->ps_pose, 0, N * 56, e->stream));
+  SearchArgs sa;
+  fill_search(e, sa);
+  sa.seed = seed + 1; sa.prop = e->ps_which; sa.bounds = e->ps_bounds; sa.tick_base = e->ps_tick;
+  sa.max_attempts = max_attempts; sa.yaw_mode = 0;
+  sa.fixed_quat[2] = 1.0;
+  sa.max_dist = max_dist; sa.commit = 0; sa.pose = e->ps_pose;
+  mre_launch_pose_search(&sa, e->stream);
+  HIPCHK(hipGetLastError());
+  if ((rc = copy_out(e, which, e->ps_which, N * 4)) || (rc = copy_out(e, pick, e->ps_pick, N * 56)) ||
+      (rc = copy_out(e, place, e->ps_pose, N * 56)))
+    return rc;
+  return copy_out(e, attempts, e->ps_attempts, N * 4);
+}
+
 extern "C" int mre_set_env_ids(mre_env* e, const long long* ids) {
   if (!e) return fail(MRE_ERR_ARG, "null handle");
   if (ids) e->env_ids.assign(ids, ids + e->N); else e->env_ids.clear();
+  if (e->d_env_ids) { HIPCHK(hipFree(e->d_env_ids)); e->d_env_ids = nullptr; }
+  if (ids) {
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipMalloc(&e->d_env_ids, (size_t)e->N * 8));
+    return copy_in(e, e->d_env_ids, e->env_ids.data(), (size_t)e->N * 8);
+  }
   return MRE_OK;
 }
 
 extern "C" int mre_set_env_id_offset(mre_env* e, long long offset) {
   if (!e) return fail(MRE_ERR_ARG, "null handle");
   e->env_ids.clear();
+  if (e->d_env_ids) { (void)hipFree(e->d_env_ids); e->d_env_ids = nullptr; }
   e->env_id_offset = offset;
   return MRE_OK;
 }

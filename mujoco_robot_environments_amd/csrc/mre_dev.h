@@ -174,6 +174,50 @@ struct StepArgs {
                              //  over the launch's steps
 };
 
+// Rejection sampling of a cube pose (k_pose_search): PropPlacer.__call__'s per-prop loop
+// (environment/prop_initializer.py:164-232) and prop_place (tasks/rearrangement.py:597-665).  One wave
+// per env; attempt t draws u = U01(seed, global env id, tick_base + t, channel 0..3), the pose
+// lo + (hi - lo) u[0:3] (fp64, rounded to fp32 for the test), moves the cube there IN LDS ONLY, runs the
+// narrow phase of every pair of the cube with a geom other than the table, and rejects the pose while a
+// detected contact (dist < margin) has dist <= max_dist.
+struct SearchArgs {
+  const DevModel* M;
+  int N;
+  float* qpos;               // [N][NQP]; written only when commit != 0
+  const int* nprops;         // [N]
+  const float* prop_size;    // [N][NPROP][3]
+  const uint8_t* env_mask;   // [N] or null
+  const long long* env_ids;  // [N] global env ids or null (then env_id_offset + env)
+  long long env_id_offset;
+  unsigned long long seed;
+  const int* prop;           // [N] cube index to move (< 0: nothing to do for this env) or null
+  int fixed_prop;            //   (prop == null: this cube in every env that has it)
+  const double* bounds;      // [N][6] lo xyz, hi xyz or null
+  double shared_bounds[6];   //   (bounds == null)
+  const int* tick_base;      // [N] or null
+  long long tick0;           //   (tick_base == null)
+  int max_attempts;
+  int yaw_mode;              // 1: quat = (cos(pi u3 / 2), 0, 0, sin(pi u3 / 2)); 0: quat = fixed_quat
+  double fixed_quat[4];
+  float max_dist;            // +inf: any detected contact rejects (PropPlacer); 0.05: prop_place
+  int commit;                // 1: the accepted pose is written to qpos (PropPlacer); 0: state untouched
+  double* pose;              // [N][7] accepted pose (xyz fp64, quat) or null
+  int* attempts;             // [N]: attempts used (>= 1); -max_attempts: none accepted; 0: env skipped
+};
+
+// sort_colours' selection + prop_pick (k_sort_select; tasks/rearrangement.py:700-751, :579-595), one thread per env
+struct SortArgs {
+  const DevModel* M;
+  int N;
+  const float* qpos;         // [N][NQP]
+  const int* nprops;         // [N]
+  const double* zones;       // [N][NPROP][4]: lo x, lo y, hi x, hi y of the cube's colour zone
+  double place_z;            // get_location_bounds' hard-coded 0.4
+  int* which;                // [N] out: first cube outside its zone, -1: none
+  double* pick;              // [N][7] out: cube position + grasp quaternion
+  double* bounds;            // [N][6] out: place bounds of the selected cube (for k_pose_search)
+};
+
 // Camera + shading parameters of mre_render (csrc/mre_render.hip)
 struct RenderArgs {
   int N, height, width;

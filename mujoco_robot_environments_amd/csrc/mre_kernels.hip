@@ -1151,6 +1151,172 @@ __global__ __launch_bounds__(64) void k_reset(const DevModel* M, int N, float* q
   if (l == 0) status[env] = 0u;
 }
 
+// ---- demonstration logic around the step and the PropPlacer's rejection loop
+// counter RNG of rng.py / mre_api.cpp (splitmix64 finaliser keyed by seed, global env id, tick, channel)
+MRE_DEV unsigned long long mix64(unsigned long long x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+MRE_DEV double uniform01(unsigned long long seed, unsigned long long env, unsigned long long tick, unsigned long long ch) {
+  unsigned long long k = mix64(seed + 0x9E3779B97F4A7C15ull * env);
+  k = mix64(k ^ (tick * 0xBF58476D1CE4E5B9ull));
+  k = mix64(k ^ (ch * 0x94D049BB133111EBull));
+  return (double)(k >> 11) * (1.0 / 9007199254740992.0);
+}
+
+// Rejection sampling of one cube's pose per env (SearchArgs, mre_dev.h): the inner loops of
+// PropPlacer.__call__ (environment/prop_initializer.py:198-232) and of prop_place
+// (tasks/rearrangement.py:628-663).  The reference moves the prop in a copy of the physics and calls
+// physics.forward(); here the candidate pose lives in the wave's LDS copy of the body frames and only the
+// cube's own pairs (<= 19 of the static table, table pairs dropped: both callers ignore them) go through
+// the narrow phase, one lane per pair.
+__global__ __launch_bounds__(64) void k_pose_search(SearchArgs a) {
+  __shared__ Sm s;
+  const int env = blockIdx.x, l = threadIdx.x;
+  if (env >= a.N) return;
+  if (a.env_mask != nullptr && a.env_mask[env] == 0) return;
+  const DevModel* M = a.M;
+  const int np = a.nprops[env];
+  const int p = a.prop != nullptr ? a.prop[env] : a.fixed_prop;
+  if (p < 0 || p >= np || p >= NPROP) {
+    if (l == 0 && a.attempts != nullptr) a.attempts[env] = 0;
+    return;
+  }
+  if (l < NQP) s.qpos[l] = a.qpos[(size_t)env * NQP + l];
+  if (l == 0) s.nprops = np;
+  if (l < NPROP * 3) s.prop_size[l / 3][l % 3] = a.prop_size[(size_t)env * NPROP * 3 + l];
+  __syncthreads();
+  kinematics_only(M, s, l);
+  // the cube's pairs, in table order
+  const int gp = PROP_GEOM0 + p, table = 1, body = NRB + p;
+  int cnt = 0;
+  for (int pass = 0; pass < NPAIR / 64; pass++) {
+    const int pr = l + 64 * pass;
+    const int g1 = M->pair_g1[pr], g2 = M->pair_g2[pr];
+    bool mine = g1 >= 0 && (g1 == gp || g2 == gp) && g1 != table && g2 != table;
+    if (mine) mine = body_is_active(M, s, M->geom_body[g1]) && body_is_active(M, s, M->geom_body[g2]);
+    const unsigned long long b = __ballot(mine);
+    if (mine) s.iscr[cnt + __popcll(b & ((1ull << l) - 1ull))] = pr;
+    cnt += __popcll(b);
+  }
+  __syncthreads();
+  const int pr = l < cnt ? s.iscr[l] : -1;
+  __syncthreads();
+  float* buf = &s.JpA[0][0] + l * COLL_BUF;   // this lane's clip buffer (as in collide)
+  const unsigned long long gid = (unsigned long long)(a.env_ids != nullptr ? a.env_ids[env] : a.env_id_offset + env);
+  const unsigned long long tick0 = (unsigned long long)(a.tick_base != nullptr ? (long long)a.tick_base[env] : a.tick0);
+  const double* bd = a.bounds != nullptr ? a.bounds + (size_t)env * 6 : a.shared_bounds;
+  double pose[7];
+  int used = -a.max_attempts;
+  for (int att = 0; att < a.max_attempts; att++) {
+    for (int k = 0; k < 3; k++) pose[k] = bd[k] + (bd[3 + k] - bd[k]) * uniform01(a.seed, gid, tick0 + att, k);
+    if (a.yaw_mode) {
+      const double yaw = 3.14159265358979323846 * uniform01(a.seed, gid, tick0 + att, 3);
+      pose[3] = cos(yaw / 2); pose[4] = 0.0; pose[5] = 0.0; pose[6] = sin(yaw / 2);
+    } else {
+      for (int k = 0; k < 4; k++) pose[3 + k] = a.fixed_quat[k];
+    }
+    if (l == 0) {   // physics.forward() of the moved cube: a free body's frame is its qpos
+      float xq[4] = {(float)pose[3], (float)pose[4], (float)pose[5], (float)pose[6]};
+      qnormalize(xq);
+      for (int k = 0; k < 3; k++) s.xpos[body][k] = (float)pose[k];
+      for (int k = 0; k < 4; k++) s.xquat[body][k] = xq[k];
+      q2mat(s.xmat[body], xq);
+    }
+    __syncthreads();
+    bool hit = false;
+    if (pr >= 0) {
+      const int g1 = M->pair_g1[pr], g2 = M->pair_g2[pr];
+      float p1[3], R1[9], s1[3], rb1, p2[3], R2[9], s2[3], rb2, normal[3] = {0.f, 0.f, 1.f}, df[3];
+      geom_pose(M, s, g1, p1, R1, s1, &rb1);
+      geom_pose(M, s, g2, p2, R2, s2, &rb2);
+      const float inc = M->pair_margin[pr];
+      int n = 0;
+      v3sub(df, p2, p1);
+      if (M->geom_type[g1] == 0) {
+        float nn[3] = {R1[2], R1[5], R1[8]};
+        if (v3dot(df, nn) - rb2 <= inc) n = plane_box(p1, R1, p2, R2, s2, inc, normal, buf);
+      } else {
+        const float r = rb1 + rb2 + inc;
+        if (v3dot(df, df) <= r * r) n = box_box(p1, R1, s1, p2, R2, s2, inc, normal, buf);
+      }
+      for (int c = 0; c < n; c++) {
+        const float d = cand_dist(buf, c);
+        if (d < inc && d <= a.max_dist) hit = true;   // a detected contact (dist < margin) close enough to reject
+      }
+    }
+    const bool any = __ballot(hit) != 0ull;
+    __syncthreads();
+    if (!any) { used = att + 1; break; }
+  }
+  if (l == 0) {
+    if (a.attempts != nullptr) a.attempts[env] = used;
+    if (used > 0) {
+      if (a.pose != nullptr) for (int k = 0; k < 7; k++) a.pose[(size_t)env * 7 + k] = pose[k];
+      if (a.commit) {
+        float* q = a.qpos + (size_t)env * NQP + NRV + 7 * p;
+        for (int k = 0; k < 7; k++) q[k] = (float)pose[k];
+      }
+    }
+  }
+}
+
+// mju_mat2Quat on a row-major matrix, fp64, normalised (model/compile.py: m2q)
+MRE_DEV void mat2quat_d(const double* m, double* q) {
+  const double t = m[0] + m[4] + m[8];
+  if (t > 0) {
+    const double w = sqrt(t + 1.0) * 2;
+    q[0] = 0.25 * w; q[1] = (m[7] - m[5]) / w; q[2] = (m[2] - m[6]) / w; q[3] = (m[3] - m[1]) / w;
+  } else if (m[0] > m[4] && m[0] > m[8]) {
+    const double w = sqrt(1.0 + m[0] - m[4] - m[8]) * 2;
+    q[0] = (m[7] - m[5]) / w; q[1] = 0.25 * w; q[2] = (m[1] + m[3]) / w; q[3] = (m[2] + m[6]) / w;
+  } else if (m[4] > m[8]) {
+    const double w = sqrt(1.0 + m[4] - m[0] - m[8]) * 2;
+    q[0] = (m[2] - m[6]) / w; q[1] = (m[1] + m[3]) / w; q[2] = 0.25 * w; q[3] = (m[5] + m[7]) / w;
+  } else {
+    const double w = sqrt(1.0 + m[8] - m[0] - m[4]) * 2;
+    q[0] = (m[3] - m[1]) / w; q[1] = (m[2] + m[6]) / w; q[2] = (m[5] + m[7]) / w; q[3] = 0.25 * w;
+  }
+  const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  for (int k = 0; k < 4; k++) q[k] /= n;
+}
+
+// sort_colours' scan for the first cube outside its colour zone (tasks/rearrangement.py:727-749) and
+// prop_pick for it (:579-595): position = the cube's, yaw folded by min(|yaw|, |yaw| - 90),
+// grasp = mju_mat2Quat(Rz(yaw) Ry(180 deg)).  One thread per env, fp64 like the reference's numpy.
+__global__ __launch_bounds__(64) void k_sort_select(SortArgs a) {
+  const int env = blockIdx.x * 64 + threadIdx.x;
+  if (env >= a.N) return;
+  const float* q = a.qpos + (size_t)env * NQP + NRV;
+  const int np = a.nprops[env];
+  int which = -1;
+  for (int p = 0; p < NPROP && p < np; p++) {
+    const double* z = a.zones + ((size_t)env * NPROP + p) * 4;
+    const double x = q[7 * p], y = q[7 * p + 1];
+    if (!(z[0] <= x && x <= z[2] && z[1] <= y && y <= z[3])) { which = p; break; }
+  }
+  a.which[env] = which;
+  const int p = which < 0 ? 0 : which;
+  const float* c = q + 7 * p;
+  double w = c[3], x = c[4], y = c[5], z = c[6];
+  const double n = sqrt(w * w + x * x + y * y + z * z);
+  w /= n; x /= n; y /= n; z /= n;
+  const double r10 = 2 * (x * y + w * z), r00 = w * w + x * x - y * y - z * z;
+  const double yaw = fabs(atan2(r10, r00) * (180.0 / 3.14159265358979323846));
+  const double rz = (yaw < yaw - 90.0 ? yaw : yaw - 90.0) * (3.14159265358979323846 / 180.0);
+  const double cs = cos(rz), sn = sin(rz);
+  // Rz(rz) * diag(-1, 1, -1)
+  const double m[9] = {-cs, -sn, 0.0, -sn, cs, 0.0, 0.0, 0.0, -1.0};
+  double* o = a.pick + (size_t)env * 7;
+  for (int k = 0; k < 3; k++) o[k] = c[k];
+  mat2quat_d(m, o + 3);
+  const double* zb = a.zones + ((size_t)env * NPROP + p) * 4;
+  double* b = a.bounds + (size_t)env * 6;
+  b[0] = zb[0]; b[1] = zb[1]; b[2] = a.place_z; b[3] = zb[2]; b[4] = zb[3]; b[5] = a.place_z;
+}
+
 // ---- capacity fallback helpers (mre_api.cpp: launch_step)
 // one pass before a guarded launch (one workgroup per env): copy the env's state rows aside, mark its
 // launch info "not part of this launch", and split the launch between the two kernels -- envs flagged
@@ -1214,6 +1380,14 @@ extern "C" void mre_launch_restore_rows(const uint8_t* sel, int N, float* qpos, 
                                         uint8_t* converged, const uint8_t* sv_converged, hipStream_t stream) {
   hipLaunchKernelGGL(mre::k_restore_rows, dim3(N), dim3(64), 0, stream, sel, N, qpos, sv_qpos, qvel, sv_qvel,
                      qacc_ws, sv_qacc_ws, ctrl, sv_ctrl, status, sv_status, converged, sv_converged);
+}
+
+extern "C" void mre_launch_pose_search(const mre::SearchArgs* args, hipStream_t stream) {
+  hipLaunchKernelGGL(mre::k_pose_search, dim3(args->N), dim3(64), 0, stream, *args);
+}
+
+extern "C" void mre_launch_sort_select(const mre::SortArgs* args, hipStream_t stream) {
+  hipLaunchKernelGGL(mre::k_sort_select, dim3((args->N + 63) / 64), dim3(64), 0, stream, *args);
 }
 
 extern "C" void mre_launch_reset(const mre::DevModel* M, int N, float* qpos, float* qvel, float* qacc_ws,

@@ -285,6 +285,37 @@ class BatchedPhysics:
         check(_lib.lib().mre_get_contacts(self._h, _ptr(cnt), _ptr(con)), "mre_get_contacts")
         return cnt, con
 
+    def prop_place(self, seed: int, prop, bounds, tick, max_attempts: int = 10000, max_dist: float = 0.05):
+        """prop_place (tasks/rearrangement.py:597-665) for every env on the device (mre_prop_place):
+        prop [N] cube index (< 0: skip), bounds [N, 6] lo / hi, tick [N] first RNG tick ->
+        (pose [N, 7] fp64, attempts [N])."""
+        n = self.num_envs
+        pr = np.ascontiguousarray(prop, np.int32)
+        bd = np.ascontiguousarray(bounds, np.float64)
+        tk = np.ascontiguousarray(tick, np.int32)
+        assert pr.shape == (n,) and bd.shape == (n, 6) and tk.shape == (n,)
+        pose = np.empty((n, 7), np.float64)
+        att = np.empty(n, np.int32)
+        check(_lib.lib().mre_prop_place(self._h, int(seed), _ptr(pr), _ptr(bd), _ptr(tk), int(max_attempts),
+                                        float(max_dist), _ptr(pose), _ptr(att)), "mre_prop_place")
+        return pose, att
+
+    def sort_colours(self, seed: int, call_counts, zones, max_attempts: int = 10000, max_dist: float = 0.05):
+        """sort_colours (tasks/rearrangement.py:700-751) for every env on the device (mre_sort_colours):
+        zones [N, 4, 4] = lo x, lo y, hi x, hi y of every cube's colour zone ->
+        (which [N], pick [N, 7], place [N, 7], attempts [N])."""
+        n = self.num_envs
+        cc = np.ascontiguousarray(call_counts, np.int32)
+        zn = np.ascontiguousarray(zones, np.float64)
+        assert cc.shape == (n,) and zn.shape == (n, 4, 4)
+        which = np.empty(n, np.int32)
+        pick = np.empty((n, 7), np.float64)
+        place = np.empty((n, 7), np.float64)
+        att = np.empty(n, np.int32)
+        check(_lib.lib().mre_sort_colours(self._h, int(seed), _ptr(cc), _ptr(zn), int(max_attempts), float(max_dist),
+                                          _ptr(which), _ptr(pick), _ptr(place), _ptr(att)), "mre_sort_colours")
+        return which, pick, place, att
+
     def settle_steps(self) -> np.ndarray:
         """Physics steps every env took in the last place_props() settle (negative: not settled in 2 s)."""
         st = np.empty(self.num_envs, np.int32)

@@ -143,6 +143,7 @@ class BatchedRearrangementEnv:
         self._reset_count = 0
         self._place_count = 0
         self._place_counts = np.zeros(self.num_envs, np.int64)  # prop_place calls per env (RNG key)
+        self._zones = None  # [N, 4, 4] colour zone of every cube (set when the colours are drawn)
         self._robot: Optional[RobotArm] = None
         self.mode = None
         self.eef_home_pose = None
@@ -397,25 +398,22 @@ class BatchedRearrangementEnv:
         return np.concatenate([obj_pose, grasp])
 
     def prop_place_env(self, i: int, prop_id: int, min_pose=None, max_pose=None, info: Optional[dict] = None):
-        """Collision-free place pose (tasks/rearrangement.py:597-665): uniform samples in the
-        bounds, rejected while any other cube is closer than 0.05 m (contact.dist <= 0.05)."""
-        info = info or self.props_info_env(i)
+        """Collision-free place pose (tasks/rearrangement.py:597-665): uniform samples in the bounds,
+        the cube moved there and physics.forward() evaluated on the device (mre_prop_place), rejected
+        while a contact with a geom other than the table has dist <= 0.05."""
         ws = self._cfg.task.initializers.workspace
         lo = np.asarray(ws.min_pose if min_pose is None else min_pose, np.float64)
         hi = np.asarray(ws.max_pose if max_pose is None else max_pose, np.float64)
-        p = prop_id - PROP_GEOM_ID0
-        pos = np.zeros((1, 4, 3))
-        for pid, a in info.items():
-            pos[0, pid - PROP_GEOM_ID0] = a["position"]
-        lo4 = np.tile(lo, (1, 4, 1))
-        hi4 = np.tile(hi, (1, 4, 1))
-        pose, ok = demo_logic.batched_place_pose(self.seed, self.env_ids[i:i + 1], self._place_counts[i:i + 1], pos,
-                                                 self.nprops[i:i + 1], self.prop_half_size[i:i + 1],
-                                                 np.array([p]), lo4, hi4, np.array([True]))
-        if not ok[0]:
+        prop = np.full(self.num_envs, -1, np.int32)
+        prop[i] = prop_id - PROP_GEOM_ID0
+        bounds = np.zeros((self.num_envs, 6))
+        bounds[i, :3], bounds[i, 3:] = lo, hi
+        pose, att = self._physics.prop_place(self.seed + 1, prop, bounds, self._place_counts * demo_logic.MAX_PLACE_ATTEMPTS,
+                                             demo_logic.MAX_PLACE_ATTEMPTS, demo_logic.PLACE_CLEARANCE)
+        if att[i] <= 0:
             raise Exception("Failed to find collision free place pose.")
         self._place_counts[i] += 1
-        return pose[0]
+        return pose[i]
 
     def sort_colours_env(self, i: int, info: Optional[dict] = None):
         """tasks/rearrangement.py:700-751 for env i."""
@@ -431,13 +429,17 @@ class BatchedRearrangementEnv:
         return False, None, None
 
     def sort_colours(self):
-        """Batched sort_colours (demo_logic.batched_sort_colours): (in_progress[N], pick_pose[N,7],
-        place_pose[N,7]); envs with nothing left to do (or whose place sampling failed, recorded in
-        ``failed_phase``) get their home pose as a no-op target."""
-        poses = self._physics.sites()[2]
-        prog, pick, place, failed, _ = demo_logic.batched_sort_colours(
-            self._cfg.task, self.seed, self.env_ids, self._place_counts, poses, self.nprops,
-            self.prop_half_size, self.prop_colours)
+        """Batched sort_colours on the device (mre_sort_colours: selection, prop_pick and the
+        prop_place rejection loop of tasks/rearrangement.py:700-751 run per env in one launch pair):
+        (in_progress[N], pick_pose[N,7], place_pose[N,7]); envs with nothing left to do (or whose place
+        sampling failed, recorded in ``failed_phase``) get their home pose as a no-op target."""
+        if self._zones is None:
+            lo, hi = demo_logic.target_bounds(self._cfg.task, self.prop_colours, 4)
+            self._zones = np.concatenate([lo[..., :2], hi[..., :2]], axis=2)
+        which, pick, place, att = self._physics.sort_colours(self.seed, self._place_counts, self._zones,
+                                                             demo_logic.MAX_PLACE_ATTEMPTS, demo_logic.PLACE_CLEARANCE)
+        prog = (which >= 0) & (att > 0)
+        failed = (which >= 0) & (att < 0)
         self._place_counts[prog] += 1
         self.failed_phase[failed] = "Failed to find collision free place pose."
         idle = ~prog
