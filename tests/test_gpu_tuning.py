@@ -29,9 +29,10 @@ def test_tuner_fitness_is_a_function_of_the_gains_only():
     assert (~t.last["converged"][4]).all()
     # the penalty dominates any converged candidate's millimetre-scale reward
     assert f[1] < t.FAIL
-    # a second evaluation of the same population reproduces the first (reset() is deterministic)
+    # a second evaluation draws new scenes (reset() advances the episode counter, like the reference's
+    # env.reset() per candidate) -- again the same ones for every candidate
     f2 = t.evaluate(g)
-    assert np.array_equal(f, f2)
+    assert f2[0] == f2[2] == f2[6] and f2[1] == f2[3] == f2[5] and not np.array_equal(f, f2)
     # one generation of the reference's loop: ask -> evaluate(|x|) -> tell
     es = CMAES(np.array(TUNED), 20.0, pop, seed=0)
     x = es.ask()
