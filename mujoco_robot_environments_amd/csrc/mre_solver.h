@@ -748,28 +748,48 @@ MRE_PHASE_FN void solve_constraints(const DevModel* M, Sm& s, int l) {
   const unsigned broff = (unsigned)(reinterpret_cast<const char*>(&s.Br[0][0]) - reinterpret_cast<const char*>(&s.Jr[0][0]));
   const float* const frc = s.frc;
   int iters = 0;
-  for (int iter = 0; iter < max_iter; iter++) {
-    float impr = 0.f;
-    for (int st = 0; st < nsched; st++) {
-      const uint2 ent = *reinterpret_cast<const uint2*>(sb + tbase + tstep * (unsigned)st);
+  // The operands of a step that no step writes (schedule entry, Jacobian / M^-1 J' rows, block record)
+  // are fetched one step ahead, so that their two dependent LDS round trips overlap the block update
+  // of the current step instead of stalling the next one (2 waves per SIMD hide little by themselves).
+  struct StepOps { uint2 ent; float j0, j1r, j2r, b0r, b1r, b2r; float4 q0, q1, q2, q3; };
+  auto fetch_ent = [&](int st) { return *reinterpret_cast<const uint2*>(sb + tbase + tstep * (unsigned)st); };
+  auto fetch_rows = [&](uint2 ent) {
+    StepOps o;
+    o.ent = ent;
+    // three rows through the lane's offset / stride (rows past the block may hold stale non-finite
+    // LDS contents: select, never multiply by zero)
+    const char* jp = sb + ((ent.x & 0xFFFFu) + loff);
+    o.j0 = *reinterpret_cast<const float*>(jp);
+    o.j1r = *reinterpret_cast<const float*>(jp + lstr);
+    o.j2r = *reinterpret_cast<const float*>(jp + 2u * lstr);
+    o.b0r = *reinterpret_cast<const float*>(jp + broff);
+    o.b1r = *reinterpret_cast<const float*>(jp + lstr + broff);
+    o.b2r = *reinterpret_cast<const float*>(jp + 2u * lstr + broff);
+    // the block's uniform operands: one 64-byte record, four 16-byte LDS reads
+    const float4* rec = reinterpret_cast<const float4*>(sb + (ent.x >> 16));
+    o.q0 = rec[0]; o.q1 = rec[1]; o.q2 = rec[2]; o.q3 = rec[3];
+    return o;
+  };
+  int st = 0, iter = 0;
+  float impr = 0.f;
+  uint2 ent1 = fetch_ent(nsched > 1 ? 1 : 0);   // schedule entry of the step after the next fetch
+  // one schedule step on the operands `cur`; the operands of the following step go to `nxt`.  The
+  // loop below calls it with two operand sets in turn (no register shuffling between steps).
+  // Returns true when the solve is over.
+  auto step = [&](const StepOps& cur, StepOps& nxt) -> bool {
+      const int st1 = st + 1 < nsched ? st + 1 : 0;
+      const int st2 = st1 + 1 < nsched ? st1 + 1 : 0;
+      nxt = fetch_rows(ent1);
+      ent1 = fetch_ent(st2);
+      const uint2 ent = cur.ent;
       const unsigned w1 = ent.y;
       const bool on = (w1 & 0x400u) != 0u, is3 = (w1 & 0x800u) != 0u;
       const int row0 = (int)(w1 & 0xFFu), nr = (int)((w1 >> 8) & 3u);
       const bool h1 = nr > 1, h2 = nr > 2;
-      // operands: three rows through the lane's offset / stride (rows past the block may hold
-      // stale non-finite LDS contents: select, never multiply by zero)
-      const char* jp = sb + ((ent.x & 0xFFFFu) + loff);
-      const float j0 = *reinterpret_cast<const float*>(jp);
-      const float j1r = *reinterpret_cast<const float*>(jp + lstr);
-      const float j2r = *reinterpret_cast<const float*>(jp + 2u * lstr);
-      const float b0r = *reinterpret_cast<const float*>(jp + broff);
-      const float b1r = *reinterpret_cast<const float*>(jp + lstr + broff);
-      const float b2r = *reinterpret_cast<const float*>(jp + 2u * lstr + broff);
+      const float j0 = cur.j0, j1r = cur.j1r, j2r = cur.j2r, b0r = cur.b0r, b1r = cur.b1r, b2r = cur.b2r;
       const float j1 = h1 ? j1r : 0.f, j2 = h2 ? j2r : 0.f;
       const float b1 = h1 ? b1r : 0.f, b2 = h2 ? b2r : 0.f;
-      // the block's uniform operands: one 64-byte record, four 16-byte LDS reads
-      const float4* rec = reinterpret_cast<const float4*>(sb + (ent.x >> 16));
-      const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
+      const float4 q0 = cur.q0, q1 = cur.q1, q2 = cur.q2, q3 = cur.q3;
       const float4 r0 = make_float4(q0.x, q0.w, 0.f, q1.z);
       const float4 r1 = make_float4(q0.y, q1.x, 0.f, q1.w);
       const float4 r2 = make_float4(q0.z, q1.y, 0.f, q2.x);
@@ -866,10 +886,22 @@ MRE_PHASE_FN void solve_constraints(const DevModel* M, Sm& s, int l) {
       a += rob_lane ? (on ? au : 0.f) : linvM * wu;
       w += wu;
       __syncthreads();
+      st = st1;
+      if (st1 != 0) return false;
+      // end of a sweep
+      iters = ++iter;
+      const float improvement = wave_sum(leader ? impr : 0.f);
+      impr = 0.f;
+      return improvement * scale < tol || iter >= max_iter;
+  };
+  if (max_iter > 0 && nsched > 0) {
+    StepOps opsA = fetch_rows(fetch_ent(0)), opsB;
+    for (;;) {
+      if (step(opsA, opsB)) break;
+      if (step(opsB, opsA)) break;
     }
-    iters = iter + 1;
-    const float improvement = wave_sum(leader ? impr : 0.f);
-    if (improvement * scale < tol) break;
+  } else if (max_iter > 0) {
+    iters = 1;
   }
   if (l < NVP) { s.qacc[l] = (l < NV) ? s.qacc_smooth[l] : 0.f; s.qfrc_con[l] = 0.f; }
   __syncthreads();
