@@ -74,8 +74,16 @@ def valu_issue(avg_launch_s, solver="PGS"):
     if not n or avg_launch_s <= 0:
         return None
     simds, clock = 256 * 4, 2.4e9  # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, 2.4 GHz peak engine clock
-    return {"valu_insts_per_launch": n, "cycles_per_wave64_inst": 4, "simds": simds, "clock_hz": clock,
-            "util": n * 4.0 / (simds * clock * avg_launch_s), "source": name}
+    out = {"valu_insts_per_launch": n, "cycles_per_wave64_inst": 4, "simds": simds, "clock_hz": clock,
+           "util": n * 4.0 / (simds * clock * avg_launch_s), "source": name}
+    fl = d.get("counted_flop_f32_per_launch")
+    if fl:
+        # counted FLOPs (SQ_INSTS_VALU_{ADD,MUL,TRANS,FMA}_F32 x 64 lanes, FMA = 2) against the FP32 vector peak
+        # of MI355X_MICROARCH.md (157.3 TFLOP/s); idle lanes of a wave count as work, so this is an upper bound
+        out["counted_flop"] = {"f32_per_launch": fl, "f64_per_launch": d.get("counted_flop_f64_per_launch"),
+                               "tflops": fl / avg_launch_s / 1e12, "peak_tflops": 157.3,
+                               "frac": fl / avg_launch_s / 1e12 / 157.3}
+    return out
 
 
 def setup_envs(phys, seed, env_ids, settle_steps=300):

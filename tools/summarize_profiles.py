@@ -1,9 +1,10 @@
 """Copy one round's rocprofv3 outputs from gpurun_out/ (scratch) into profiles/ (tracked).
 
-usage: python tools/summarize_profiles.py TAG STATS_DIR FETCH_DIR WRITE_DIR SQ_DIR [BUILD NOTE]
+usage: python tools/summarize_profiles.py TAG SOLVER STATS_DIR FETCH_DIR WRITE_DIR SQ_DIR FLOP_DIR [BUILD NOTE]
+  SOLVER    : PGS (kernel mre::k_step, files TAG_*) or Newton (mre::k_step_newton, files TAG_*_newton)
   STATS_DIR : rocprofv3 --kernel-trace --stats --output-format csv -d STATS_DIR -- python bench.py ...
-  FETCH_DIR / WRITE_DIR / SQ_DIR : the three separate --pmc passes (never combined with traces
-  other than --kernel-trace).
+  FETCH_DIR / WRITE_DIR / SQ_DIR / FLOP_DIR : the separate --pmc passes (never combined with traces
+  other than --kernel-trace); FLOP_DIR (SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F32/F64) may be "-".
 Writes profiles/TAG_kernel_stats.csv, TAG_pmc_{fetch,write,sq}.csv (k_step rows only) and
 TAG_pmc_summary.json (per-launch means; FETCH_SIZE / WRITE_SIZE are KiB on gfx950).
 """
@@ -16,7 +17,8 @@ import sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL = "mre::k_step"
+KERNELS = {"PGS": "mre::k_step(", "Newton": "mre::k_step_newton("}
+KERNEL = KERNELS["PGS"]
 
 
 def one(pattern):
@@ -34,17 +36,27 @@ def counter_rows(d):
 
 
 def main():
-    tag, stats_d, fetch_d, write_d, sq_d = sys.argv[1:6]
-    note = sys.argv[6] if len(sys.argv) > 6 else ""
+    global KERNEL
+    tag, solver, stats_d, fetch_d, write_d, sq_d, flop_d = sys.argv[1:8]
+    note = sys.argv[8] if len(sys.argv) > 8 else ""
+    KERNEL = KERNELS[solver]
+    sfx = "" if solver == "PGS" else "_newton"
     out = os.path.join(ROOT, "profiles")
-    shutil.copy(one(os.path.join(stats_d, "**", "*kernel_stats.csv")), os.path.join(out, f"{tag}_kernel_stats.csv"))
+    shutil.copy(one(os.path.join(stats_d, "**", "*kernel_stats.csv")), os.path.join(out, f"{tag}_kernel_stats{sfx}.csv"))
     summary = {
-        "command": "rocprofv3 --pmc <COUNTERS> --kernel-trace --output-format csv -- python bench.py --steps 10 "
-                   "--warmup 2 --no-cpu-baseline (three separate passes: FETCH_SIZE | WRITE_SIZE | SQ_*)",
-        "kernel": KERNEL, "launch": "1 control tick = 5 physics steps x 4096 envs", "build": note}
-    for name, d in (("fetch", fetch_d), ("write", write_d), ("sq", sq_d)):
+        "command": f"rocprofv3 --pmc <COUNTERS> --kernel-trace --output-format csv -- python bench.py --solver {solver} "
+                   "--steps 10 --warmup 2 --no-cpu-baseline (separate passes: FETCH_SIZE | WRITE_SIZE | SQ_* | "
+                   "SQ_INSTS_VALU_*_F32/F64)",
+        "kernel": KERNEL.rstrip("("), "launch": "1 control tick = 5 physics steps x 4096 envs", "build": note}
+    passes = [("fetch", fetch_d), ("write", write_d), ("sq", sq_d)]
+    if flop_d != "-":
+        passes.append(("flop", flop_d))
+    for name, d in passes:
         path, rows = counter_rows(d)
-        with open(os.path.join(out, f"{tag}_pmc_{name}.csv"), "w", newline="") as f:
+        if not rows:
+            print(f"no rows of {KERNEL} in {path}")
+            continue
+        with open(os.path.join(out, f"{tag}_pmc_{name}{sfx}.csv"), "w", newline="") as f:
             w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
             w.writeheader()
             w.writerows(rows)
@@ -60,10 +72,16 @@ def main():
     summary["hbm_read_bytes_per_launch"] = summary["FETCH_SIZE_per_launch"] * 1024.0
     summary["hbm_write_bytes_per_launch"] = summary["WRITE_SIZE_per_launch"] * 1024.0
     summary["traffic_bytes_per_launch"] = summary["hbm_read_bytes_per_launch"] + summary["hbm_write_bytes_per_launch"]
+    g = lambda k: summary.get(f"SQ_INSTS_VALU_{k}_per_launch", 0.0)
+    if "SQ_INSTS_VALU_FMA_F32_per_launch" in summary:
+        # counted FLOPs: every counted wave instruction at its full 64 lanes (exec masks are not
+        # visible to the counter), FMA = 2
+        summary["counted_flop_f32_per_launch"] = 64.0 * (g("ADD_F32") + g("MUL_F32") + g("TRANS_F32") + 2.0 * g("FMA_F32"))
+        summary["counted_flop_f64_per_launch"] = 64.0 * (g("ADD_F64") + g("MUL_F64") + 2.0 * g("FMA_F64"))
     summary["note"] = ("FETCH_SIZE/WRITE_SIZE are in KiB. The gfx950 x2 FETCH_SIZE correction applies to 16-B-per-lane "
                        "streaming reads; this kernel reads dword rows, so the read figure is reported uncorrected "
                        "(upper bound with the correction: 2x).")
-    with open(os.path.join(out, f"{tag}_pmc_summary.json"), "w") as f:
+    with open(os.path.join(out, f"{tag}_pmc_summary{sfx}.json"), "w") as f:
         json.dump(summary, f, indent=1)
     print(json.dumps(summary, indent=1))
 
