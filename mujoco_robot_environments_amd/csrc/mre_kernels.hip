@@ -25,6 +25,7 @@
 #include "mre_collide.h"
 
 namespace mre {
+using ModelP = MRE_MODEL_PTR(DevModel);
 
 // OSC scratch (mre_osc.h); lives in LDS region R1 (see Sm)
 struct OscSm {
@@ -145,7 +146,7 @@ struct BodyRegs {
   float anchor[3], axis[3], xipos[3], ximat[9];
 };
 
-MRE_DEV bool body_is_active(const DevModel* M, const Sm& s, int b) {
+MRE_DEV bool body_is_active(ModelP M, const Sm& s, int b) {
   int p = M->body_propid[b];
   return p < 0 || p < s.nprops;
 }
@@ -154,19 +155,27 @@ MRE_DEV bool body_is_active(const DevModel* M, const Sm& s, int b) {
 // writeback: store the normalised free-joint quaternions in qpos (mj_kinematics does); the
 // query-only pass at the end of a launch must leave the state bits alone
 template <bool WRITEBACK>
-MRE_DEV void kinematics(const DevModel* M, Sm& s, int l, BodyRegs& br) {
+MRE_DEV void kinematics(ModelP M, Sm& s, int l, BodyRegs& br) {
   if (l == 0) {
     v3zero(s.xpos[0]);
     s.xquat[0][0] = 1.f; s.xquat[0][1] = s.xquat[0][2] = s.xquat[0][3] = 0.f;
     for (int k = 0; k < 9; k++) s.xmat[0][k] = (k % 4 == 0) ? 1.f : 0.f;
   }
-  __syncthreads();
-  const int lvl = (l < NB) ? M->body_level[l] : -1;
+  MRE_SYNC();
+  // the lane's body constants are fetched before the level loop: one batch of global loads whose latency
+  // is paid once, instead of one dependent fetch per level behind a fence
+  const int b = l < NB ? l : 0;
+  const int lvl = (l < NB) ? M->body_level[b] : -1;
+  const int qa = M->body_qposadr[b], jtype = M->body_jnttype[b], par = M->body_parent[b];
+  float bpos[3], bquat[4], jpos[3], jaxis[3], ipos[3], iquat[4];
+  v3copy(bpos, M->body_pos[b]); v3copy(jpos, M->jnt_pos[b]); v3copy(jaxis, M->jnt_axis[b]);
+  v3copy(ipos, M->body_ipos[b]);
+  for (int k = 0; k < 4; k++) { bquat[k] = M->body_quat[b][k]; iquat[k] = M->body_iquat[b][k]; }
+  const float qref = M->qpos0[qa];
   for (int level = 1; level <= MAXCHAIN; ++level) {
     if (lvl == level) {
-      const int b = l, qa = M->body_qposadr[b];
       float xp[3], xq[4];
-      if (M->body_jnttype[b] == 2) {
+      if (jtype == 2) {
         v3copy(xp, &s.qpos[qa]);
         for (int k = 0; k < 4; k++) xq[k] = s.qpos[qa + 3 + k];
         qnormalize(xq);
@@ -174,18 +183,18 @@ MRE_DEV void kinematics(const DevModel* M, Sm& s, int l, BodyRegs& br) {
         v3copy(br.anchor, xp);
         br.axis[0] = 0.f; br.axis[1] = 0.f; br.axis[2] = 1.f;
       } else {
-        const int p = M->body_parent[b];
+        const int p = par;
         float tmp[3], q0[4], ql[4];
-        m3mulv(tmp, s.xmat[p], M->body_pos[b]);
+        m3mulv(tmp, s.xmat[p], bpos);
         v3add(xp, s.xpos[p], tmp);
-        qmul(q0, s.xquat[p], M->body_quat[b]);
-        qrotv(tmp, q0, M->jnt_pos[b]);
+        qmul(q0, s.xquat[p], bquat);
+        qrotv(tmp, q0, jpos);
         v3add(br.anchor, xp, tmp);
-        qrotv(br.axis, q0, M->jnt_axis[b]);
-        axisangle2q(ql, M->jnt_axis[b], s.qpos[qa] - M->qpos0[qa]);
+        qrotv(br.axis, q0, jaxis);
+        axisangle2q(ql, jaxis, s.qpos[qa] - qref);
         qmul(xq, q0, ql);
         qnormalize(xq);
-        qrotv(tmp, xq, M->jnt_pos[b]);
+        qrotv(tmp, xq, jpos);
         v3sub(xp, br.anchor, tmp);
       }
       float xm[9], qi[4], tmp[3];
@@ -193,12 +202,12 @@ MRE_DEV void kinematics(const DevModel* M, Sm& s, int l, BodyRegs& br) {
       v3copy(s.xpos[b], xp);
       for (int k = 0; k < 4; k++) s.xquat[b][k] = xq[k];
       for (int k = 0; k < 9; k++) s.xmat[b][k] = xm[k];
-      m3mulv(tmp, xm, M->body_ipos[b]);
+      m3mulv(tmp, xm, ipos);
       v3add(br.xipos, xp, tmp);
-      qmul(qi, xq, M->body_iquat[b]);
+      qmul(qi, xq, iquat);
       q2mat(br.ximat, qi);
     }
-    __syncthreads();
+    MRE_SYNC();
   }
   // sites (lane = site)
   if (l < NSITE) {
@@ -212,7 +221,7 @@ MRE_DEV void kinematics(const DevModel* M, Sm& s, int l, BodyRegs& br) {
 }
 
 // ---------------------------------------------------------------- mj_comPos
-MRE_DEV void com_pos(const DevModel* M, Sm& s, int l, const BodyRegs& br) {
+MRE_DEV void com_pos(ModelP M, Sm& s, int l, const BodyRegs& br) {
   const bool robot = (l >= 1 && l < NRB);
   float mass = 0.f;
   if (l < NB) mass = (M->body_propid[l] >= 0) ? s.prop_mass[M->body_propid[l]] : M->body_mass[l];
@@ -261,17 +270,17 @@ MRE_DEV void com_pos(const DevModel* M, Sm& s, int l, const BodyRegs& br) {
 
 // S1a: kinematics + comPos as one real function so that the per-lane body frame registers
 // (anchor, axis, inertial frame) never leave the register file
-MRE_PHASE_FN void position_stage(const DevModel* M, Sm& s, int l) {
+MRE_PHASE_FN void position_stage(ModelP M, Sm& s, int l) {
   BodyRegs br;
   kinematics<true>(M, s, l, br);
   com_pos(M, s, l, br);
-  __syncthreads();
+  MRE_SYNC();
 }
 // kinematics only (site queries at the end of a launch)
-MRE_PHASE_FN void kinematics_only(const DevModel* M, Sm& s, int l) {
+MRE_PHASE_FN void kinematics_only(ModelP M, Sm& s, int l) {
   BodyRegs br;
   kinematics<false>(M, s, l, br);
-  __syncthreads();
+  MRE_SYNC();
 }
 
 // cdof of cube body b, local dof j (mju_dofCom with zero offset)
@@ -315,7 +324,7 @@ MRE_DEV void dq_rot(double* r, const double* q, const double* v) {
   r[0] = v[0] + 2.0 * (w * cx + dx); r[1] = v[1] + 2.0 * (w * cy + dy); r[2] = v[2] + 2.0 * (w * cz + dz);
 }
 // pose of hinge body b in its parent's frame (mj_kinematics, one body): position p, rotation q
-MRE_DEV void hinge_local_d(const DevModel* M, const Sm& s, int b, double* p, double* q) {
+MRE_DEV void hinge_local_d(ModelP M, const Sm& s, int b, double* p, double* q) {
   double q0[4], ql[4], ax[3], jp[3], t0[3], t1[3];
   for (int k = 0; k < 4; k++) q0[k] = (double)M->body_quat[b][k];
   for (int k = 0; k < 3; k++) { ax[k] = (double)M->jnt_axis[b][k]; jp[k] = (double)M->jnt_pos[b][k]; }
@@ -331,7 +340,7 @@ MRE_DEV void hinge_local_d(const DevModel* M, const Sm& s, int b, double* p, dou
   for (int k = 0; k < 3; k++) p[k] = (double)M->body_pos[b][k] + t0[k] - t1[k];
 }
 // spatial inertia (10) of body c about point O, axes of the frame its pose (p, q) is given in
-MRE_DEV void inert_about_d(const DevModel* M, int c, const double* p, const double* q, const double* O, double* ci) {
+MRE_DEV void inert_about_d(ModelP M, int c, const double* p, const double* q, const double* O, double* ci) {
   double ip[3] = {(double)M->body_ipos[c][0], (double)M->body_ipos[c][1], (double)M->body_ipos[c][2]}, t[3], qi[4];
   double iq[4] = {(double)M->body_iquat[c][0], (double)M->body_iquat[c][1], (double)M->body_iquat[c][2], (double)M->body_iquat[c][3]};
   dq_rot(t, q, ip);
@@ -364,7 +373,7 @@ MRE_DEV void inert_about_d(const DevModel* M, int c, const double* p, const doub
 // of the arm's last link, and the momentum map P = crb * cdof that the finger rows of M are built
 // from (crb_mass_matrix).  Chains below the arm are at most two bodies deep (checked in mre_create).
 // lane = finger body: its pose in the arm link's frame (composition with its parent's joint included)
-MRE_PHASE_FN void gripper_pose(const DevModel* M, Sm& s, int l) {
+MRE_PHASE_FN void gripper_pose(ModelP M, Sm& s, int l) {
   if (l >= GRIP_BODY0 && l < NRB) {
     const int b = l;
     double p[3], q[4];
@@ -381,9 +390,9 @@ MRE_PHASE_FN void gripper_pose(const DevModel* M, Sm& s, int l) {
     for (int k = 0; k < 3; k++) s.gpose[b - GRIP_BODY0][k] = p[k];
     for (int k = 0; k < 4; k++) s.gpose[b - GRIP_BODY0][3 + k] = q[k];
   }
-  __syncthreads();
+  MRE_SYNC();
 }
-MRE_PHASE_FN void gripper_local(const DevModel* M, Sm& s, int l) {
+MRE_PHASE_FN void gripper_local(ModelP M, Sm& s, int l) {
   if (l >= GRIP_BODY0 && l < NRB) {
     const int b = l;
     const double* pose = s.gpose[b - GRIP_BODY0];
@@ -413,13 +422,13 @@ MRE_PHASE_FN void gripper_local(const DevModel* M, Sm& s, int l) {
     P[5] = ci[7] * cd[0] - ci[6] * cd[1] + ci[9] * cd[5];
     for (int k = 0; k < 6; k++) { s.gC[b - GRIP_BODY0][k] = (float)cd[k]; s.gP[b - GRIP_BODY0][k] = (float)P[k]; }
   }
-  __syncthreads();
+  MRE_SYNC();
 }
 
 // One side of a `connect` constraint in the frame of the arm's last link: the anchor point x of body
 // b and, for the finger dofs on the way up (b, then its parent if that is a finger body), the lever
 // vectors u_c x (x - a_c) (axis u_c, joint anchor a_c), times `sign`.
-MRE_DEV void connect_side_d(const DevModel* M, const Sm& s, int b, const float* a, double sign, double* x,
+MRE_DEV void connect_side_d(ModelP M, const Sm& s, int b, const float* a, double sign, double* x,
                             double (*vec)[3]) {
   const double* pose = s.gpose[b - GRIP_BODY0];
   const double al[3] = {(double)a[0], (double)a[1], (double)a[2]};
@@ -454,7 +463,7 @@ MRE_DEV void connect_side_d(const DevModel* M, const Sm& s, int b, const float* 
 // Results go to the head of qfrc_con (dead between integrate and the next solve), 16 floats per
 // constraint: [0:3] residual, [4 + 3 m : 7 + 3 m] lever vector of finger dof m (body1, its parent,
 // body2, its parent; zero where the chain is shorter), all in the arm link's axes.
-MRE_PHASE_FN void connect_rows_local(const DevModel* M, Sm& s, int l) {
+MRE_PHASE_FN void connect_rows_local(ModelP M, Sm& s, int l) {
   if (l < 2 && M->eq_type[l] == 0) {
     double x1[3], x2[3], v1[2][3], v2[2][3];
     connect_side_d(M, s, M->eq_obj[l][0], M->eq_data[l], 1.0, x1, v1);
@@ -466,11 +475,11 @@ MRE_PHASE_FN void connect_rows_local(const DevModel* M, Sm& s, int l) {
       o[10 + k] = (float)v2[0][k]; o[13 + k] = (float)v2[1][k];
     }
   }
-  __syncthreads();
+  MRE_SYNC();
 }
 
 // ------------------------------------------------------- mj_crb (robot block)
-MRE_DEV void crb_mass_matrix(const DevModel* M, Sm& s, int l) {
+MRE_DEV void crb_mass_matrix(ModelP M, Sm& s, int l) {
   if (l >= 1 && l < NRB) {
     const unsigned mask = M->body_desc_mask[l];
     float acc[10];
@@ -484,7 +493,7 @@ MRE_DEV void crb_mass_matrix(const DevModel* M, Sm& s, int l) {
 #pragma unroll
     for (int k = 0; k < 10; k++) s.crb[l][k] = acc[k];
   }
-  __syncthreads();
+  MRE_SYNC();
   for (int e = l; e < NMR; e += 64) {
     const int i = M->M_i[e], j = M->M_j[e];
     float v;
@@ -606,7 +615,7 @@ MRE_DEV void factor_robot_regs(const float* src_, float* LD_, float* dinv_) {
   factor_regs_rows<NRV - 1>(A, dinv);
 #pragma unroll
   for (int e = 0; e < NMR; e++) LD[e] = A[e];
-  __syncthreads();
+  MRE_SYNC();
 }
 
 // x <- M^-1 x for up to four right-hand sides at once, level-parallel: lane = (group g = l / 16,
@@ -614,7 +623,7 @@ MRE_DEV void factor_robot_regs(const float* src_, float* LD_, float* dinv_) {
 // up (a dof folds in all its descendants, which are final), scaling, forward pass from the roots
 // down; the terms of every sum are applied in mj_solveLD's order, so the result is bit-identical
 // to the serial algorithm.  The dof tree is at most sol_maxdepth + 1 levels deep (9 for this robot).
-MRE_PHASE_FN void solve_robot_par(const DevModel* M, const float* LD, const float* dinv, float* xb, int xstride,
+MRE_PHASE_FN void solve_robot_par(ModelP M, const float* LD, const float* dinv, float* xb, int xstride,
                                   int ngroups, int l) {
   const int g = l >> 4, i = l & 15;
   const bool on = i < NRV && g < ngroups;
@@ -637,10 +646,10 @@ MRE_PHASE_FN void solve_robot_par(const DevModel* M, const float* LD, const floa
       }
       x[i] = acc;
     }
-    __syncthreads();
+    MRE_SYNC();
   }
   if (on) x[i] *= dinv[i];
-  __syncthreads();
+  MRE_SYNC();
   for (int d = 1; d <= maxd; ++d) {
     if (depth == d) {
       float acc = x[i];
@@ -651,7 +660,7 @@ MRE_PHASE_FN void solve_robot_par(const DevModel* M, const float* LD, const floa
       }
       x[i] = acc;
     }
-    __syncthreads();
+    MRE_SYNC();
   }
 }
 
@@ -664,7 +673,7 @@ MRE_PHASE_FN void solve_robot_par(const DevModel* M, const float* LD, const floa
 namespace mre {
 
 // ------------------------------------------------ mj_comVel + mj_rne + mj_passive
-MRE_PHASE_FN void velocity_stage(const DevModel* M, Sm& s, int l) {
+MRE_PHASE_FN void velocity_stage(ModelP M, Sm& s, int l) {
   // cvel, cdof_dot (lane = body; each lane re-accumulates its chain prefix)
   float cv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (l >= 1 && l < NB) {
@@ -702,7 +711,7 @@ MRE_PHASE_FN void velocity_stage(const DevModel* M, Sm& s, int l) {
 #pragma unroll
     for (int t = 0; t < 6; t++) s.cvel[b][t] = cv[t];
   }
-  __syncthreads();
+  MRE_SYNC();
   // cacc, cfrc_body (lane = body)
   if (l >= 1 && l < NB) {
     const int b = l;
@@ -729,7 +738,7 @@ MRE_PHASE_FN void velocity_stage(const DevModel* M, Sm& s, int l) {
 #pragma unroll
     for (int t = 0; t < 6; t++) s.cfrc[b][t] = f[t] + t1[t];
   }
-  __syncthreads();
+  MRE_SYNC();
   // qfrc_bias (lane = dof): cdof . sum of cfrc over the subtree of the dof's body
   if (l < NV) {
     const int b = M->dof_body[l];
@@ -754,7 +763,7 @@ MRE_PHASE_FN void velocity_stage(const DevModel* M, Sm& s, int l) {
 
 // ------------------------- mj_fwdActuation + mj_passive + mj_fwdAcceleration
 // returns (wave-uniform) whether the finger actuator force is clamped
-MRE_DEV bool smooth_forces(const DevModel* M, Sm& s, int l) {
+MRE_DEV bool smooth_forces(ModelP M, Sm& s, int l) {
   const float ten_len = M->ten_coef[0] * s.qpos[M->ten_dof[0]] + M->ten_coef[1] * s.qpos[M->ten_dof[1]];
   const float ten_vel = M->ten_coef[0] * s.qvel[M->ten_dof[0]] + M->ten_coef[1] * s.qvel[M->ten_dof[1]];
   const float cg = clampf(s.ctrl[NU - 1], M->act_ctrlrange[NU - 1][0], M->act_ctrlrange[NU - 1][1]);
@@ -777,21 +786,21 @@ MRE_DEV bool smooth_forces(const DevModel* M, Sm& s, int l) {
     s.qfrc_smooth[l] = f;
     s.qacc_smooth[l] = f;
   }
-  __syncthreads();
+  MRE_SYNC();
   solve_robot_par(M, s.qLD, s.qLDinv, s.qacc_smooth, 0, 1, l);
   if (l >= NRV && l < NV) {
     const int p = (l - NRV) / 6, k = (l - NRV) % 6;
     const float md = (k < 3) ? s.prop_mass[p] : s.prop_inertia[p][k - 3];
     s.qacc_smooth[l] = s.qacc_smooth[l] / md;
   }
-  __syncthreads();
+  MRE_SYNC();
   return clamped;
 }
 
 // ------------------------------------------- mj_implicit (implicitfast) + advance
 // part 1: MH and the right-hand side; the kernel body then factors MH (factor_robot_regs, inlined
 // there: a kernel has no callee-saved registers to spill) and calls part 2
-MRE_PHASE_FN void integrate_setup(const DevModel* M, Sm& s, int l, bool grip_clamped) {
+MRE_PHASE_FN void integrate_setup(ModelP M, Sm& s, int l, bool grip_clamped) {
   const float h = M->timestep;
   if (l < NVP) s.qacc_ws[l] = (l < NV) ? s.qacc[l] : 0.f;
   // MH = M - h*dF/dv restricted to M's pattern (diagonal terms only here)
@@ -808,11 +817,11 @@ MRE_PHASE_FN void integrate_setup(const DevModel* M, Sm& s, int l, bool grip_cla
     s.qLD[e] = v;
   }
   if (l < NRV) s.scratch[l] = s.qfrc_smooth[l] + s.qfrc_con[l];
-  __syncthreads();
+  MRE_SYNC();
 }
 
 // part 2 (after the solve of MH x = f, also run from the kernel body): advance velocities and positions
-MRE_PHASE_FN void integrate(const DevModel* M, Sm& s, int l, unsigned flags) {
+MRE_PHASE_FN void integrate(ModelP M, Sm& s, int l, unsigned flags) {
   const float h = M->timestep;
   const bool freeze = (flags & F_FREEZE_ROBOT) != 0;
   if (l < NV) {
@@ -823,7 +832,7 @@ MRE_PHASE_FN void integrate(const DevModel* M, Sm& s, int l, unsigned flags) {
       s.qvel[l] += h * s.qacc[l];  // free joints carry no damping: MH = M on cube blocks
     }
   }
-  __syncthreads();
+  MRE_SYNC();
   if (l >= 1 && l < NB) {
     const int b = l, qa = M->body_qposadr[b], da = M->body_dofadr[b];
     if (b < NRB) {
@@ -840,7 +849,7 @@ MRE_PHASE_FN void integrate(const DevModel* M, Sm& s, int l, unsigned flags) {
       for (int k = 0; k < 4; k++) s.qpos[qa + 3 + k] = qn[k];
     }
   }
-  __syncthreads();
+  MRE_SYNC();
 }
 
 // =========================================================================
@@ -849,9 +858,11 @@ MRE_PHASE_FN void integrate(const DevModel* M, Sm& s, int l, unsigned flags) {
 #ifdef MRE_PHASE_STAMPS
 #define MRE_STAMP(k)                                                         \
   do {                                                                       \
-    const unsigned long long now_ = __builtin_amdgcn_s_memtime();            \
-    if ((k) / 4 == MRE_PHASE_STAMPS) stamp_acc[(k) % 4] += now_ - stamp_t;   \
-    stamp_t = now_;                                                          \
+    if ((k) < 12 || MRE_PHASE_STAMPS == 3) {                                 \
+      const unsigned long long now_ = __builtin_amdgcn_s_memtime();          \
+      if ((k) / 4 == MRE_PHASE_STAMPS) stamp_acc[(k) % 4] += now_ - stamp_t; \
+      stamp_t = now_;                                                        \
+    }                                                                        \
   } while (0)
 #else
 #define MRE_STAMP(k) do {} while (0)
@@ -865,7 +876,7 @@ MRE_DEV void step_body(const StepArgs& a, Sm& s) {
   const int env = a.env_order != nullptr ? a.env_order[blockIdx.x] : (int)blockIdx.x;
   const int l = threadIdx.x;
   if (a.env_mask != nullptr && a.env_mask[env] == 0) return;
-  const DevModel* M = a.M;
+  ModelP M = (ModelP)a.M;
 
   // ---- load state (one coalesced row per array)
   if (l < NQP) s.qpos[l] = a.qpos[(size_t)env * NQP + l];
@@ -881,7 +892,7 @@ MRE_DEV void step_body(const StepArgs& a, Sm& s) {
     const float sz = a.prop_size[(size_t)env * NPROP * 3 + l];
     s.prop_size[l / 3][l % 3] = sz;
   }
-  __syncthreads();
+  MRE_SYNC();
   if (l < NPROP) {
     const float m = M->body_mass[NRB + l];
     const float* z = s.prop_size[l];
@@ -890,7 +901,7 @@ MRE_DEV void step_body(const StepArgs& a, Sm& s) {
     s.prop_inertia[l][1] = m / 3.f * (z[0] * z[0] + z[2] * z[2]);
     s.prop_inertia[l][2] = m / 3.f * (z[0] * z[0] + z[1] * z[1]);
   }
-  __syncthreads();
+  MRE_SYNC();
 
 #ifdef MRE_PHASE_STAMPS
   unsigned long long stamp_acc[4] = {0, 0, 0, 0};
@@ -904,7 +915,7 @@ MRE_DEV void step_body(const StepArgs& a, Sm& s) {
     if (l < 16) s.osc_tgt[l] = a.osc_target[(size_t)env * 16 + l];
     // MinMax.compute_control_output: max_val 255 (closed) / min_val 0 (open), min_max.yaml:3-4
     grip_cmd = a.grip_closed[env] ? M->act_ctrlrange[NU - 1][1] : M->act_ctrlrange[NU - 1][0];
-    __syncthreads();
+    MRE_SYNC();
   }
   int steps_done = 0;
   bool settled = false;
@@ -912,18 +923,22 @@ MRE_DEV void step_body(const StepArgs& a, Sm& s) {
     // ------------------------------------------------ S1: position stage
     MRE_STAMP(7);
     position_stage(M, s, l);
+    MRE_STAMP(12);
     gripper_pose(M, s, l);
+    MRE_STAMP(13);
     gripper_local(M, s, l);
     if ((a.flags & F_NO_CONSTRAINTS) == 0) connect_rows_local(M, s, l);
+    MRE_STAMP(14);
     crb_mass_matrix(M, s, l);
-    __syncthreads();
+    MRE_SYNC();
     factor_robot_regs(s.qM, s.qLD, s.qLDinv);
+    MRE_STAMP(15);
     MRE_STAMP(0);
     // ------------------------------------------------ S1b: velocity stage (before collision:
     // its temporaries share LDS region R2 with the contact geometry)
 
     velocity_stage(M, s, l);
-    __syncthreads();
+    MRE_SYNC();
     MRE_STAMP(1);
     // ------------------------------------------------ S1c: collision + constraint assembly
     const bool constrained = (a.flags & F_NO_CONSTRAINTS) == 0;
@@ -947,7 +962,7 @@ MRE_DEV void step_body(const StepArgs& a, Sm& s) {
     if (a.mode == CTRL_SEQ && (step % a.control_steps) == 0) {
       const int tick = step / a.control_steps;
       if (l < NU) s.ctrl[l] = a.ctrl_seq[((size_t)tick * a.N + env) * NU + l];
-      __syncthreads();
+      MRE_SYNC();
     }
     if (a.mode == CTRL_OSC && (step % a.control_steps) == 0) {
       // RobotArm.run_controller tick (robot_arm.py:69-88): is_converged() of the previous
@@ -955,7 +970,7 @@ MRE_DEV void step_body(const StepArgs& a, Sm& s) {
       if (step > 0 && osc_converged(M, s, oscp, s.osc_tgt)) arm_converged = true;
       osc_compute(M, s, osc, oscp, s.osc_tgt, l);
       if (l == 0) s.ctrl[NU - 1] = grip_cmd;
-      __syncthreads();
+      MRE_SYNC();
     }
     // ------------------------------------------------ S2
     MRE_STAMP(4);
@@ -972,7 +987,7 @@ MRE_DEV void step_body(const StepArgs& a, Sm& s) {
       MRE_STAMP(6);
     } else {
       if (l < NVP) { s.qacc[l] = s.qacc_smooth[l]; s.qfrc_con[l] = 0.f; }
-      __syncthreads();
+      MRE_SYNC();
     }
 
     integrate_setup(M, s, l, clamped);
@@ -1011,12 +1026,12 @@ MRE_DEV void step_body(const StepArgs& a, Sm& s) {
     gripper_pose(M, s, l);
     gripper_local(M, s, l);
     crb_mass_matrix(M, s, l);
-    __syncthreads();
+    MRE_SYNC();
     velocity_stage(M, s, l);
-    __syncthreads();
+    MRE_SYNC();
     osc_compute(M, s, osc, oscp, s.osc_tgt, l);
     if (l == 0) s.ctrl[NU - 1] = grip_cmd;
-    __syncthreads();
+    MRE_SYNC();
   }
   if (a.nsteps == 0 && (a.flags & F_DETECT) != 0 && a.contacts != nullptr) {
     // physics.forward() + physics.data.contact: kinematics, then every detected contact
@@ -1029,7 +1044,7 @@ MRE_DEV void step_body(const StepArgs& a, Sm& s) {
       const int pr = s.con_pair[l];
       o[1 + 3 * l] = (float)M->pair_g1[pr]; o[2 + 3 * l] = (float)M->pair_g2[pr]; o[3 + 3 * l] = s.con_dist[l];
     }
-    __syncthreads();
+    MRE_SYNC();
     if (l == 0) s.overflow = 0;   // a cut detection list is reported in the count, not as a status bit
   }
   // ---- final kinematics for site queries
@@ -1177,7 +1192,7 @@ __global__ __launch_bounds__(64) void k_pose_search(SearchArgs a) {
   const int env = blockIdx.x, l = threadIdx.x;
   if (env >= a.N) return;
   if (a.env_mask != nullptr && a.env_mask[env] == 0) return;
-  const DevModel* M = a.M;
+  ModelP M = (ModelP)a.M;
   const int np = a.nprops[env];
   const int p = a.prop != nullptr ? a.prop[env] : a.fixed_prop;
   if (p < 0 || p >= np || p >= NPROP) {
@@ -1187,7 +1202,7 @@ __global__ __launch_bounds__(64) void k_pose_search(SearchArgs a) {
   if (l < NQP) s.qpos[l] = a.qpos[(size_t)env * NQP + l];
   if (l == 0) s.nprops = np;
   if (l < NPROP * 3) s.prop_size[l / 3][l % 3] = a.prop_size[(size_t)env * NPROP * 3 + l];
-  __syncthreads();
+  MRE_SYNC();
   kinematics_only(M, s, l);
   // the cube's pairs, in table order
   const int gp = PROP_GEOM0 + p, table = 1, body = NRB + p;
@@ -1201,9 +1216,9 @@ __global__ __launch_bounds__(64) void k_pose_search(SearchArgs a) {
     if (mine) s.iscr[cnt + __popcll(b & ((1ull << l) - 1ull))] = pr;
     cnt += __popcll(b);
   }
-  __syncthreads();
+  MRE_SYNC();
   const int pr = l < cnt ? s.iscr[l] : -1;
-  __syncthreads();
+  MRE_SYNC();
   float* buf = &s.JpA[0][0] + l * COLL_BUF;   // this lane's clip buffer (as in collide)
   const unsigned long long gid = (unsigned long long)(a.env_ids != nullptr ? a.env_ids[env] : a.env_id_offset + env);
   const unsigned long long tick0 = (unsigned long long)(a.tick_base != nullptr ? (long long)a.tick_base[env] : a.tick0);
@@ -1225,7 +1240,7 @@ __global__ __launch_bounds__(64) void k_pose_search(SearchArgs a) {
       for (int k = 0; k < 4; k++) s.xquat[body][k] = xq[k];
       q2mat(s.xmat[body], xq);
     }
-    __syncthreads();
+    MRE_SYNC();
     bool hit = false;
     if (pr >= 0) {
       const int g1 = M->pair_g1[pr], g2 = M->pair_g2[pr];
@@ -1248,7 +1263,7 @@ __global__ __launch_bounds__(64) void k_pose_search(SearchArgs a) {
       }
     }
     const bool any = __ballot(hit) != 0ull;
-    __syncthreads();
+    MRE_SYNC();
     if (!any) { used = att + 1; break; }
   }
   if (l == 0) {

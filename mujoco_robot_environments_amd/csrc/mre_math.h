@@ -7,6 +7,27 @@
 // whole phases are real functions: register allocation is scoped per phase instead of across
 // the fused step loop (the inlined kernel needed 332 registers -> 1 wave per SIMD)
 #define MRE_PHASE_FN __device__ __attribute__((noinline))
+// Ordering point between lanes of the ONE wave that steps an env.  A workgroup is a single wavefront, whose
+// LDS instructions issue and execute in order, so lanes see each other's earlier LDS writes without waiting for
+// them: all that is needed is that the compiler keeps the memory operations on their side of the point.
+// __syncthreads() would add `s_waitcnt lgkmcnt(0)` (drain every LDS operation in flight, writes included) to
+// each of the few hundred ordering points of a step.
+#define MRE_SYNC()                                        \
+  do {                                                    \
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); \
+    __builtin_amdgcn_wave_barrier();                      \
+  } while (0)
+// Pointer to the uploaded model, typed as a GLOBAL-address-space pointer.  A plain `const DevModel*` that
+// reaches a noinline phase function (or comes out of the by-value launch arguments) is a generic pointer to
+// the compiler: its loads become flat_load, which count on BOTH memory counters, so every LDS wait also
+// waits for the model constants in flight.  With the address space in the type the loads are global_load
+// (vmcnt only) and overlap the LDS traffic.
+// (the host pass of hipcc parses the device functions too but has no address spaces to convert between)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MRE_MODEL_PTR(T) const T __attribute__((address_space(1)))*
+#else
+#define MRE_MODEL_PTR(T) const T*
+#endif
 
 namespace mre {
 

@@ -247,7 +247,7 @@ MRE_PHASE_FN void nw_build_lists(Sm& s, int l) {
     for (int p = 0; p < NPROP; p++) s.ccount[p] = (uint8_t)cnt[p];
     s.cpl_robot = (uint8_t)cr; s.cpl_cubes = (uint8_t)cc;
   }
-  __syncthreads();
+  MRE_SYNC();
 }
 
 // Per-lane constants of the solver phases
@@ -258,7 +258,7 @@ struct NwLane {
   float mu_scale;   // mu = friction * sqrt(R1 / R0) = friction / sqrt(impratio)
   float scale;      // 1 / (meaninertia * nv)
 };
-MRE_DEV NwLane nw_lane(const DevModel* M, const Sm& s, int l) {
+MRE_DEV NwLane nw_lane(ModelP M, const Sm& s, int l) {
   NwLane c;
   c.lp = (l >= NRV && l < NV) ? (l - NRV) / 6 : -1;
   c.lk = (l >= NRV && l < NV) ? (l - NRV) % 6 : 0;
@@ -276,7 +276,7 @@ MRE_DEV NwLane nw_lane(const DevModel* M, const Sm& s, int l) {
 // In: s.qacc (current iterate), s.nw_Ma.  Out: s.frc, s.rstate, s.hc, s.qfrc_con, s.nw_grad.
 MRE_DEV float nw_update_gradient(Sm& s, int l, const NwLane& c, int nscalar, int ncon) {
   const float sc = nw_update<true>(s, l, nscalar, ncon, c.mu_scale, s.jar);
-  __syncthreads();
+  MRE_SYNC();
   const float qc = nw_JTf(s, l, c.lp, c.lk, nscalar);
   const bool on = l < NV && c.lact;
   const float fs = on ? s.qfrc_smooth[l] : 0.f, as = on ? s.qacc_smooth[l] : 0.f;
@@ -286,23 +286,23 @@ MRE_DEV float nw_update_gradient(Sm& s, int l, const NwLane& c, int nscalar, int
     s.nw_grad[l] = on ? Ma - fs - qc : 0.f;
   }
   const float cost = sc + wave_sum(0.5f * (Ma - fs) * (qa - as));
-  __syncthreads();
+  MRE_SYNC();
   return cost;
 }
 
 // Phase 1: dense robot M, warm start (the cheaper of qacc_warmstart and qacc_smooth in primal
 // cost), first constraint update and gradient.  Returns the cost.
-MRE_PHASE_FN float nw_setup(const DevModel* M, Sm& s, int l) {
+MRE_PHASE_FN float nw_setup(ModelP M, Sm& s, int l) {
   const NwLane c = nw_lane(M, s, l);
   const int nefc = s.nefc, ncon = s.ncon, nscalar = 7 + s.nl;
   for (int e = l; e < NRV * MD_LD; e += 64) (&s.Md[0][0])[e] = 0.f;
-  __syncthreads();
+  MRE_SYNC();
   for (int e = l; e < NMR; e += 64) {
     const int i = M->M_i[e], j = M->M_j[e];
     const float v = s.qM[e];
     s.Md[i][j] = v; s.Md[j][i] = v;
   }
-  __syncthreads();
+  MRE_SYNC();
   const bool on = l < NV && c.lact;
   const float fs = on ? s.qfrc_smooth[l] : 0.f, as = on ? s.qacc_smooth[l] : 0.f;
   float qa = on ? s.qacc_ws[l] : 0.f;
@@ -312,7 +312,7 @@ MRE_PHASE_FN float nw_setup(const DevModel* M, Sm& s, int l) {
     s.jar[i] = row_dot(s, i, s.qacc_ws) - aref;
     s.jv[i] = row_dot(s, i, s.qacc_smooth) - aref;
   }
-  __syncthreads();
+  MRE_SYNC();
   const float gauss = wave_sum(0.5f * (Ma - fs) * (qa - as));
   const float cost_ws = gauss + nw_update<false>(s, l, nscalar, ncon, c.mu_scale, s.jar);
   const float cost_sm = nw_update<false>(s, l, nscalar, ncon, c.mu_scale, s.jv);
@@ -321,13 +321,13 @@ MRE_PHASE_FN float nw_setup(const DevModel* M, Sm& s, int l) {
     for (int i = l; i < nefc; i += 64) s.jar[i] = s.jv[i];
   }
   if (l < NVP) { s.qacc[l] = qa; s.nw_Ma[l] = Ma; }
-  __syncthreads();
+  MRE_SYNC();
   return nw_update_gradient(s, l, c, nscalar, ncon);
 }
 
 // Phase 2: search = -H^-1 grad.  H = M + J' D J (+ cone Hessians) with its rows in registers,
 // block-sparse factorisation H = W W', both triangular solves.
-MRE_PHASE_FN void nw_direction(const DevModel* M, Sm& s, int l) {
+MRE_PHASE_FN void nw_direction(ModelP M, Sm& s, int l) {
   const NwLane c = nw_lane(M, s, l);
   const int nefc = s.nefc, nscalar = 7 + s.nl, nprops = s.nprops;
   const int lp = c.lp, lk = c.lk;
@@ -431,7 +431,7 @@ MRE_PHASE_FN void nw_direction(const DevModel* M, Sm& s, int l) {
 #pragma unroll
   for (int k = 0; k < NV; k++)
     if (l <= k) s.W[k * (k + 1) / 2 + l] = hh[k];
-  __syncthreads();
+  MRE_SYNC();
   {
     const int base = l < NV ? l * (l + 1) / 2 : 0;
     const int nva = NRV + 6 * nprops;  // inactive cube blocks: x = 0
@@ -446,14 +446,14 @@ MRE_PHASE_FN void nw_direction(const DevModel* M, Sm& s, int l) {
   // Newton decrement grad' H^-1 grad: the cost decrease the quadratic model predicts is half of it
   const float dec = wave_sum((l < NVP ? s.nw_grad[l] : 0.f) * x);
   if (l == 0) s.scratch[2] = dec;
-  __syncthreads();
+  MRE_SYNC();
 }
 
 // Phase 2': the same direction from the factor of the last nw_direction call (still in s.W), for a
 // gradient whose active set did not change -- MuJoCo's Newton likewise keeps its Cholesky factor
 // while the constraint states stand.  Both triangular solves read W from LDS: W y = g by columns
 // (for column k the lanes j < k read consecutive words), W' x = y as in nw_direction.
-MRE_PHASE_FN void nw_direction_reuse(const DevModel* M, Sm& s, int l) {
+MRE_PHASE_FN void nw_direction_reuse(ModelP M, Sm& s, int l) {
   const NwLane c = nw_lane(M, s, l);
   const int nva = NRV + 6 * s.nprops;
   const bool on = l < NV && c.lact;
@@ -477,12 +477,12 @@ MRE_PHASE_FN void nw_direction_reuse(const DevModel* M, Sm& s, int l) {
   if (l < NVP) s.nw_search[l] = -x;
   const float dec = wave_sum(gin * x);
   if (l == 0) s.scratch[2] = dec;
-  __syncthreads();
+  MRE_SYNC();
 }
 
 // Phase 3: exact line search along s.nw_search (PrimalSearch), move, constraint update, gradient.
 // Returns the new cost; s.scratch[0] = step (0 when no step was possible), s.scratch[1] = |grad|.
-MRE_PHASE_FN float nw_search_move(const DevModel* M, Sm& s, int l) {
+MRE_PHASE_FN float nw_search_move(ModelP M, Sm& s, int l) {
   const NwLane c = nw_lane(M, s, l);
   const int nefc = s.nefc, ncon = s.ncon, nscalar = 7 + s.nl;
   const float tol = M->tolerance, mu_scale = c.mu_scale;
@@ -492,7 +492,7 @@ MRE_PHASE_FN float nw_search_move(const DevModel* M, Sm& s, int l) {
   const float sv = on ? s.nw_search[l] : 0.f;
   const float Mv = on ? nw_mulM(s, l, c.mdiag, s.nw_search) : 0.f;
   for (int i = l; i < nefc; i += 64) s.jv[i] = row_dot(s, i, s.nw_search);
-  __syncthreads();
+  MRE_SYNC();
   const float snorm = sqrtf(wave_sum(sv * sv));
   float alpha = 0.f;
   if (snorm >= kMinVal) {
@@ -584,17 +584,17 @@ MRE_PHASE_FN float nw_search_move(const DevModel* M, Sm& s, int l) {
     }
   }
   if (l == 0) { s.scratch[0] = alpha; s.scratch[1] = 0.f; }
-  if (alpha == 0.f) { __syncthreads(); return 0.f; }
+  if (alpha == 0.f) { MRE_SYNC(); return 0.f; }
   qa = fmaf(alpha, sv, qa);
   Ma = fmaf(alpha, Mv, Ma);
   if (l < NVP) { s.qacc[l] = qa; s.nw_Ma[l] = Ma; }
   for (int i = l; i < nefc; i += 64) s.jar[i] = fmaf(alpha, s.jv[i], s.jar[i]);
-  __syncthreads();
+  MRE_SYNC();
   const float cost = nw_update_gradient(s, l, c, nscalar, ncon);
   const float gr = l < NVP ? s.nw_grad[l] : 0.f;
   const float gn = sqrtf(wave_sum(gr * gr));
   if (l == 0) s.scratch[1] = gn;
-  __syncthreads();
+  MRE_SYNC();
   return cost;
 }
 
@@ -618,10 +618,10 @@ MRE_PHASE_FN float nw_search_move(const DevModel* M, Sm& s, int l) {
     if ((8 + (k)) / 4 == MRE_PHASE_STAMPS) stamp_acc[(k) % 4] += now_ - stamp_t; \
     stamp_t = now_;                                                          \
   } while (0)
-MRE_DEV void newton_solve(const DevModel* M, Sm& s, int l, unsigned long long* stamp_acc, unsigned long long& stamp_t) {
+MRE_DEV void newton_solve(ModelP M, Sm& s, int l, unsigned long long* stamp_acc, unsigned long long& stamp_t) {
 #else
 #define NW_STAMP(k) do {} while (0)
-MRE_DEV void newton_solve(const DevModel* M, Sm& s, int l) {
+MRE_DEV void newton_solve(ModelP M, Sm& s, int l) {
 #endif
   const float tol = M->tolerance;
   const int max_iter = M->iterations;
@@ -679,7 +679,7 @@ MRE_DEV void newton_solve(const DevModel* M, Sm& s, int l) {
   }
   if (l < NVP && !(l < NV)) s.qacc[l] = 0.f;
   if (l == 0) s.solver_iters = iter | (nfull << 8);
-  __syncthreads();
+  MRE_SYNC();
 }
 
 }  // namespace mre

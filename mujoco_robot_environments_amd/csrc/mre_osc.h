@@ -27,7 +27,7 @@ MRE_DEV float gauss_jordan_inplace(float* A, int l) {
     const float aik = on ? A[i * LD + k] : 0.f;
     const float akj = on ? A[k * LD + j] : 0.f;
     const float aij = on ? A[i * LD + j] : 0.f;
-    __syncthreads();
+    MRE_SYNC();
     det *= piv;
     const float p = 1.0f / piv;
     if (on) {
@@ -38,7 +38,7 @@ MRE_DEV float gauss_jordan_inplace(float* A, int l) {
       else v = aij - aik * akj * p;
       A[i * LD + j] = v;
     }
-    __syncthreads();
+    MRE_SYNC();
   }
   return det;
 }
@@ -85,7 +85,7 @@ MRE_DEV void sym_pinv6_serial(const float* A_in, float* out, float* V, float* w,
 }
 
 // position / orientation error of the controller site w.r.t. the target
-MRE_DEV void osc_errors(const DevModel* M, const Sm& s, const float* tgt, float* ep, float* eo) {
+MRE_DEV void osc_errors(ModelP M, const Sm& s, const float* tgt, float* ep, float* eo) {
   const int st = M->eef_site;
   v3sub(ep, tgt, s.site_xpos[st]);
   float q[4], qc[4], qe[4];
@@ -97,7 +97,7 @@ MRE_DEV void osc_errors(const DevModel* M, const Sm& s, const float* tgt, float*
   eo[0] = sg * qe[1]; eo[1] = sg * qe[2]; eo[2] = sg * qe[3];
 }
 
-MRE_DEV bool osc_converged(const DevModel* M, const Sm& s, const OscConfig* cp, const float* tgt) {
+MRE_DEV bool osc_converged(ModelP M, const Sm& s, const OscConfig* cp, const float* tgt) {
   const OscConfig& c = *cp;
   float ep[3], eo[3];
   osc_errors(M, s, tgt, ep, eo);
@@ -105,7 +105,7 @@ MRE_DEV bool osc_converged(const DevModel* M, const Sm& s, const OscConfig* cp, 
 }
 
 // writes s.ctrl[0..6]; tgt = [pos3 quat4 vel3 angvel3] (uniform pointer into LDS)
-MRE_PHASE_FN void osc_compute(const DevModel* M, Sm& s, OscSm& o, const OscConfig* cp, const float* tgt, int l) {
+MRE_PHASE_FN void osc_compute(ModelP M, Sm& s, OscSm& o, const OscConfig* cp, const float* tgt, int l) {
   const OscConfig& c = *cp;
   const int st = M->eef_site;
   // J (lane = r*7+a) and dense arm mass block (lane = i*7+j)
@@ -123,7 +123,7 @@ MRE_PHASE_FN void osc_compute(const DevModel* M, Sm& s, OscSm& o, const OscConfi
     o.M[i][j] = s.qM[M->dof_Madr[hi] + (hi - lo)];
   }
   if (l == 0) osc_errors(M, s, tgt, o.ep, o.eo);
-  __syncthreads();
+  MRE_SYNC();
   gauss_jordan_inplace<7, 7>(&o.M[0][0], l);  // o.M <- M^-1
   if (l < 42) {
     const int i = l / 6, cc = l % 6;
@@ -141,7 +141,7 @@ MRE_PHASE_FN void osc_compute(const DevModel* M, Sm& s, OscSm& o, const OscConfi
     const int a = l - 54;
     o.tn[a] = c.kp_null * (c.null_q[a] - s.qpos[a]) + c.kd_null * (0.f - s.qvel[a]);
   }
-  __syncthreads();
+  MRE_SYNC();
   if (l < 36) {
     const int r = l / 6, cc = l % 6;
     float sum = 0.f;
@@ -154,12 +154,12 @@ MRE_PHASE_FN void osc_compute(const DevModel* M, Sm& s, OscSm& o, const OscConfi
     o.F[k] = (k < 3) ? c.kp_pos * o.ep[k] + c.kd_pos * (tgt[7 + k] - o.xd[k])
                      : c.kp_ori * o.eo[k - 3] + c.kd_ori * (tgt[10 + k - 3] - o.xd[k]);
   }
-  __syncthreads();
+  MRE_SYNC();
   const float det = gauss_jordan_inplace<6, 6>(&o.Lam[0][0], l);  // o.Lam <- inv(L^-1)
   const bool use_pinv = c.pinv_always || !(fabsf(det) >= 1e-2f);
   if (use_pinv) {
     if (l == 0) sym_pinv6_serial(&o.Li[0][0], &o.Lam[0][0], &o.V[0][0], o.w, &o.Jbar[0][0] /* free until Jbar is formed */, 1e-2f);
-    __syncthreads();
+    MRE_SYNC();
   }
   if (l < 6) {
     float sum = 0.f;
@@ -172,19 +172,19 @@ MRE_PHASE_FN void osc_compute(const DevModel* M, Sm& s, OscSm& o, const OscConfi
     for (int k = 0; k < 6; k++) sum += o.MiJt[i][k] * o.Lam[k][cc];
     o.Jbar[i][cc] = sum;
   }
-  __syncthreads();
+  MRE_SYNC();
   if (l < 6) {
     float sum = 0.f;
     for (int a = 0; a < 7; a++) sum += o.Jbar[a][l] * o.tn[a];
     o.Jbt[l] = sum;
   }
-  __syncthreads();
+  MRE_SYNC();
   if (l < 7) {
     float t = 0.f, pj = 0.f;
     for (int r = 0; r < 6; r++) { t += o.J[r][l] * o.LF[r]; pj += o.J[r][l] * o.Jbt[r]; }
     s.ctrl[l] = t + (o.tn[l] - pj) + s.qfrc_bias[l];
   }
-  __syncthreads();
+  MRE_SYNC();
 }
 
 }  // namespace mre

@@ -31,7 +31,7 @@ constexpr int TAB_ZEROS = 48;
 static_assert(TAB_BYTES == 8 * (TAB_OFF + 1) + 4 * TAB_ZEROS, "operand table size");
 
 #ifndef MRE_NEWTON
-MRE_DEV void build_schedule(const DevModel* M, Sm& s);
+MRE_DEV void build_schedule(ModelP M, Sm& s);
 #endif
 // bit of the unordered cube pair {p, q} in Sm::cpl_cubes: (0,1) (0,2) (0,3) (1,2) (1,3) (2,3)
 MRE_DEV constexpr int cube_pair_bit(int p, int q) {
@@ -43,7 +43,7 @@ MRE_DEV float prop_invM(const Sm& s, int p, int k) {
   return 1.0f / ((k < 3) ? s.prop_mass[p] : s.prop_inertia[p][k - 3]);
 }
 
-MRE_DEV void geom_pose(const DevModel* M, const Sm& s, int g, float* p, float* R, float* size,
+MRE_DEV void geom_pose(ModelP M, const Sm& s, int g, float* p, float* R, float* size,
                        float* rbound) {
   const int b = M->geom_body[g];
   float tmp[3], q[4];
@@ -66,63 +66,104 @@ MRE_DEV void geom_pose(const DevModel* M, const Sm& s, int g, float* p, float* R
 // only (dist < margin - gap), in pair order, capped at NCON_MAX.
 // detect: keep every DETECTED contact (dist < margin: what physics.data.contact lists,
 // environment/prop_initializer.py:121-140) instead of the active ones (dist < margin - gap)
-MRE_PHASE_FN void collide(const DevModel* M, Sm& s, int l, bool detect) {
+// centre and bounding radius of geom g (the part of geom_pose the broad phase needs)
+MRE_DEV void geom_center(ModelP M, const Sm& s, int g, float* p, float* rbound) {
+  const int b = M->geom_body[g];
+  float tmp[3];
+  m3mulv(tmp, s.xmat[b], M->geom_pos[g]);
+  v3add(p, s.xpos[b], tmp);
+  const int pid = M->geom_propid[g];
+  *rbound = pid >= 0 ? v3norm(s.prop_size[pid]) : M->geom_rbound[g];
+}
+
+// Two stages.  Broad phase: lane = entry of the static pair table (one wave-wide pass per 64 pairs), bounding
+// sphere / plane distance test on the geom centres only, survivors compacted IN TABLE ORDER into a byte list.
+// Narrow phase: lane = survivor (one pass for up to 64 of them; a scene has a dozen), full geom frames,
+// box-box / plane-box, then the per-lane candidate counts are turned into output slots by a ballot prefix
+// sum, so contacts come out in pair order exactly as a pair-by-pair loop would list them.
+MRE_PHASE_FN void collide(ModelP M, Sm& s, int l, bool detect) {
   // per-lane clip buffers alias the Jacobian pools (contiguous Jp|Jr|Br, unused until assembly)
   // [JpA .. sched] is one contiguous block of arrays that are only written after collision
   static_assert(offsetof(Sm, hdr) + sizeof(((Sm*)0)->hdr) - offsetof(Sm, JpA) >= sizeof(float) * 64 * COLL_BUF,
                 "clip buffers do not fit");
+  static_assert(NPAIR <= 256 && sizeof(((Sm*)0)->iscr) >= NPAIR, "survivor list: one byte per pair");
   float* buf = &s.JpA[0][0] + l * COLL_BUF;
-  int base = 0;  // contacts kept by the earlier passes (the pair table is two waves long)
+  uint8_t* list = reinterpret_cast<uint8_t*>(s.iscr);
+  const unsigned long long lt = (1ull << l) - 1ull;   // lanes below this one
+  int nsurv = 0;
   for (int pass = 0; pass < NPAIR / 64; pass++) {
     const int pr = l + 64 * pass;
-    float normal[3] = {0.f, 0.f, 1.f};
-    int n = 0;
     const int g1 = M->pair_g1[pr], g2 = M->pair_g2[pr];
+    bool live = false;
     if (g1 >= 0) {
       const int b1 = M->geom_body[g1], b2 = M->geom_body[g2];
       if (body_is_active(M, s, b1) && body_is_active(M, s, b2)) {
-        float p1[3], R1[9], s1[3], rb1, p2[3], R2[9], s2[3], rb2;
-        geom_pose(M, s, g1, p1, R1, s1, &rb1);
-        geom_pose(M, s, g2, p2, R2, s2, &rb2);
         const float inc = detect ? M->pair_margin[pr] : M->pair_margin[pr] - M->pair_gap[pr];
-        float df[3];
+        float p1[3], p2[3], rb1, rb2, df[3];
+        geom_center(M, s, g1, p1, &rb1);
+        geom_center(M, s, g2, p2, &rb2);
         v3sub(df, p2, p1);
         if (M->geom_type[g1] == 0) {
-          float nn[3] = {R1[2], R1[5], R1[8]};
-          if (v3dot(df, nn) - rb2 <= inc) n = plane_box(p1, R1, p2, R2, s2, inc, normal, buf);
+          float q[4], R1[9];
+          qmul(q, s.xquat[b1], M->geom_quat[g1]);
+          q2mat(R1, q);
+          const float nn[3] = {R1[2], R1[5], R1[8]};
+          live = v3dot(df, nn) - rb2 <= inc;
         } else {
           const float r = rb1 + rb2 + inc;
-          if (v3dot(df, df) <= r * r) n = box_box(p1, R1, s1, p2, R2, s2, inc, normal, buf);
+          live = v3dot(df, df) <= r * r;
         }
-        // mesh stand-in pairs keep one contact (deepest point), like MuJoCo's convex-mesh test
-        if (M->pair_single[pr] && n > 1) {
-          int best = 0;
-          for (int c = 1; c < n; c++) if (cand_dist(buf, c) < cand_dist(buf, best)) best = c;
-          if (best != 0) {
-            for (int k = 0; k < 3; k++) cand_xyz(buf, 0)[k] = cand_xyz(buf, best)[k];
-            cand_dist(buf, 0) = cand_dist(buf, best);
-          }
-          n = 1;
-        }
-        // instantiate only contacts with dist < includemargin
-        int m = 0;
-        for (int c = 0; c < n; c++)
-          if (cand_dist(buf, c) < inc) {
-            if (m != c) {
-              for (int k = 0; k < 3; k++) cand_xyz(buf, m)[k] = cand_xyz(buf, c)[k];
-              cand_dist(buf, m) = cand_dist(buf, c);
-            }
-            m++;
-          }
-        n = m;
       }
     }
-    s.iscr[l] = n;
-    __syncthreads();
-    int off = base;
-    for (int k = 0; k < l; k++) off += s.iscr[k];
-    if (l == 63) {
-      const int tot = off + n;
+    const unsigned long long m = __ballot(live);
+    if (live) list[nsurv + __popcll(m & lt)] = (uint8_t)pr;
+    nsurv += __popcll(m);
+  }
+  if (l == 0) s.ncon = 0;
+  MRE_SYNC();
+  int base = 0;  // contacts kept by the earlier passes
+  for (int c0 = 0; c0 < nsurv; c0 += 64) {
+    const int pr = (c0 + l < nsurv) ? list[c0 + l] : -1;
+    float normal[3] = {0.f, 0.f, 1.f};
+    int n = 0;
+    if (pr >= 0) {
+      const int g1 = M->pair_g1[pr], g2 = M->pair_g2[pr];
+      float p1[3], R1[9], s1[3], rb1, p2[3], R2[9], s2[3], rb2;
+      geom_pose(M, s, g1, p1, R1, s1, &rb1);
+      geom_pose(M, s, g2, p2, R2, s2, &rb2);
+      const float inc = detect ? M->pair_margin[pr] : M->pair_margin[pr] - M->pair_gap[pr];
+      if (M->geom_type[g1] == 0) n = plane_box(p1, R1, p2, R2, s2, inc, normal, buf);
+      else n = box_box(p1, R1, s1, p2, R2, s2, inc, normal, buf);
+      // mesh stand-in pairs keep one contact (deepest point), like MuJoCo's convex-mesh test
+      if (M->pair_single[pr] && n > 1) {
+        int best = 0;
+        for (int c = 1; c < n; c++) if (cand_dist(buf, c) < cand_dist(buf, best)) best = c;
+        if (best != 0) {
+          for (int k = 0; k < 3; k++) cand_xyz(buf, 0)[k] = cand_xyz(buf, best)[k];
+          cand_dist(buf, 0) = cand_dist(buf, best);
+        }
+        n = 1;
+      }
+      // instantiate only contacts with dist < includemargin
+      int m = 0;
+      for (int c = 0; c < n; c++)
+        if (cand_dist(buf, c) < inc) {
+          if (m != c) {
+            for (int k = 0; k < 3; k++) cand_xyz(buf, m)[k] = cand_xyz(buf, c)[k];
+            cand_dist(buf, m) = cand_dist(buf, c);
+          }
+          m++;
+        }
+      n = m;
+    }
+    // exclusive prefix sum of n (<= 8) over the lanes, bit by bit through ballots
+    int off = base, tot = base;
+    for (int bit = 0; bit < 4; bit++) {
+      const unsigned long long m = __ballot((n >> bit) & 1);
+      off += __popcll(m & lt) << bit;
+      tot += __popcll(m) << bit;
+    }
+    if (l == 0) {
       s.ncon = tot < NCON_MAX ? tot : NCON_MAX;
       if (tot > NCON_MAX) s.overflow = 1;
     }
@@ -140,9 +181,9 @@ MRE_PHASE_FN void collide(const DevModel* M, Sm& s, int l, bool detect) {
         s.con_pair[id] = (uint8_t)pr;
       }
     }
-    __syncthreads();
-    base = s.ncon;   // (capped: once the list is full the later passes add nothing)
-    if (s.overflow) break;
+    MRE_SYNC();
+    if (tot > NCON_MAX) break;   // (overflow: the env is re-run on the large kernel, or reported)
+    base = tot;
   }
 }
 
@@ -163,7 +204,7 @@ MRE_DEV float impedance(const float* solimp, float pos, float margin) {
 }
 
 // accumulate sg * ax . (d point / d q) of a point on robot body b into Jr[rs]
-MRE_DEV void jac_robot(const DevModel* M, Sm& s, int rs, int b, const float* p, const float* ax, float sg) {
+MRE_DEV void jac_robot(ModelP M, Sm& s, int rs, int b, const float* p, const float* ax, float sg) {
   float off[3];
   v3sub(off, p, s.com_robot);
   const int n = M->chain_len[b];
@@ -237,7 +278,7 @@ MRE_PHASE_FN void solve_robot_rows(Sm& s, int l) {
 #pragma unroll
     for (int k = 0; k < NRV; k++) s.Br[rs][k] = x[k];
   }
-  __syncthreads();
+  MRE_SYNC();
 }
 
 #endif  // !MRE_NEWTON
@@ -255,7 +296,7 @@ constexpr int GRIP0 = GRIP_BODY0;
 // (the fp64 evaluation of the two `connect` rows lives next to gripper_local in mre_kernels.hip)
 
 // ------------------------- mj_makeConstraint + mj_makeImpedance + reference + project
-MRE_PHASE_FN void assemble_constraints(const DevModel* M, Sm& s, int l) {
+MRE_PHASE_FN void assemble_constraints(ModelP M, Sm& s, int l) {
   // ---- joint limits: lane = robot body; at most one side can be violated
   int lim = 0, lim_side = 0;
   if (l >= 1 && l < NRB && M->jnt_limited[l]) {
@@ -264,7 +305,7 @@ MRE_PHASE_FN void assemble_constraints(const DevModel* M, Sm& s, int l) {
     else if (M->jnt_range[l][1] - q < 0.f) { lim = 1; lim_side = 1; }
   }
   s.iscr[l] = lim;
-  __syncthreads();
+  MRE_SYNC();
   int lim_idx = 0;
   for (int k = 0; k < l; k++) lim_idx += s.iscr[k];
   if (l == 63) s.nl = lim_idx + lim;
@@ -276,7 +317,7 @@ MRE_PHASE_FN void assemble_constraints(const DevModel* M, Sm& s, int l) {
     s.con_b1[l] = (uint8_t)M->geom_body[M->pair_g1[pr]];
     s.con_b2[l] = (uint8_t)M->geom_body[M->pair_g2[pr]];
   }
-  __syncthreads();
+  MRE_SYNC();
   // ---- robot-slot assignment and capacity (serial, lane 0)
   if (l == 0) {
     const int base = 7 + s.nl;
@@ -307,14 +348,14 @@ MRE_PHASE_FN void assemble_constraints(const DevModel* M, Sm& s, int l) {
     build_schedule(M, s);
 #endif
   }
-  __syncthreads();
+  MRE_SYNC();
   const int nefc = s.nefc, nl = s.nl;
   // ---- zero robot slots and the scalar-triple records (rows past a short last triple stay 0)
   for (int e = l; e < s.nrrow * NRV; e += 64) (&s.Jr[0][0])[e] = 0.f;
 #ifndef MRE_NEWTON
   for (int e = l; e < 8 * 16; e += 64) (&s.blkrec[0][0])[e] = 0.f;
 #endif
-  __syncthreads();
+  MRE_SYNC();
   // ---- rows (lane = row)
   for (int i = l; i < nefc; i += 64) {
     int rs = HDR_NONE, pa = 0xF, pb = 0xF;
@@ -435,14 +476,14 @@ MRE_PHASE_FN void assemble_constraints(const DevModel* M, Sm& s, int l) {
     if (i >= 7 + nl && (i - 7 - nl) % 3 == 0) s.blkrec[8 + (i - 7 - nl) / 3][15] = M->pair_friction[s.con_pair[(i - 7 - nl) / 3]][0];
 #endif
   }
-  __syncthreads();
+  MRE_SYNC();
 }
 
 #ifndef MRE_NEWTON
 // second half of the assembly, after the kernel body has run solve_robot_rows (Br = M^-1 Jr'); the
 // phases do not nest calls, so none of them needs a callee-saved register (= scratch) to keep
 // state across one
-MRE_PHASE_FN void assemble_blocks(const DevModel* M, Sm& s, int l) {
+MRE_PHASE_FN void assemble_blocks(ModelP M, Sm& s, int l) {
   const int nefc = s.nefc, nl = s.nl;
   // ---- diagonal blocks of A = J M^-1 J' + R.  Contacts: 3x3 block of the contact's rows.
   // Scalar rows (equality / limit, robot-only) are grouped in consecutive triples whose
@@ -481,7 +522,7 @@ MRE_PHASE_FN void assemble_blocks(const DevModel* M, Sm& s, int l) {
     if (r == 2) { s.blkrec[slot][14] = acc[2]; }
     s.blkrec[slot][6 + r] = 1.0f / diag;
   }
-  __syncthreads();
+  MRE_SYNC();
 }
 
 MRE_DEV float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
@@ -565,7 +606,7 @@ MRE_DEV void lane_JB(const Sm& s, int row, int rs, int l, int lk, int slot, floa
 // step 1 + max(last step of every island it touches).  Blocks of one step touch disjoint
 // islands, and any two blocks sharing an island keep their sequential order, so a sweep over
 // the schedule produces exactly the iterates of the sequential Gauss-Seidel sweep.
-MRE_DEV void build_schedule(const DevModel* M, Sm& s) {
+MRE_DEV void build_schedule(ModelP M, Sm& s) {
   int* last = s.iscr;  // per-island last step (LDS; lane 0 only)
   for (int k = 0; k < 5; k++) last[k] = 0;
   const int nscalar = 7 + s.nl;
@@ -608,7 +649,7 @@ MRE_DEV void build_schedule(const DevModel* M, Sm& s) {
 
 // ------------------------------------------------------------- mj_fwdConstraint
 // On exit: s.qacc = qacc_smooth + M^-1 J' f, s.qfrc_con = J' f.
-MRE_PHASE_FN void solve_constraints(const DevModel* M, Sm& s, int l) {
+MRE_PHASE_FN void solve_constraints(ModelP M, Sm& s, int l) {
   const int nefc = s.nefc, nl = s.nl;
   const int isl = lane_island(l);
   const int ldof = lane_dof(l);
@@ -624,7 +665,7 @@ MRE_PHASE_FN void solve_constraints(const DevModel* M, Sm& s, int l) {
     jar[i] = row_dot(s, i, s.qacc_ws) - aref;
     rowB(s, i) = row_dot(s, i, s.qacc_smooth) - aref;
   }
-  __syncthreads();
+  MRE_SYNC();
   for (int i = l; i < nefc; i += 64) {
     const float D = 1.0f / rowR(s, i);
     if (i < 7) s.frc[i] = -D * jar[i];
@@ -651,7 +692,7 @@ MRE_PHASE_FN void solve_constraints(const DevModel* M, Sm& s, int l) {
       s.frc[i] = f0; s.frc[i + 1] = f1; s.frc[i + 2] = f2;
     }
   }
-  __syncthreads();
+  MRE_SYNC();
   // ---- a = M^-1 J' f, w = J' f for the warm start (lane = dof in the solver layout)
   float a = 0.f, w = 0.f;
   for (int bi = 0; bi < s.nblk; bi++) {
@@ -667,9 +708,9 @@ MRE_PHASE_FN void solve_constraints(const DevModel* M, Sm& s, int l) {
     }
   }
   if (l < NVP) s.scratch[l] = 0.f;
-  __syncthreads();
+  MRE_SYNC();
   if (lvalid) s.scratch[ldof] = a;
-  __syncthreads();
+  MRE_SYNC();
   // dual cost 0.5 f'ARf + f'b ; cold start if positive
   float part = 0.f;
   for (int i = l; i < nefc; i += 64) {
@@ -678,12 +719,12 @@ MRE_PHASE_FN void solve_constraints(const DevModel* M, Sm& s, int l) {
     part += fi * (0.5f * Af + rowB(s, i));
   }
   const float cost = wave_sum(part);
-  __syncthreads();
+  MRE_SYNC();
   if (cost > 0.f) {
     a = 0.f; w = 0.f;
     for (int i = l; i < nefc; i += 64) s.frc[i] = 0.f;
   }
-  __syncthreads();
+  MRE_SYNC();
   // ---- PGS sweeps over the island schedule
   const int nva = NRV + 6 * s.nprops;
   float msum = M->M0_diag_robot_sum;
@@ -737,7 +778,7 @@ MRE_PHASE_FN void solve_constraints(const DevModel* M, Sm& s, int l) {
     tab[TAB_OFF] = ent;
   }
   if (l < TAB_ZEROS) zeros[l] = 0.f;
-  __syncthreads();
+  MRE_SYNC();
   // per-lane constants: lanes that own no dof read the all-off entry at every step
   const bool rob_lane = l < NRV;
   const unsigned tab0 = (unsigned)(reinterpret_cast<const char*>(tab) - sb);
@@ -885,7 +926,7 @@ MRE_PHASE_FN void solve_constraints(const DevModel* M, Sm& s, int l) {
       const float au = b0r * d0 + b1 * d1 + b2 * d2;
       a += rob_lane ? (on ? au : 0.f) : linvM * wu;
       w += wu;
-      __syncthreads();
+      MRE_SYNC();
       st = st1;
       if (st1 != 0) return false;
       // end of a sweep
@@ -904,10 +945,10 @@ MRE_PHASE_FN void solve_constraints(const DevModel* M, Sm& s, int l) {
     iters = 1;
   }
   if (l < NVP) { s.qacc[l] = (l < NV) ? s.qacc_smooth[l] : 0.f; s.qfrc_con[l] = 0.f; }
-  __syncthreads();
+  MRE_SYNC();
   if (lvalid) { s.qacc[ldof] += a; s.qfrc_con[ldof] = w; }
   if (l == 0) s.solver_iters = iters;
-  __syncthreads();
+  MRE_SYNC();
 }
 
 #endif  // !MRE_NEWTON
