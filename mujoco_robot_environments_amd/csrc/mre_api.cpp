@@ -38,7 +38,6 @@ extern "C" void mre_launch_reset(const DevModel* M, int N, float* qpos, float* q
                                  float* ctrl, uint32_t* status, const uint8_t* mask,
                                  hipStream_t stream);
 
-constexpr int MAXBLK_ANY = 64;  // upper bound of the schedule length in either capacity set
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) {
@@ -201,27 +200,23 @@ static int launch_step(mre_env* e, const StepArgs& a, bool settle = false) {
         e->h_large[i] = 0; changed = true; e->n_large--; e->n_demotions++;  // back below 5/8: demote
       }
     }
-    // Dispatch order for the next launch: a launch ends with its slowest wavefront, and an env's
-    // time is set by the length of its Gauss-Seidel schedule (robot contacts are sequential), so the
-    // envs with the longest schedules go first (counting sort, stable; results do not depend on it).
+    // Dispatch order for the next launch: a launch ends with its slowest wavefront, and the hardware hands
+    // workgroups to free slots in index order, so the envs that took longest in this launch (the kernel
+    // reports each env's own duration, s_memtime ticks >> 10) go first in the next one -- longest
+    // processing time first.  Counting sort over 256 duration buckets, stable; results do not depend on it.
     if (!e->use_order) {
-      int count[MAXBLK_ANY + 2] = {0};
-      bool any_long = false;
-      for (size_t i = 0; i < N; i++) {
-        const int li1 = e->h_launch_info[4 * i + 1];
-        int c = e->h_launch_info[4 * i] < 0 ? 0 : (li1 >> 16);
-        if (c > MAXBLK_ANY) c = MAXBLK_ANY;
-        if (c > 8) any_long = true;
-        count[MAXBLK_ANY - c + 1]++;
-      }
-      if (any_long) {
-        for (int k = 1; k <= MAXBLK_ANY + 1; k++) count[k] += count[k - 1];
-        for (size_t i = 0; i < N; i++) {
-          const int li1 = e->h_launch_info[4 * i + 1];
-          int c = e->h_launch_info[4 * i] < 0 ? 0 : (li1 >> 16);
-          if (c > MAXBLK_ANY) c = MAXBLK_ANY;
-          e->h_auto_order[count[MAXBLK_ANY - c]++] = (int)i;
-        }
+      int kmax = 0;
+      for (size_t i = 0; i < N; i++)
+        if (e->h_launch_info[4 * i] >= 0) { const int k = e->h_launch_info[4 * i + 1] >> 16; if (k > kmax) kmax = k; }
+      if (kmax > 0) {
+        int count[258] = {0};
+        auto bucket = [&](size_t i) {
+          const int k = e->h_launch_info[4 * i] < 0 ? 0 : (e->h_launch_info[4 * i + 1] >> 16);
+          return (int)((long long)k * 255 / kmax);
+        };
+        for (size_t i = 0; i < N; i++) count[255 - bucket(i) + 1]++;
+        for (int k = 1; k <= 256; k++) count[k] += count[k - 1];
+        for (size_t i = 0; i < N; i++) e->h_auto_order[count[255 - bucket(i)]++] = (int)i;
         // (the pinned staging buffer is rewritten only after the next launch's read-back sync)
         HIPCHK(hipMemcpyAsync(e->auto_order, e->h_auto_order, N * 4, hipMemcpyHostToDevice, e->stream));
         e->have_auto_order = true;

@@ -169,9 +169,9 @@ struct StepArgs {
   float* contacts;           // [N][1 + 3 * CONTACT_EXPORT] or null (F_DETECT): count, then (geom1, geom2, dist) each
   int* settle_steps;         // [N] or null (F_SETTLE_EXIT): physics steps the env took in this launch
   int min_settle_steps;
-  int* launch_info;          // [N][4] or null: {overflowed in this launch, max ncon | max schedule
-                             //  length << 16, max nefc, max robot rows | max cube-cube contacts << 16}
-                             //  over the launch's steps
+  int* launch_info;          // [N][4] or null: {overflowed in this launch, max ncon | the env's own duration
+                             //  in this launch (s_memtime ticks >> 10) << 16, max nefc, max robot rows | max cube-cube
+                             //  contacts << 16} over the launch's steps
 };
 
 // Rejection sampling of a cube pose (k_pose_search): PropPlacer.__call__'s per-prop loop

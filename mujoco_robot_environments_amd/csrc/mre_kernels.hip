@@ -910,7 +910,9 @@ MRE_DEV void step_body(const StepArgs& a, Sm& s) {
   bool arm_converged = (a.flags & F_CONV_CONTINUE) != 0 && a.converged != nullptr && a.converged[env] != 0;
   float grip_cmd = 0.f;
   const OscConfig* oscp = a.osc + (size_t)env * a.osc_stride;  // per-env gains when tuning a population
-  int hw_ncon = 0, hw_nefc = 0, hw_nrrow = 0, hw_npp = 0, hw_nsched = 0;  // high-water marks of this launch
+  int hw_ncon = 0, hw_nefc = 0, hw_nrrow = 0, hw_npp = 0;  // high-water marks of this launch
+  // the env's own duration in this launch is the cost key of the heavy-first dispatch of the next one
+  const unsigned long long launch_t0 = __builtin_amdgcn_s_memtime();
   if (a.mode == CTRL_OSC) {
     if (l < 16) s.osc_tgt[l] = a.osc_target[(size_t)env * 16 + l];
     // MinMax.compute_control_output: max_val 255 (closed) / min_val 0 (open), min_max.yaml:3-4
@@ -954,7 +956,7 @@ MRE_DEV void step_body(const StepArgs& a, Sm& s) {
       assemble_blocks(M, s, l);
 #endif
       MRE_STAMP(3);
-      hw_ncon = max(hw_ncon, s.ncon); hw_nefc = max(hw_nefc, s.nefc); hw_nsched = max(hw_nsched, s.nsched);
+      hw_ncon = max(hw_ncon, s.ncon); hw_nefc = max(hw_nefc, s.nefc);
       hw_nrrow = max(hw_nrrow, s.nrrow); hw_npp = max(hw_npp, s.npp);
     }
 
@@ -1086,7 +1088,8 @@ MRE_DEV void step_body(const StepArgs& a, Sm& s) {
   if (l < NU) a.ctrl[(size_t)env * NU + l] = s.ctrl[l];
   if (l == 0 && a.launch_info != nullptr) {
     int* li = a.launch_info + (size_t)env * 4;
-    li[0] = s.overflow; li[1] = hw_ncon | (hw_nsched << 16); li[2] = hw_nefc; li[3] = hw_nrrow | (hw_npp << 16);
+    const unsigned long long dt = (__builtin_amdgcn_s_memtime() - launch_t0) >> 10;
+    li[0] = s.overflow; li[1] = hw_ncon | ((int)(dt < 0x7FFFull ? dt : 0x7FFFull) << 16); li[2] = hw_nefc; li[3] = hw_nrrow | (hw_npp << 16);
   }
   if (l == 0 && a.status != nullptr) {
     unsigned st = 0;
