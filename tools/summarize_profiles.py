@@ -19,6 +19,7 @@ from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNELS = {"PGS": "mre::k_step(", "Newton": "mre::k_step_newton("}
 KERNEL = KERNELS["PGS"]
+WARMUP = 20  # bench.py default --warmup
 
 
 def one(pattern):
@@ -32,7 +33,10 @@ def counter_rows(d):
     path = one(os.path.join(d, "**", "*counter_collection.csv"))
     with open(path) as f:
         rows = [r for r in csv.DictReader(f) if r["Kernel_Name"].startswith(KERNEL)]
-    return path, rows
+    # the first WARMUP dispatches of the kernel are the bench's untimed warm-up launches
+    ids = sorted({int(r["Dispatch_Id"]) for r in rows})
+    keep = set(ids[WARMUP:]) if len(ids) > WARMUP else set(ids)
+    return path, [r for r in rows if int(r["Dispatch_Id"]) in keep]
 
 
 def main():
@@ -45,7 +49,7 @@ def main():
     shutil.copy(one(os.path.join(stats_d, "**", "*kernel_stats.csv")), os.path.join(out, f"{tag}_kernel_stats{sfx}.csv"))
     summary = {
         "command": f"rocprofv3 --pmc <COUNTERS> --kernel-trace --output-format csv -- python bench.py --solver {solver} "
-                   "--steps 10 --warmup 2 --no-cpu-baseline (separate passes: FETCH_SIZE | WRITE_SIZE | SQ_* | "
+                   "--no-cpu-baseline (20 warm-up launches dropped, 200 timed launches averaged; separate passes: FETCH_SIZE | WRITE_SIZE | SQ_* | "
                    "SQ_INSTS_VALU_*_F32/F64)",
         "kernel": KERNEL.rstrip("("), "launch": "1 control tick = 5 physics steps x 4096 envs", "build": note}
     passes = [("fetch", fetch_d), ("write", write_d), ("sq", sq_d)]
@@ -61,8 +65,12 @@ def main():
             w.writeheader()
             w.writerows(rows)
         acc = defaultdict(list)
+        dur = {}
         for r in rows:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+            dur[r["Dispatch_Id"]] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+        summary[f"avg_launch_ms_in_{name}_pass"] = sum(dur.values()) / len(dur)
+        summary[f"launches_in_{name}_pass"] = len(dur)
         for k, v in sorted(acc.items()):
             summary[f"{k}_per_launch"] = sum(v) / len(v)
         summary["LDS_Block_Size"] = int(rows[0]["LDS_Block_Size"])
@@ -73,6 +81,10 @@ def main():
     summary["hbm_write_bytes_per_launch"] = summary["WRITE_SIZE_per_launch"] * 1024.0
     summary["traffic_bytes_per_launch"] = summary["hbm_read_bytes_per_launch"] + summary["hbm_write_bytes_per_launch"]
     g = lambda k: summary.get(f"SQ_INSTS_VALU_{k}_per_launch", 0.0)
+    if "SQ_INSTS_VALU_per_launch" in summary:
+        # VALU issue: a wave64 VALU instruction holds its SIMD for 4 cycles; 1024 SIMDs at 2.4 GHz
+        t = summary["avg_launch_ms_in_sq_pass"] * 1e-3
+        summary["valu_issue_util_in_sq_pass"] = summary["SQ_INSTS_VALU_per_launch"] * 4.0 / (1024 * 2.4e9 * t)
     if "SQ_INSTS_VALU_FMA_F32_per_launch" in summary:
         # counted FLOPs: every counted wave instruction at its full 64 lanes (exec masks are not
         # visible to the counter), FMA = 2
