@@ -103,8 +103,21 @@ class BatchedPhysics:
         check(_lib.lib().mre_set_props(self._h, _ptr(n), _ptr(s)), "mre_set_props")
         self.sync()
 
+    def _mask(self, mask):
+        """uint8 [N] mask as numpy (host) or a CUDA torch tensor (device pointer handed over as is)."""
+        if mask is None:
+            return None
+        if isinstance(mask, torch.Tensor):
+            m = mask.to(torch.uint8).contiguous()
+            assert tuple(m.shape) == (self.num_envs,)
+            if m.is_cuda:
+                self._after_torch(m)
+                return m
+            return m.numpy()
+        return np.ascontiguousarray(mask, np.uint8)
+
     def reset(self, mask=None) -> None:
-        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        m = self._mask(mask)
         check(_lib.lib().mre_reset(self._h, _ptr(m)), "mre_reset")
         self.sync()
 
@@ -127,7 +140,7 @@ class BatchedPhysics:
 
     def place_props(self, seed: int, ws_min, ws_max, mask=None, max_attempts: int = 1000,
                     settle_steps: int = 300) -> None:
-        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        m = self._mask(mask)
         lo = np.ascontiguousarray(ws_min, np.float32)
         hi = np.ascontiguousarray(ws_max, np.float32)
         check(_lib.lib().mre_place_props(self._h, _ptr(m), int(seed), _ptr(lo), _ptr(hi),

@@ -258,3 +258,62 @@ def test_run_controller_in_chunks_equals_one_launch(compiled_model, monkeypatch)
     for chunk in ("50", "7"):
         for k in range(4):
             assert np.array_equal(out["0"][k], out[chunk][k]), (chunk, k)
+
+
+def test_reset_with_a_device_mask_and_control_from_a_fresh_torch_tensor(compiled_model, monkeypatch):
+    """include/mre.h: masks are `host or device`; controls produced by torch ops on torch's stream a
+    moment ago must be ordered before the handle's stream reads them (mre_wait_stream), also when no
+    guarded launch host-syncs in between (MRE_NO_FALLBACK=1)."""
+    import torch
+    from mujoco_robot_environments_amd.physics import BatchedPhysics
+    A, _ = compiled_model
+    monkeypatch.setenv("MRE_NO_FALLBACK", "1")
+    N = 256
+    phys = BatchedPhysics(N, model=A)
+    phys.reset()
+    q0 = phys.qpos().copy()
+    big = torch.randn(4096, 4096, device=phys.device)
+    for it in range(3):
+        # a long matmul keeps torch's stream busy; the control is its by-product
+        big = (big @ big).tanh()
+        ctrl = (big[:N, :8] * 0 + float(it + 1)).contiguous()
+        phys.set_control(ctrl)
+        del ctrl                      # the caching allocator may hand the block out again
+        _ = torch.full((N, 8), -99.0, device=phys.device)
+        phys.step(1)
+    phys.sync()
+    # the last applied control is what the kernel read
+    c = phys.ctrl() if hasattr(phys, "ctrl") else None
+    if c is not None:
+        assert np.allclose(c[:, :7], 3.0)
+    q1 = phys.qpos()
+    assert np.isfinite(q1).all() and not np.array_equal(q0, q1)
+    # reset through a CUDA uint8 mask: odd envs go back to the start state, even envs stay
+    mask = (torch.arange(N, device=phys.device) % 2).to(torch.uint8)
+    phys.reset(mask=mask)
+    q2 = phys.qpos()
+    assert np.array_equal(q2[0::2], q1[0::2])
+    assert np.array_equal(q2[1::2][:, :7], q0[1::2][:, :7])
+    phys.close() if hasattr(phys, "close") else None
+
+
+def test_bench_two_rank_rehearsal_on_one_gpu():
+    """`python bench.py --gpus 2` as the driver's launcher would run it, rehearsed on one card: two
+    ranks (gloo instead of RCCL, both pinned to device 0) shard 2 x 4096 envs by global env id, time
+    the same K steps between barriers, and rank 0 prints the one JSON line with the whole-job rate."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MRE_BENCH_BACKEND="gloo", MRE_BENCH_DEVICE="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+                          "--no-cpu-baseline", "--solver", "PGS"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["envs_per_gpu"] == 4096
+    # value = units all ranks processed / max-over-ranks time
+    assert abs(d["value"] - 2 * 4096 * 5 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
