@@ -337,8 +337,11 @@ def main():
                          "kernel": kname, "avg_launch_ms": avg_launch_s * 1e3, "launches": launches,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "valu_issue": valu_issue(avg_launch_s, solver) if pmc else None,
-                         "note": "the path is bound by VALU issue, not by HBM: per-env state stays in LDS across the "
-                                 "5 fused steps (see valu_issue)"},
+                         "note": ("HBM is not the bound: per-env state stays in LDS across the 5 fused steps. PGS: VALU "
+                                  "issue (see valu_issue; the 100 sweeps are 81 % of a tick)" if solver == "PGS" else
+                                  "HBM is not the bound: per-env state stays in LDS across the 5 fused steps. Newton: "
+                                  "dependent LDS round trips at 2 waves/SIMD (waves parked in s_waitcnt 43 % of their "
+                                  "cycles, SQ_WAIT_ANY; VALU issue in valu_issue)")},
             "health": {"nan_envs": int(((status & 2) != 0).sum()), "overflow_envs": int(((status & 4) != 0).sum()),
                        "mean_ncon": float(stats[:, 0].mean()), "mean_nefc": float(stats[:, 1].mean()),
                        "mean_solver_iters": float(stats[:, 2].mean()), "max_solver_iters": int(stats[:, 2].max()),
