@@ -35,7 +35,7 @@ elif sys.argv[1] == "run":
             env = dict(os.environ, MRE_LIB=os.path.join(DIAG, f"libmre_stamps{k}.so"))
             out = subprocess.check_output([sys.executable, __file__, "run"] + sys.argv[2:], env=env, text=True)
             tot += [float(x) for x in out.split()[-4:]]
-        s = sum(tot[:8])
+        s = sum(tot[:12]) if solver == "Newton" else sum(tot[:8])   # (the position sub-buckets repeat bucket 0)
         print(f"solver {solver}: cycles / 16 per env and tick (5 steps), share of the tick")
         names = NAMES if solver == "Newton" else NAMES[:8] + NAMES[12:]
         for n, v in zip(names, tot):
