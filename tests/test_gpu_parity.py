@@ -27,9 +27,13 @@ def _oracle_envs(oracle_model, nprops, sizes):
 
 
 def _rollout_both(compiled_model, oracle_model, N, T, flags, scale, seed=0, no_constraints=False,
-                  control_steps=5, z_extra=0.0, gravity_comp=False, yaw=False, solver=None, census=False):
+                  control_steps=5, z_extra=0.0, gravity_comp=False, yaw=False, solver=None, census=False,
+                  fp32_state=False):
     """census=True also returns, per step and env, the constraint census the solve of that step saw
-    (active contacts + 64 * bit mask of the joints at a limit), device and oracle."""
+    (active contacts + 64 * bit mask of the joints at a limit), device and oracle.
+    fp32_state=True also returns the qpos trace of a SECOND fp64 oracle run whose state (qpos, qvel,
+    warm start) is rounded to float32 after every step -- all arithmetic still fp64: the part of the
+    device-vs-oracle gap that any implementation holding its state in fp32 has."""
     import torch
     from mujoco_robot_environments_amd import rng
     A, _ = compiled_model
@@ -78,6 +82,29 @@ def _rollout_both(compiled_model, oracle_model, N, T, flags, scale, seed=0, no_c
                 ocen[t * control_steps + k, i] = e.census   # the rows the coming solve will see
                 e.step(1)
                 oq[t * control_steps + k, i] = e.arr("qpos")[:43]
+    if fp32_state:
+        import concurrent.futures as cf
+
+        def rounded(i):
+            e = _oracle_envs(oracle_model, nprops[i:i + 1], sizes[i:i + 1])[0]
+            e.no_constraints(no_constraints)
+            if solver is not None:
+                e.set_solver(solver)
+            e.arr("qpos")[:43] = q0[i]
+            e.forward()
+            out = np.zeros((T * control_steps, 43))
+            for t in range(T):
+                e.arr("ctrl")[:] = acts32[t, i]
+                for k in range(control_steps):
+                    e.step(1)
+                    for nm in ("qpos", "qvel", "qacc_warmstart"):
+                        v = e.arr(nm)
+                        v[:] = v.astype(np.float32)
+                    out[t * control_steps + k] = e.arr("qpos")[:43]
+            return out
+        with cf.ThreadPoolExecutor(8) as ex:   # ctypes releases the GIL
+            bq = np.stack(list(ex.map(rounded, range(N))), axis=1)
+        return gq, oq, nprops, phys, gcen, ocen, bq
     if census:
         return gq, oq, nprops, phys, gcen, ocen
     return gq, oq, nprops, phys
