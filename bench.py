@@ -53,8 +53,11 @@ def pmc_summary(solver="PGS"):
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* runs of this same bench command); the counters cannot
     be read from inside the process, so the per-launch figures are carried over."""
     import glob
+    import re
     sfx = "_pmc_summary.json" if solver == "PGS" else "_pmc_summary_newton.json"
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*" + sfx)))
+    # rNNx_pmc_summary[_newton].json only (other summaries in profiles/ describe other kernels)
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*" + sfx))
+                   if re.fullmatch(r"r\d\d[a-z]" + re.escape(sfx), os.path.basename(f)))
     if not files:
         return {}, None
     with open(files[-1]) as f:
@@ -338,7 +341,7 @@ def main():
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "valu_issue": valu_issue(avg_launch_s, solver) if pmc else None,
                          "note": ("HBM is not the bound: per-env state stays in LDS across the 5 fused steps. PGS: VALU "
-                                  "issue (see valu_issue; the 100 sweeps are 81 % of a tick)" if solver == "PGS" else
+                                  "issue (see valu_issue; the 100 sweeps are 82 % of a tick)" if solver == "PGS" else
                                   "HBM is not the bound: per-env state stays in LDS across the 5 fused steps. Newton: "
                                   "dependent LDS round trips at 2 waves/SIMD (waves parked in s_waitcnt 43 % of their "
                                   "cycles, SQ_WAIT_ANY; VALU issue in valu_issue)")},

@@ -20,7 +20,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     out[c.split("_")[0].lower() + "_bytes_per_pixel"] = sum(v) / len(v) * 1024.0 / out["pixels"]
 out["bench_256"] = json.load(open("gpurun_out/render_${T}_256.json"))
 out["bench_4096"] = json.load(open("gpurun_out/render_${T}_4096.json"))
-json.dump(out, open("gpurun_out/render_${T}_pmc_summary.json", "w"), indent=1)
+json.dump(out, open("gpurun_out/render_${T}_hbm_counters.json", "w"), indent=1)
 print(json.dumps({k: v for k, v in out.items() if not k.startswith("bench")}))
 print(out["bench_256"]["ms_per_batch_frame"], out["bench_4096"]["ms_per_batch_frame"], out["bench_4096"]["roofline"]["frac"])
 PY
