@@ -1288,6 +1288,16 @@ extern "C" int mre_sort_colours(mre_env* e, uint64_t seed, const int32_t* call_c
   return copy_out(e, attempts, e->ps_attempts, N * 4);
 }
 
+// Per-env record of the last guarded launch (the rows the capacity fallback and the dispatch order read):
+// info[i] = {overflow flag (-1: env was not part of the launch), max contacts | duration << 16 (s_memtime
+// ticks >> 10), max constraint rows, max robot rows | max cube-cube contacts << 16}.
+extern "C" int mre_get_launch_info(mre_env* e, int32_t* info) {
+  if (!e || !info) return fail(MRE_ERR_ARG, "mre_get_launch_info: null");
+  HIPCHK(hipSetDevice(e->device));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return copy_out(e, info, e->h_launch_info, (size_t)e->N * 16);
+}
+
 extern "C" int mre_set_env_ids(mre_env* e, const long long* ids) {
   if (!e) return fail(MRE_ERR_ARG, "null handle");
   if (ids) e->env_ids.assign(ids, ids + e->N); else e->env_ids.clear();

@@ -903,6 +903,9 @@ MRE_DEV void step_body(const StepArgs& a, Sm& s) {
   }
   MRE_SYNC();
 
+#if defined(MRE_PHASE_STAMPS) && defined(MRE_NEWTON) && MRE_PHASE_STAMPS == 4
+  if (l < 4) nw_dir_acc[l] = 0ull;
+#endif
 #ifdef MRE_PHASE_STAMPS
   unsigned long long stamp_acc[4] = {0, 0, 0, 0};
   unsigned long long stamp_t = __builtin_amdgcn_s_memtime();
@@ -1101,6 +1104,9 @@ MRE_DEV void step_body(const StepArgs& a, Sm& s) {
       a.stats[env * 4 + 2] = s.solver_iters; a.stats[env * 4 + 3] = s.nl;
 #ifdef MRE_PHASE_STAMPS
       for (int k = 0; k < 4; k++) a.stats[env * 4 + k] = (int)(stamp_acc[k] >> 4);
+#if defined(MRE_NEWTON) && MRE_PHASE_STAMPS == 4
+      for (int k = 0; k < 4; k++) a.stats[env * 4 + k] = (int)(nw_dir_acc[k] >> 4);
+#endif
 #endif
     }
   }

@@ -327,7 +327,16 @@ MRE_PHASE_FN float nw_setup(ModelP M, Sm& s, int l) {
 
 // Phase 2: search = -H^-1 grad.  H = M + J' D J (+ cone Hessians) with its rows in registers,
 // block-sparse factorisation H = W W', both triangular solves.
+#if defined(MRE_PHASE_STAMPS) && MRE_PHASE_STAMPS == 4
+__shared__ unsigned long long nw_dir_acc[4];   // diagnostic builds only: time inside nw_direction by part
+#define NW_DIR_STAMP(k) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); if (l == 0) nw_dir_acc[k] += n_ - t_; t_ = n_; } while (0)
+#else
+#define NW_DIR_STAMP(k) do {} while (0)
+#endif
 MRE_PHASE_FN void nw_direction(ModelP M, Sm& s, int l) {
+#if defined(MRE_PHASE_STAMPS) && MRE_PHASE_STAMPS == 4
+  unsigned long long t_ = __builtin_amdgcn_s_memtime();
+#endif
   const NwLane c = nw_lane(M, s, l);
   const int nefc = s.nefc, nscalar = 7 + s.nl, nprops = s.nprops;
   const int lp = c.lp, lk = c.lk;
@@ -339,47 +348,83 @@ MRE_PHASE_FN void nw_direction(ModelP M, Sm& s, int l) {
     else if (l == k) v = c.lact ? c.mdiag : 1.0f;
     hh[k] = v;
   }
-  // Row metadata goes to registers first (lane r of chunk k = row 64 k + r): the pass over the rows
-  // then takes header and 1 / R by v_readlane instead of two dependent LDS round trips per row, and
-  // visits only the rows in the quadratic state (ballot masks).  The Jacobian entry of the NEXT row
-  // is loaded while the rank-1 update of the current one runs.
-  constexpr int NCH = (NEFC_MAX + 63) / 64;
-  int meta[NCH];
-  float dv[NCH];
-  unsigned long long mq[NCH];
+  // ---- J' diag(D) J over the rows in the quadratic state: a genuine contraction (39 x nefc times nefc x 39),
+  // done on the matrix cores.  The 39 dofs are laid out in three 16-wide tiles (0: robot dofs 0..14, 1: cubes 0
+  // and 1, 2: cubes 2 and 3; 6 dofs each, the rest padding); v_mfma_f32_16x16x4_f32 consumes four rows per
+  // issue: operand lane 16 k + m holds row r0 + k at tile dof m (A = J D, B = J), and the six tiles of the lower
+  // triangle accumulate in 24 registers.  Per chunk of four rows a lane fetches its row's header, state and 1 / R
+  // and ONE Jacobian word per tile -- no per-row branches, no cross-lane traffic.  Rows in any other state
+  // enter with D = 0 (cone contacts are added below with their 3 x 3 Hessian).
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  v4f c00 = {0.f, 0.f, 0.f, 0.f}, c10 = c00, c11 = c00, c20 = c00, c21 = c00, c22 = c00;
+  {
+    const int g = l >> 4, m16 = l & 15;
+    const int tp = m16 < 12 ? m16 / 6 : -1;   // cube of this lane's dof in tile 1 (tile 2: tp + 2)
+    const int tk = m16 % 6;
+    for (int r0 = 0; r0 < nefc; r0 += 4) {
+      const int i = r0 + g;
+      const bool on = i < nefc && s.rstate[i < nefc ? i : 0] == NW_QUAD;
+      const int ii = on ? i : 0;
+      const int h = s.hdr[ii];
+      const float D = on ? 1.0f / s.efc_R[ii] : 0.f;
+      const int rs = h & 0xFF, pa = (h >> 8) & 0xF, pb = (h >> 12) & 0xF;
+      const int cr = ii - nscalar;   // contact row index (prop parts exist for contact rows only)
+      float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+      if (on) {
+        if (rs != HDR_NONE && m16 < NRV) v0 = s.Jr[rs][m16];
+        if (tp >= 0) {
+          if (pa == tp) v1 = s.JpA[cr][tk];
+          else if (pb == tp) v1 = s.JpB[3 * s.con_bslot[cr / 3] + cr % 3][tk];
+          if (pa == tp + 2) v2 = s.JpA[cr][tk];
+          else if (pb == tp + 2) v2 = s.JpB[3 * s.con_bslot[cr / 3] + cr % 3][tk];
+        }
+      }
+      const float a0 = v0 * D, a1 = v1 * D, a2 = v2 * D;
+      c00 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, v0, c00, 0, 0, 0);
+      c10 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, v0, c10, 0, 0, 0);
+      c11 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, v1, c11, 0, 0, 0);
+      c20 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, v0, c20, 0, 0, 0);
+      c21 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, v1, c21, 0, 0, 0);
+      c22 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, v2, c22, 0, 0, 0);
+    }
+    // Tiles -> rows: lane j needs row j of H.  One tile at a time through LDS (the factor's home, unused until
+    // the elimination is over): the accumulator of lane 16 q + n holds C[4 q + v][n], v = 0..3.  The lanes that
+    // own the tile's row dofs read a row, and for an off-diagonal tile the lanes that own its column dofs
+    // read a column (H is symmetric).
+    float* T = s.W;
+    constexpr int TS = 17;
+    // this lane's tile and index in it (lane = dof)
+    const int mytile = l < NRV ? 0 : (l < NRV + 12 ? 1 : (l < NV ? 2 : -1));
+    const int mym = l < NRV ? l : (l < NRV + 12 ? l - NRV : l - NRV - 12);
+    auto spill = [&](const v4f& cv) {
 #pragma unroll
-  for (int k = 0; k < NCH; k++) {
-    const int i = 64 * k + l;
-    const bool on = i < nefc;
-    const int st = on ? (int)s.rstate[i] : NW_SAT;
-    meta[k] = on ? (int)s.hdr[i] : 0;
-    dv[k] = on ? 1.0f / s.efc_R[i] : 0.f;
-    mq[k] = __ballot(st == NW_QUAD);
+      for (int v = 0; v < 4; v++) T[(4 * g + v) * TS + m16] = cv[v];
+    };
+    // (TI, TJ): tile row / column block; BI, BJ: first hh index of the blocks; NI, NJ: dofs in them
+#define NW_TILE(CV, TI, TJ, BI, NI, BJ, NJ)                                               \
+    spill(CV);                                                                            \
+    MRE_SYNC();                                                                           \
+    if (mytile == TI) {                                                                   \
+      _Pragma("unroll") for (int n = 0; n < NJ; n++) hh[BJ + n] += T[mym * TS + n];       \
+    }                                                                                     \
+    if (TI != TJ && mytile == TJ) {                                                       \
+      _Pragma("unroll") for (int q = 0; q < NI; q++) hh[BI + q] += T[q * TS + mym];       \
+    }                                                                                     \
+    MRE_SYNC();
+    NW_TILE(c00, 0, 0, 0, NRV, 0, NRV)
+    if (nprops > 0) {
+      NW_TILE(c10, 1, 0, NRV, 12, 0, NRV)
+      NW_TILE(c11, 1, 1, NRV, 12, NRV, 12)
+    }
+    if (nprops > 2) {
+      NW_TILE(c20, 2, 0, NRV + 12, 12, 0, NRV)
+      NW_TILE(c21, 2, 1, NRV + 12, 12, NRV, 12)
+      NW_TILE(c22, 2, 2, NRV + 12, 12, NRV + 12, 12)
+    }
+#undef NW_TILE
   }
   const unsigned long long mcone = __ballot(l < s.ncon && s.rstate[nscalar + 3 * (l < s.ncon ? l : 0)] == NW_CONE);
-#pragma unroll
-  for (int k = 0; k < NCH; k++) {
-    unsigned long long m = mq[k];
-    if (m == 0ull) continue;
-    int r = __builtin_ctzll(m);
-    m &= m - 1ull;
-    int h = __builtin_amdgcn_readlane(meta[k], r);
-    float J = nw_Jl(s, 64 * k + r, h, l, lp, lk);
-    while (true) {
-      const float D = rdlane(dv[k], r);
-      const int hc = h;
-      const float Jc = J;
-      const bool more = m != 0ull;
-      if (more) {
-        r = __builtin_ctzll(m);
-        m &= m - 1ull;
-        h = __builtin_amdgcn_readlane(meta[k], r);
-        J = nw_Jl(s, 64 * k + r, h, l, lp, lk);
-      }
-      nw_rank1(hh, Jc * D, Jc, (hc & 0xFF) != HDR_NONE, (hc >> 8) & 0xF, (hc >> 12) & 0xF);
-      if (!more) break;
-    }
-  }
+  NW_DIR_STAMP(0);
   // contacts in the middle zone: J_c' H_c J_c with the 3 x 3 cone Hessian
   for (unsigned long long m = mcone; m != 0ull; m &= m - 1ull) {
     const int cc = __builtin_ctzll(m);
@@ -398,6 +443,7 @@ MRE_PHASE_FN void nw_direction(ModelP M, Sm& s, int l) {
     nw_rank1(hh, t1, J1, has_r, pa, pb);
     nw_rank1(hh, t2, J2, has_r, pa, pb);
   }
+  NW_DIR_STAMP(1);
   // symbolic elimination over the blocks (node 0 robot, node 1 + p cube p), cubes last to first
   unsigned adj[5];
   {
@@ -427,6 +473,7 @@ MRE_PHASE_FN void nw_direction(ModelP M, Sm& s, int l) {
   if (nprops > 1) nw_elim_range<NRV + 11, NRV + 6>(hh, g, y, dinv, l, adj[2] & 0x3u);
   if (nprops > 0) nw_elim_range<NRV + 5, NRV>(hh, g, y, dinv, l, adj[1] & 0x1u);
   nw_elim_range<NRV - 1, 0>(hh, g, y, dinv, l, 0u);
+  NW_DIR_STAMP(2);
   // ---- W' x = y: columns of W through LDS (packed by columns: (j, k), j <= k at k(k+1)/2 + j)
 #pragma unroll
   for (int k = 0; k < NV; k++)
@@ -447,6 +494,7 @@ MRE_PHASE_FN void nw_direction(ModelP M, Sm& s, int l) {
   const float dec = wave_sum((l < NVP ? s.nw_grad[l] : 0.f) * x);
   if (l == 0) s.scratch[2] = dec;
   MRE_SYNC();
+  NW_DIR_STAMP(3);
 }
 
 // Phase 2': the same direction from the factor of the last nw_direction call (still in s.W), for a

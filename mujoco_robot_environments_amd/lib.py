@@ -26,7 +26,7 @@ EXPORTS = [
     "mre_set_trace", "mre_osc_set_target", "mre_osc_configure", "mre_gripper_set",
     "mre_run_controller", "mre_get_sites", "mre_get_status", "mre_get_solver_stats",
     "mre_profile_enable", "mre_profile_read", "mre_set_env_id_offset", "mre_set_env_order",
-    "mre_set_fallback", "mre_get_fallback_stats", "mre_set_solver", "mre_get_solver", "mre_wait_stream", "mre_osc_compute", "mre_get_contacts", "mre_get_settle_steps", "mre_prop_place", "mre_sort_colours", "mre_crc32c", "mre_osc_configure_env", "mre_set_env_ids", "mre_set_render_colours", "mre_render",
+    "mre_set_fallback", "mre_get_fallback_stats", "mre_set_solver", "mre_get_solver", "mre_wait_stream", "mre_osc_compute", "mre_get_contacts", "mre_get_settle_steps", "mre_get_launch_info", "mre_prop_place", "mre_sort_colours", "mre_crc32c", "mre_osc_configure_env", "mre_set_env_ids", "mre_set_render_colours", "mre_render",
 ]
 
 
@@ -127,6 +127,7 @@ def lib() -> C.CDLL:
     L.mre_osc_compute.argtypes = [vp, fp, fp]
     L.mre_get_contacts.argtypes = [vp, fp, fp]
     L.mre_get_settle_steps.argtypes = [vp, fp]
+    L.mre_get_launch_info.argtypes = [vp, fp]
     L.mre_prop_place.argtypes = [vp, C.c_uint64, fp, fp, fp, ci, C.c_float, fp, fp]
     L.mre_sort_colours.argtypes = [vp, C.c_uint64, fp, fp, ci, C.c_float, fp, fp, fp, fp]
     L.mre_set_render_colours.argtypes = [vp, fp, fp]

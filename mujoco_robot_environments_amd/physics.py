@@ -329,6 +329,14 @@ class BatchedPhysics:
                                           _ptr(which), _ptr(pick), _ptr(place), _ptr(att)), "mre_sort_colours")
         return which, pick, place, att
 
+    def launch_info(self) -> dict:
+        """Per-env record of the last stepping launch (mre_get_launch_info): overflow flag, high-water marks
+        and the env's own duration (clock ticks >> 10, the key of the longest-first dispatch)."""
+        li = np.empty((self.num_envs, 4), np.int32)
+        check(_lib.lib().mre_get_launch_info(self._h, _ptr(li)), "mre_get_launch_info")
+        return dict(overflow=li[:, 0], ncon=li[:, 1] & 0xFFFF, duration=li[:, 1] >> 16, nefc=li[:, 2],
+                    nrrow=li[:, 3] & 0xFFFF, npp=li[:, 3] >> 16)
+
     def settle_steps(self) -> np.ndarray:
         """Physics steps every env took in the last place_props() settle (negative: not settled in 2 s)."""
         st = np.empty(self.num_envs, np.int32)

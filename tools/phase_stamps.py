@@ -10,11 +10,12 @@ CSRC = os.path.join(ROOT, "mujoco_robot_environments_amd", "csrc")
 DIAG = os.path.join(ROOT, "tools", "_diag")
 NAMES = ["position+crb+factor", "velocity", "collide", "assemble", "control", "smooth", "solve", "integrate+io",
          "newton: setup", "newton: direction (H, factor, solves)", "newton: direction (factor re-used)", "newton: line search + move + update",
-         "  position: kinematics + comPos", "  position: gripper_pose (fp64)", "  position: gripper_local + connect rows (fp64)", "  position: crb + factor"]
+         "  position: kinematics + comPos", "  position: gripper_pose (fp64)", "  position: gripper_local + connect rows (fp64)", "  position: crb + factor",
+         "  direction: init + scalar rows", "  direction: cone Hessians", "  direction: elimination + forward solve", "  direction: W to LDS, back solve, decrement"]
 
 if sys.argv[1] == "build":
     os.makedirs(DIAG, exist_ok=True)
-    for k in (0, 1, 2, 3):
+    for k in (0, 1, 2, 3, 4):
         base = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-ffp-contract=on"]
         objs = []
         for name, src, flags in (("k", "mre_kernels.hip", [f"-DMRE_PHASE_STAMPS={k}"]),
@@ -31,7 +32,7 @@ elif sys.argv[1] == "run":
     if "MRE_LIB" not in os.environ:
         solver = sys.argv[3] if len(sys.argv) > 3 else "PGS"
         tot = []
-        for k in ((0, 1, 2, 3) if solver == "Newton" else (0, 1, 3)):
+        for k in ((0, 1, 2, 3, 4) if solver == "Newton" else (0, 1, 3)):
             env = dict(os.environ, MRE_LIB=os.path.join(DIAG, f"libmre_stamps{k}.so"))
             out = subprocess.check_output([sys.executable, __file__, "run"] + sys.argv[2:], env=env, text=True)
             tot += [float(x) for x in out.split()[-4:]]
