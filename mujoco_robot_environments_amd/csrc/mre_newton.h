@@ -361,12 +361,22 @@ MRE_PHASE_FN void nw_direction(ModelP M, Sm& s, int l) {
     const int g = l >> 4, m16 = l & 15;
     const int tp = m16 < 12 ? m16 / 6 : -1;   // cube of this lane's dof in tile 1 (tile 2: tp + 2)
     const int tk = m16 % 6;
-    for (int r0 = 0; r0 < nefc; r0 += 4) {
+    // (the metadata of the next chunk is fetched while the Jacobian words of this one are on their way)
+    auto meta = [&](int r0, int& ii, int& st, int& h, float& R) {
       const int i = r0 + g;
-      const bool on = i < nefc && s.rstate[i < nefc ? i : 0] == NW_QUAD;
-      const int ii = on ? i : 0;
-      const int h = s.hdr[ii];
-      const float D = on ? 1.0f / s.efc_R[ii] : 0.f;
+      ii = i < nefc ? i : 0;
+      st = i < nefc ? (int)s.rstate[ii] : NW_SAT;
+      h = s.hdr[ii];
+      R = s.efc_R[ii];
+    };
+    int iiN, stN, hN;
+    float RN;
+    meta(0, iiN, stN, hN, RN);
+    for (int r0 = 0; r0 < nefc; r0 += 4) {
+      const int ii = iiN, h = hN;
+      const bool on = stN == NW_QUAD;
+      const float D = on ? 1.0f / RN : 0.f;
+      if (r0 + 4 < nefc) meta(r0 + 4, iiN, stN, hN, RN);
       const int rs = h & 0xFF, pa = (h >> 8) & 0xF, pb = (h >> 12) & 0xF;
       const int cr = ii - nscalar;   // contact row index (prop parts exist for contact rows only)
       float v0 = 0.f, v1 = 0.f, v2 = 0.f;
@@ -375,17 +385,21 @@ MRE_PHASE_FN void nw_direction(ModelP M, Sm& s, int l) {
         if (tp >= 0) {
           if (pa == tp) v1 = s.JpA[cr][tk];
           else if (pb == tp) v1 = s.JpB[3 * s.con_bslot[cr / 3] + cr % 3][tk];
-          if (pa == tp + 2) v2 = s.JpA[cr][tk];
-          else if (pb == tp + 2) v2 = s.JpB[3 * s.con_bslot[cr / 3] + cr % 3][tk];
+          if (nprops > 2) {
+            if (pa == tp + 2) v2 = s.JpA[cr][tk];
+            else if (pb == tp + 2) v2 = s.JpB[3 * s.con_bslot[cr / 3] + cr % 3][tk];
+          }
         }
       }
       const float a0 = v0 * D, a1 = v1 * D, a2 = v2 * D;
       c00 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, v0, c00, 0, 0, 0);
       c10 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, v0, c10, 0, 0, 0);
       c11 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, v1, c11, 0, 0, 0);
-      c20 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, v0, c20, 0, 0, 0);
-      c21 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, v1, c21, 0, 0, 0);
-      c22 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, v2, c22, 0, 0, 0);
+      if (nprops > 2) {   // (wave-uniform: cubes 2 and 3 exist)
+        c20 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, v0, c20, 0, 0, 0);
+        c21 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, v1, c21, 0, 0, 0);
+        c22 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, v2, c22, 0, 0, 0);
+      }
     }
     // Tiles -> rows: lane j needs row j of H.  One tile at a time through LDS (the factor's home, unused until
     // the elimination is over): the accumulator of lane 16 q + n holds C[4 q + v][n], v = 0..3.  The lanes that
@@ -396,30 +410,39 @@ MRE_PHASE_FN void nw_direction(ModelP M, Sm& s, int l) {
     // this lane's tile and index in it (lane = dof)
     const int mytile = l < NRV ? 0 : (l < NRV + 12 ? 1 : (l < NV ? 2 : -1));
     const int mym = l < NRV ? l : (l < NRV + 12 ? l - NRV : l - NRV - 12);
-    auto spill = [&](const v4f& cv) {
+    auto spill = [&](const v4f& cv, int off) {
 #pragma unroll
-      for (int v = 0; v < 4; v++) T[(4 * g + v) * TS + m16] = cv[v];
+      for (int v = 0; v < 4; v++) T[off + (4 * g + v) * TS + m16] = cv[v];
     };
-    // (TI, TJ): tile row / column block; BI, BJ: first hh index of the blocks; NI, NJ: dofs in them
-#define NW_TILE(CV, TI, TJ, BI, NI, BJ, NJ)                                               \
-    spill(CV);                                                                            \
-    MRE_SYNC();                                                                           \
-    if (mytile == TI) {                                                                   \
-      _Pragma("unroll") for (int n = 0; n < NJ; n++) hh[BJ + n] += T[mym * TS + n];       \
-    }                                                                                     \
-    if (TI != TJ && mytile == TJ) {                                                       \
-      _Pragma("unroll") for (int q = 0; q < NI; q++) hh[BI + q] += T[q * TS + mym];       \
-    }                                                                                     \
+    // (TI, TJ): tile row / column block; BI, BJ: first hh index of the blocks; NI, NJ: dofs in them; two
+    // tiles share a round trip (the factor's LDS holds two padded 16 x 17 tiles)
+#define NW_TILE(OFF, TI, TJ, BI, NI, BJ, NJ)                                                   \
+    if (mytile == TI) {                                                                        \
+      _Pragma("unroll") for (int n = 0; n < NJ; n++) hh[BJ + n] += T[OFF + mym * TS + n];      \
+    }                                                                                          \
+    if (TI != TJ && mytile == TJ) {                                                            \
+      _Pragma("unroll") for (int q = 0; q < NI; q++) hh[BI + q] += T[OFF + q * TS + mym];      \
+    }
+    constexpr int T2 = 16 * TS;
+    static_assert(2 * T2 <= NV * (NV + 1) / 2, "two tiles fit the factor's storage");
+    spill(c00, 0); spill(c10, T2);
     MRE_SYNC();
-    NW_TILE(c00, 0, 0, 0, NRV, 0, NRV)
+    NW_TILE(0, 0, 0, 0, NRV, 0, NRV)
+    if (nprops > 0) { NW_TILE(T2, 1, 0, NRV, 12, 0, NRV) }
+    MRE_SYNC();
     if (nprops > 0) {
-      NW_TILE(c10, 1, 0, NRV, 12, 0, NRV)
-      NW_TILE(c11, 1, 1, NRV, 12, NRV, 12)
+      spill(c11, 0); spill(c20, T2);
+      MRE_SYNC();
+      NW_TILE(0, 1, 1, NRV, 12, NRV, 12)
+      if (nprops > 2) { NW_TILE(T2, 2, 0, NRV + 12, 12, 0, NRV) }
+      MRE_SYNC();
     }
     if (nprops > 2) {
-      NW_TILE(c20, 2, 0, NRV + 12, 12, 0, NRV)
-      NW_TILE(c21, 2, 1, NRV + 12, 12, NRV, 12)
-      NW_TILE(c22, 2, 2, NRV + 12, 12, NRV + 12, 12)
+      spill(c21, 0); spill(c22, T2);
+      MRE_SYNC();
+      NW_TILE(0, 2, 1, NRV + 12, 12, NRV, 12)
+      NW_TILE(T2, 2, 2, NRV + 12, 12, NRV + 12, 12)
+      MRE_SYNC();
     }
 #undef NW_TILE
   }
@@ -480,12 +503,16 @@ MRE_PHASE_FN void nw_direction(ModelP M, Sm& s, int l) {
     if (l <= k) s.W[k * (k + 1) / 2 + l] = hh[k];
   MRE_SYNC();
   {
+    // column l of W (rows j < l) into the registers the H rows just left: 38 independent LDS reads, then
+    // the dependent chain y_l -= W[j][l] x_j runs on registers with compile-time lanes
     const int base = l < NV ? l * (l + 1) / 2 : 0;
     const int nva = NRV + 6 * nprops;  // inactive cube blocks: x = 0
-    for (int j = 0; j < nva; j++) {
-      const float cw = (j < l && l < NV) ? s.W[base + j] : 0.f;
+#pragma unroll
+    for (int j = 0; j < NV - 1; j++) hh[j] = (j < l && l < nva) ? s.W[base + j] : 0.f;
+#pragma unroll
+    for (int j = 0; j < NV - 1; j++) {
       const float xj = rdlane(y * dinv, j);
-      y = fmaf(-cw, xj, y);
+      y = fmaf(-hh[j], xj, y);
     }
   }
   const float x = (l < NV && c.lact) ? y * dinv : 0.f;
