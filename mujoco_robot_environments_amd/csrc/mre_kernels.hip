@@ -26,6 +26,9 @@
 
 namespace mre {
 using ModelP = MRE_MODEL_PTR(DevModel);
+#if defined(MRE_PHASE_STAMPS) && MRE_PHASE_STAMPS >= 4
+__shared__ unsigned long long dbg_acc[4];   // diagnostic builds only (MRE_DBG_STAMP)
+#endif
 
 // OSC scratch (mre_osc.h); lives in LDS region R1 (see Sm)
 struct OscSm {
@@ -271,10 +274,13 @@ MRE_DEV void com_pos(ModelP M, Sm& s, int l, const BodyRegs& br) {
 // S1a: kinematics + comPos as one real function so that the per-lane body frame registers
 // (anchor, axis, inertial frame) never leave the register file
 MRE_PHASE_FN void position_stage(ModelP M, Sm& s, int l) {
+  MRE_DBG_T0();
   BodyRegs br;
   kinematics<true>(M, s, l, br);
+  MRE_DBG_STAMP(5, 0);
   com_pos(M, s, l, br);
   MRE_SYNC();
+  MRE_DBG_STAMP(5, 1);
 }
 // kinematics only (site queries at the end of a launch)
 MRE_PHASE_FN void kinematics_only(ModelP M, Sm& s, int l) {
@@ -903,8 +909,8 @@ MRE_DEV void step_body(const StepArgs& a, Sm& s) {
   }
   MRE_SYNC();
 
-#if defined(MRE_PHASE_STAMPS) && defined(MRE_NEWTON) && MRE_PHASE_STAMPS == 4
-  if (l < 4) nw_dir_acc[l] = 0ull;
+#if defined(MRE_PHASE_STAMPS) && MRE_PHASE_STAMPS >= 4
+  if (l < 4) dbg_acc[l] = 0ull;
 #endif
 #ifdef MRE_PHASE_STAMPS
   unsigned long long stamp_acc[4] = {0, 0, 0, 0};
@@ -1104,8 +1110,8 @@ MRE_DEV void step_body(const StepArgs& a, Sm& s) {
       a.stats[env * 4 + 2] = s.solver_iters; a.stats[env * 4 + 3] = s.nl;
 #ifdef MRE_PHASE_STAMPS
       for (int k = 0; k < 4; k++) a.stats[env * 4 + k] = (int)(stamp_acc[k] >> 4);
-#if defined(MRE_NEWTON) && MRE_PHASE_STAMPS == 4
-      for (int k = 0; k < 4; k++) a.stats[env * 4 + k] = (int)(nw_dir_acc[k] >> 4);
+#if MRE_PHASE_STAMPS >= 4
+      for (int k = 0; k < 4; k++) a.stats[env * 4 + k] = (int)(dbg_acc[k] >> 4);
 #endif
 #endif
     }

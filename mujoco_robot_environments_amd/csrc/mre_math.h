@@ -6,6 +6,20 @@
 #define MRE_DEV __device__ __forceinline__
 // whole phases are real functions: register allocation is scoped per phase instead of across
 // the fused step loop (the inlined kernel needed 332 registers -> 1 wave per SIMD)
+// Diagnostic builds (-DMRE_PHASE_STAMPS=4, 5, ...: tools/phase_stamps.py): time inside a phase function by part,
+// summed by lane 0 into four LDS words that the kernel returns through the stats rows.
+#if defined(MRE_PHASE_STAMPS) && MRE_PHASE_STAMPS >= 4
+#define MRE_DBG_T0() unsigned long long dbg_t_ = __builtin_amdgcn_s_memtime()
+#define MRE_DBG_STAMP(SET, K)                                                      \
+  do {                                                                             \
+    const unsigned long long n_ = __builtin_amdgcn_s_memtime();                    \
+    if (MRE_PHASE_STAMPS == (SET) && threadIdx.x == 0) dbg_acc[K] += n_ - dbg_t_;  \
+    dbg_t_ = n_;                                                                   \
+  } while (0)
+#else
+#define MRE_DBG_T0() do {} while (0)
+#define MRE_DBG_STAMP(SET, K) do {} while (0)
+#endif
 #define MRE_PHASE_FN __device__ __attribute__((noinline))
 // Ordering point between lanes of the ONE wave that steps an env.  A workgroup is a single wavefront, whose
 // LDS instructions issue and execute in order, so lanes see each other's earlier LDS writes without waiting for
@@ -92,9 +106,27 @@ MRE_DEV void qrotv(float* r, const float* q, const float* v) {
   q2mat(m, q);
   m3mulv(r, m, v);
 }
+// sin and cos of an angle of a few radians (half joint angles, half rotation steps): three-constant
+// Cody-Waite reduction by pi/2 and the single-precision minimax kernels on [-pi/4, pi/4] (about 1 ulp).
+// sincosf() carries a Payne-Hanek reduction for arguments up to 1e38 -- a hundred instructions that the
+// kinematics would execute on each of its nine tree levels.
+MRE_DEV void sincos_small(float x, float* sn, float* cs) {
+  const float j = rintf(x * 0.6366197723675814f);
+  float r = fmaf(-j, 1.5703125f, x);
+  r = fmaf(-j, 4.837512969970703125e-4f, r);
+  r = fmaf(-j, 7.54978995489188192e-8f, r);
+  const float z = r * r;
+  const float ps = fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f), z * r, r);
+  const float pc = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f), z * z,
+                        fmaf(-0.5f, z, 1.0f));
+  const int q = (int)j & 3;
+  const float a = (q & 1) ? pc : ps, b = (q & 1) ? ps : pc;
+  *sn = (q & 2) ? -a : a;
+  *cs = ((q + 1) & 2) ? -b : b;
+}
 MRE_DEV void axisangle2q(float* q, const float* axis, float angle) {
   float s, c;
-  sincosf(0.5f * angle, &s, &c);
+  sincos_small(0.5f * angle, &s, &c);
   q[0] = c; q[1] = axis[0] * s; q[2] = axis[1] * s; q[3] = axis[2] * s;
 }
 MRE_DEV void mat2q(float* q, const float* m) {

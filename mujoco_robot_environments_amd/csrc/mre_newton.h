@@ -327,16 +327,8 @@ MRE_PHASE_FN float nw_setup(ModelP M, Sm& s, int l) {
 
 // Phase 2: search = -H^-1 grad.  H = M + J' D J (+ cone Hessians) with its rows in registers,
 // block-sparse factorisation H = W W', both triangular solves.
-#if defined(MRE_PHASE_STAMPS) && MRE_PHASE_STAMPS == 4
-__shared__ unsigned long long nw_dir_acc[4];   // diagnostic builds only: time inside nw_direction by part
-#define NW_DIR_STAMP(k) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); if (l == 0) nw_dir_acc[k] += n_ - t_; t_ = n_; } while (0)
-#else
-#define NW_DIR_STAMP(k) do {} while (0)
-#endif
 MRE_PHASE_FN void nw_direction(ModelP M, Sm& s, int l) {
-#if defined(MRE_PHASE_STAMPS) && MRE_PHASE_STAMPS == 4
-  unsigned long long t_ = __builtin_amdgcn_s_memtime();
-#endif
+  MRE_DBG_T0();
   const NwLane c = nw_lane(M, s, l);
   const int nefc = s.nefc, nscalar = 7 + s.nl, nprops = s.nprops;
   const int lp = c.lp, lk = c.lk;
@@ -447,7 +439,7 @@ MRE_PHASE_FN void nw_direction(ModelP M, Sm& s, int l) {
 #undef NW_TILE
   }
   const unsigned long long mcone = __ballot(l < s.ncon && s.rstate[nscalar + 3 * (l < s.ncon ? l : 0)] == NW_CONE);
-  NW_DIR_STAMP(0);
+  MRE_DBG_STAMP(4, 0);
   // contacts in the middle zone: J_c' H_c J_c with the 3 x 3 cone Hessian
   for (unsigned long long m = mcone; m != 0ull; m &= m - 1ull) {
     const int cc = __builtin_ctzll(m);
@@ -466,7 +458,7 @@ MRE_PHASE_FN void nw_direction(ModelP M, Sm& s, int l) {
     nw_rank1(hh, t1, J1, has_r, pa, pb);
     nw_rank1(hh, t2, J2, has_r, pa, pb);
   }
-  NW_DIR_STAMP(1);
+  MRE_DBG_STAMP(4, 1);
   // symbolic elimination over the blocks (node 0 robot, node 1 + p cube p), cubes last to first
   unsigned adj[5];
   {
@@ -496,7 +488,7 @@ MRE_PHASE_FN void nw_direction(ModelP M, Sm& s, int l) {
   if (nprops > 1) nw_elim_range<NRV + 11, NRV + 6>(hh, g, y, dinv, l, adj[2] & 0x3u);
   if (nprops > 0) nw_elim_range<NRV + 5, NRV>(hh, g, y, dinv, l, adj[1] & 0x1u);
   nw_elim_range<NRV - 1, 0>(hh, g, y, dinv, l, 0u);
-  NW_DIR_STAMP(2);
+  MRE_DBG_STAMP(4, 2);
   // ---- W' x = y: columns of W through LDS (packed by columns: (j, k), j <= k at k(k+1)/2 + j)
 #pragma unroll
   for (int k = 0; k < NV; k++)
@@ -521,7 +513,7 @@ MRE_PHASE_FN void nw_direction(ModelP M, Sm& s, int l) {
   const float dec = wave_sum((l < NVP ? s.nw_grad[l] : 0.f) * x);
   if (l == 0) s.scratch[2] = dec;
   MRE_SYNC();
-  NW_DIR_STAMP(3);
+  MRE_DBG_STAMP(4, 3);
 }
 
 // Phase 2': the same direction from the factor of the last nw_direction call (still in s.W), for a

@@ -11,11 +11,12 @@ DIAG = os.path.join(ROOT, "tools", "_diag")
 NAMES = ["position+crb+factor", "velocity", "collide", "assemble", "control", "smooth", "solve", "integrate+io",
          "newton: setup", "newton: direction (H, factor, solves)", "newton: direction (factor re-used)", "newton: line search + move + update",
          "  position: kinematics + comPos", "  position: gripper_pose (fp64)", "  position: gripper_local + connect rows (fp64)", "  position: crb + factor",
-         "  direction: init + scalar rows", "  direction: cone Hessians", "  direction: elimination + forward solve", "  direction: W to LDS, back solve, decrement"]
+         "  direction: init + scalar rows", "  direction: cone Hessians", "  direction: elimination + forward solve", "  direction: W to LDS, back solve, decrement",
+         "  position_stage: kinematics", "  position_stage: comPos", "  (unused)", "  (unused)"]
 
 if sys.argv[1] == "build":
     os.makedirs(DIAG, exist_ok=True)
-    for k in (0, 1, 2, 3, 4):
+    for k in ([int(x) for x in sys.argv[2:]] or (0, 1, 2, 3, 4, 5)):
         base = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-ffp-contract=on"]
         objs = []
         for name, src, flags in (("k", "mre_kernels.hip", [f"-DMRE_PHASE_STAMPS={k}"]),
@@ -32,11 +33,17 @@ elif sys.argv[1] == "run":
     if "MRE_LIB" not in os.environ:
         solver = sys.argv[3] if len(sys.argv) > 3 else "PGS"
         tot = []
-        for k in ((0, 1, 2, 3, 4) if solver == "Newton" else (0, 1, 3)):
+        for k in ([int(x) for x in os.environ["MRE_STAMP_SETS"].split(",")] if "MRE_STAMP_SETS" in os.environ else ((0, 1, 2, 3, 4, 5) if solver == "Newton" else (0, 1, 3))):
             env = dict(os.environ, MRE_LIB=os.path.join(DIAG, f"libmre_stamps{k}.so"))
             out = subprocess.check_output([sys.executable, __file__, "run"] + sys.argv[2:], env=env, text=True)
             tot += [float(x) for x in out.split()[-4:]]
-        s = sum(tot[:12]) if solver == "Newton" else sum(tot[:8])   # (the position sub-buckets repeat bucket 0)
+        if "MRE_STAMP_SETS" in os.environ:   # selected sets only: raw numbers
+            sets = [int(x) for x in os.environ["MRE_STAMP_SETS"].split(",")]
+            for q, k in enumerate(sets):
+                for n, v in zip(NAMES[4 * k:4 * k + 4], tot[4 * q:4 * q + 4]):
+                    print(f"{n:48s} {v:12.0f}")
+            sys.exit(0)
+        s = sum(tot[:12]) if solver == "Newton" else sum(tot[:8])   # (the sub-buckets repeat their parents)
         print(f"solver {solver}: cycles / 16 per env and tick (5 steps), share of the tick")
         names = NAMES if solver == "Newton" else NAMES[:8] + NAMES[12:]
         for n, v in zip(names, tot):
