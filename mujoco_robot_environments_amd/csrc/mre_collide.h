@@ -34,26 +34,33 @@ MRE_DEV void row3(float* o, const float (*m)[3], int i) {
 // clip polygon p (x, y, depth) against |x| <= sx, |y| <= sy using q as the second buffer;
 // result ends in p.  p, q are LDS pointers private to this lane.
 MRE_DEV int clip_poly(float* p, float* q, int n, float sx, float sy) {
+  // the two buffers swap roles from edge to edge (four edges: the result is back in p), and a vertex that was
+  // the end of one polygon edge stays in registers as the start of the next
+  float* src = p;
+  float* dst = q;
   for (int e = 0; e < 4; e++) {
     const int ax = e >> 1;
     const float sg = (e & 1) ? -1.0f : 1.0f;
     const float lim = ax ? sy : sx;
     int nq = 0;
+    const float f0 = src[0], f1 = src[1], f2 = src[2];
+    float a0 = f0, a1 = f1, a2 = f2;
     for (int i = 0; i < n; i++) {
-      const int i2 = (i + 1 == n) ? 0 : i + 1;
-      const float a0 = p[3 * i], a1 = p[3 * i + 1], a2 = p[3 * i + 2];
-      const float b0 = p[3 * i2], b1 = p[3 * i2 + 1], b2 = p[3 * i2 + 2];
+      const bool last = i + 1 == n;
+      const int i2 = last ? 0 : i + 1;
+      const float b0 = last ? f0 : src[3 * i2], b1 = last ? f1 : src[3 * i2 + 1], b2 = last ? f2 : src[3 * i2 + 2];
       const float da = sg * (ax ? a1 : a0) - lim, db = sg * (ax ? b1 : b0) - lim;
-      if (da <= 0 && nq < 8) { q[3 * nq] = a0; q[3 * nq + 1] = a1; q[3 * nq + 2] = a2; nq++; }
+      if (da <= 0 && nq < 8) { dst[3 * nq] = a0; dst[3 * nq + 1] = a1; dst[3 * nq + 2] = a2; nq++; }
       if ((da <= 0) != (db <= 0) && nq < 8) {
         const float t = da / (da - db);
-        q[3 * nq] = a0 + t * (b0 - a0); q[3 * nq + 1] = a1 + t * (b1 - a1); q[3 * nq + 2] = a2 + t * (b2 - a2);
+        dst[3 * nq] = a0 + t * (b0 - a0); dst[3 * nq + 1] = a1 + t * (b1 - a1); dst[3 * nq + 2] = a2 + t * (b2 - a2);
         nq++;
       }
+      a0 = b0; a1 = b1; a2 = b2;
     }
     n = nq;
-    for (int i = 0; i < 3 * n; i++) p[i] = q[i];
     if (n == 0) return 0;
+    float* t = src; src = dst; dst = t;
   }
   return n;
 }

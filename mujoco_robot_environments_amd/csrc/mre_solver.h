@@ -87,6 +87,7 @@ MRE_PHASE_FN void collide(ModelP M, Sm& s, int l, bool detect) {
   static_assert(offsetof(Sm, hdr) + sizeof(((Sm*)0)->hdr) - offsetof(Sm, JpA) >= sizeof(float) * 64 * COLL_BUF,
                 "clip buffers do not fit");
   static_assert(NPAIR <= 256 && sizeof(((Sm*)0)->iscr) >= NPAIR, "survivor list: one byte per pair");
+  MRE_DBG_T0();
   float* buf = &s.JpA[0][0] + l * COLL_BUF;
   uint8_t* list = reinterpret_cast<uint8_t*>(s.iscr);
   const unsigned long long lt = (1ull << l) - 1ull;   // lanes below this one
@@ -121,6 +122,7 @@ MRE_PHASE_FN void collide(ModelP M, Sm& s, int l, bool detect) {
   }
   if (l == 0) s.ncon = 0;
   MRE_SYNC();
+  MRE_DBG_STAMP(6, 0);
   int base = 0;  // contacts kept by the earlier passes
   for (int c0 = 0; c0 < nsurv; c0 += 64) {
     const int pr = (c0 + l < nsurv) ? list[c0 + l] : -1;
@@ -132,8 +134,10 @@ MRE_PHASE_FN void collide(ModelP M, Sm& s, int l, bool detect) {
       geom_pose(M, s, g1, p1, R1, s1, &rb1);
       geom_pose(M, s, g2, p2, R2, s2, &rb2);
       const float inc = detect ? M->pair_margin[pr] : M->pair_margin[pr] - M->pair_gap[pr];
+      MRE_DBG_STAMP(6, 1);
       if (M->geom_type[g1] == 0) n = plane_box(p1, R1, p2, R2, s2, inc, normal, buf);
       else n = box_box(p1, R1, s1, p2, R2, s2, inc, normal, buf);
+      MRE_DBG_STAMP(6, 2);
       // mesh stand-in pairs keep one contact (deepest point), like MuJoCo's convex-mesh test
       if (M->pair_single[pr] && n > 1) {
         int best = 0;
@@ -182,6 +186,7 @@ MRE_PHASE_FN void collide(ModelP M, Sm& s, int l, bool detect) {
       }
     }
     MRE_SYNC();
+    MRE_DBG_STAMP(6, 3);
     if (tot > NCON_MAX) break;   // (overflow: the env is re-run on the large kernel, or reported)
     base = tot;
   }
