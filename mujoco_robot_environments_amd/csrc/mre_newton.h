@@ -550,6 +550,7 @@ MRE_PHASE_FN void nw_direction_reuse(ModelP M, Sm& s, int l) {
 // Phase 3: exact line search along s.nw_search (PrimalSearch), move, constraint update, gradient.
 // Returns the new cost; s.scratch[0] = step (0 when no step was possible), s.scratch[1] = |grad|.
 MRE_PHASE_FN float nw_search_move(ModelP M, Sm& s, int l) {
+  MRE_DBG_T0();
   const NwLane c = nw_lane(M, s, l);
   const int nefc = s.nefc, ncon = s.ncon, nscalar = 7 + s.nl;
   const float tol = M->tolerance, mu_scale = c.mu_scale;
@@ -560,6 +561,7 @@ MRE_PHASE_FN float nw_search_move(ModelP M, Sm& s, int l) {
   const float Mv = on ? nw_mulM(s, l, c.mdiag, s.nw_search) : 0.f;
   for (int i = l; i < nefc; i += 64) s.jv[i] = row_dot(s, i, s.nw_search);
   MRE_SYNC();
+  MRE_DBG_STAMP(7, 0);
   const float snorm = sqrtf(wave_sum(sv * sv));
   float alpha = 0.f;
   if (snorm >= kMinVal) {
@@ -651,6 +653,7 @@ MRE_PHASE_FN float nw_search_move(ModelP M, Sm& s, int l) {
     }
   }
   if (l == 0) { s.scratch[0] = alpha; s.scratch[1] = 0.f; }
+  MRE_DBG_STAMP(7, 1);
   if (alpha == 0.f) { MRE_SYNC(); return 0.f; }
   qa = fmaf(alpha, sv, qa);
   Ma = fmaf(alpha, Mv, Ma);
@@ -662,6 +665,7 @@ MRE_PHASE_FN float nw_search_move(ModelP M, Sm& s, int l) {
   const float gn = sqrtf(wave_sum(gr * gr));
   if (l == 0) s.scratch[1] = gn;
   MRE_SYNC();
+  MRE_DBG_STAMP(7, 2);
   return cost;
 }
 

@@ -13,11 +13,12 @@ NAMES = ["position+crb+factor", "velocity", "collide", "assemble", "control", "s
          "  position: kinematics + comPos", "  position: gripper_pose (fp64)", "  position: gripper_local + connect rows (fp64)", "  position: crb + factor",
          "  direction: init + scalar rows", "  direction: cone Hessians", "  direction: elimination + forward solve", "  direction: W to LDS, back solve, decrement",
          "  position_stage: kinematics", "  position_stage: comPos", "  (unused)", "  (unused)",
-         "  collide: broad phase", "  collide: geom frames", "  collide: box-box / plane-box", "  collide: filter, prefix, write-out"]
+         "  collide: broad phase", "  collide: geom frames", "  collide: box-box / plane-box", "  collide: filter, prefix, write-out",
+         "  search: M v, J v", "  search: line search", "  search: move, update, J'f, gradient", "  (unused)"]
 
 if sys.argv[1] == "build":
     os.makedirs(DIAG, exist_ok=True)
-    for k in ([int(x) for x in sys.argv[2:]] or (0, 1, 2, 3, 4, 5, 6)):
+    for k in ([int(x) for x in sys.argv[2:]] or (0, 1, 2, 3, 4, 5, 6, 7)):
         base = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-ffp-contract=on"]
         objs = []
         for name, src, flags in (("k", "mre_kernels.hip", [f"-DMRE_PHASE_STAMPS={k}"]),
