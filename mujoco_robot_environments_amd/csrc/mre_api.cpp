@@ -863,6 +863,7 @@ extern "C" int mre_step(mre_env* e, int nsubsteps, unsigned flags) {
   StepArgs a;
   fill_args(e, a);
   a.nsteps = nsubsteps; a.flags = flags;
+  if (nsubsteps > 0) a.sites = nullptr;  // (site poses are refreshed by mre_get_sites: no kinematics pass for them here)
   int rc = launch_step(e, a);
   if (rc) return rc;
   if (e->trace) e->trace_pos += nsubsteps;
@@ -880,6 +881,7 @@ extern "C" int mre_rollout(mre_env* e, const float* ctrl_seq, int nticks, int co
   fill_args(e, a);
   a.nsteps = nticks * control_steps; a.control_steps = control_steps; a.mode = CTRL_SEQ;
   a.ctrl_seq = ctrl_seq; a.flags = flags;
+  a.sites = nullptr;  // (as in mre_step)
   int rc = launch_step(e, a);
   if (rc) return rc;
   if (e->trace) e->trace_pos += a.nsteps;

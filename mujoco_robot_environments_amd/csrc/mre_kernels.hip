@@ -1058,8 +1058,9 @@ MRE_DEV void step_body(const StepArgs& a, Sm& s) {
     MRE_SYNC();
     if (l == 0) s.overflow = 0;   // a cut detection list is reported in the count, not as a status bit
   }
-  // ---- final kinematics for site queries
-  kinematics_only(M, s, l);
+  // ---- final kinematics: for the controller's convergence test and for the site / geom exports (a stepping
+  // launch of mre_step / mre_rollout asks for neither: mre_get_sites refreshes the frames itself)
+  if (a.mode == CTRL_OSC || a.sites != nullptr || a.geoms != nullptr) kinematics_only(M, s, l);
   if (a.mode == CTRL_OSC && a.nsteps > 0) {
     if (osc_converged(M, s, oscp, s.osc_tgt)) arm_converged = true;
     if (l == 0) {
