@@ -715,7 +715,9 @@ MRE_DEV void newton_solve(ModelP M, Sm& s, int l) {
   int iter = 0, nfull = 0, stalls = 0;
   while (iter < max_iter) {
     const NwMasks mk = nw_masks(s, l, nscalar, ncon);
-    const bool reuse = have_factor && !force_full && mk == mf;
+    // (a contact in the middle zone makes H a function of the iterate, not only of the active set: its factor
+    // is never re-used -- MuJoCo likewise rebuilds the cone Hessians every iteration)
+    const bool reuse = have_factor && !force_full && mk == mf && mk.cc == 0ull;
     if (reuse) {
       nw_direction_reuse(M, s, l);
       NW_STAMP(2);
