@@ -345,8 +345,7 @@ MRE_PHASE_FN void nw_direction(ModelP M, Sm& s, int l) {
   // and 1, 2: cubes 2 and 3; 6 dofs each, the rest padding); v_mfma_f32_16x16x4_f32 consumes four rows per
   // issue: operand lane 16 k + m holds row r0 + k at tile dof m (A = J D, B = J), and the six tiles of the lower
   // triangle accumulate in 24 registers.  Per chunk of four rows a lane fetches its row's header, state and 1 / R
-  // and ONE Jacobian word per tile -- no per-row branches, no cross-lane traffic.  Rows in any other state
-  // enter with D = 0 (cone contacts are added below with their 3 x 3 Hessian).
+  // and ONE Jacobian word per tile -- no per-row branches, no cross-lane traffic.  Rows in any other state enter with D = 0.
   typedef float v4f __attribute__((ext_vector_type(4)));
   v4f c00 = {0.f, 0.f, 0.f, 0.f}, c10 = c00, c11 = c00, c20 = c00, c21 = c00, c22 = c00;
   {
@@ -364,26 +363,47 @@ MRE_PHASE_FN void nw_direction(ModelP M, Sm& s, int l) {
     int iiN, stN, hN;
     float RN;
     meta(0, iiN, stN, hN, RN);
+    // J of constraint row (contact-row index crx, robot slot rsx) at this lane's dof of the three tiles
+    auto gather = [&](int crx, int rsx, int pa, int pb, float& w0, float& w1, float& w2) {
+      w0 = 0.f; w1 = 0.f; w2 = 0.f;
+      if (rsx != HDR_NONE && m16 < NRV) w0 = s.Jr[rsx][m16];
+      if (tp >= 0) {
+        if (pa == tp) w1 = s.JpA[crx][tk];
+        else if (pb == tp) w1 = s.JpB[3 * s.con_bslot[crx / 3] + crx % 3][tk];
+        if (nprops > 2) {
+          if (pa == tp + 2) w2 = s.JpA[crx][tk];
+          else if (pb == tp + 2) w2 = s.JpB[3 * s.con_bslot[crx / 3] + crx % 3][tk];
+        }
+      }
+    };
     for (int r0 = 0; r0 < nefc; r0 += 4) {
-      const int ii = iiN, h = hN;
-      const bool on = stN == NW_QUAD;
-      const float D = on ? 1.0f / RN : 0.f;
+      const int ii = iiN, h = hN, st = stN;
+      const bool quad = st == NW_QUAD, cone = st == NW_CONE;
+      const float D = quad ? 1.0f / RN : 0.f;
       if (r0 + 4 < nefc) meta(r0 + 4, iiN, stN, hN, RN);
       const int rs = h & 0xFF, pa = (h >> 8) & 0xF, pb = (h >> 12) & 0xF;
       const int cr = ii - nscalar;   // contact row index (prop parts exist for contact rows only)
       float v0 = 0.f, v1 = 0.f, v2 = 0.f;
-      if (on) {
-        if (rs != HDR_NONE && m16 < NRV) v0 = s.Jr[rs][m16];
-        if (tp >= 0) {
-          if (pa == tp) v1 = s.JpA[cr][tk];
-          else if (pb == tp) v1 = s.JpB[3 * s.con_bslot[cr / 3] + cr % 3][tk];
-          if (nprops > 2) {
-            if (pa == tp + 2) v2 = s.JpA[cr][tk];
-            else if (pb == tp + 2) v2 = s.JpB[3 * s.con_bslot[cr / 3] + cr % 3][tk];
-          }
-        }
+      if (quad || cone) gather(cr, rs, pa, pb, v0, v1, v2);
+      float a0 = v0 * D, a1 = v1 * D, a2 = v2 * D;
+      if (cone) {
+        // a contact in the middle zone enters with its 3 x 3 Hessian: row k of the contact contributes
+        // (sum_m Hc[k][m] J_m)' J_k, so the A operand of this lane is the Hc-weighted mix of the contact's three
+        // rows at its dof (the robot slots and prop rows of one contact are consecutive)
+        const int k = cr % 3, cc = cr / 3, cr0 = cr - k;
+        const int rs0 = rs != HDR_NONE ? rs - k : HDR_NONE;
+        const float* hc = s.hc[cc];
+        const float H0 = k == 0 ? hc[0] : (k == 1 ? hc[1] : hc[2]);
+        const float H1 = k == 0 ? hc[1] : (k == 1 ? hc[3] : hc[4]);
+        const float H2 = k == 0 ? hc[2] : (k == 1 ? hc[4] : hc[5]);
+        float x0, x1, x2, y0, y1, y2, z0, z1, z2;
+        gather(cr0, rs0, pa, pb, x0, x1, x2);
+        gather(cr0 + 1, rs0 != HDR_NONE ? rs0 + 1 : HDR_NONE, pa, pb, y0, y1, y2);
+        gather(cr0 + 2, rs0 != HDR_NONE ? rs0 + 2 : HDR_NONE, pa, pb, z0, z1, z2);
+        a0 = H0 * x0 + H1 * y0 + H2 * z0;
+        a1 = H0 * x1 + H1 * y1 + H2 * z1;
+        a2 = H0 * x2 + H1 * y2 + H2 * z2;
       }
-      const float a0 = v0 * D, a1 = v1 * D, a2 = v2 * D;
       c00 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, v0, c00, 0, 0, 0);
       c10 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, v0, c10, 0, 0, 0);
       c11 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, v1, c11, 0, 0, 0);
@@ -437,26 +457,6 @@ MRE_PHASE_FN void nw_direction(ModelP M, Sm& s, int l) {
       MRE_SYNC();
     }
 #undef NW_TILE
-  }
-  const unsigned long long mcone = __ballot(l < s.ncon && s.rstate[nscalar + 3 * (l < s.ncon ? l : 0)] == NW_CONE);
-  MRE_DBG_STAMP(4, 0);
-  // contacts in the middle zone: J_c' H_c J_c with the 3 x 3 cone Hessian
-  for (unsigned long long m = mcone; m != 0ull; m &= m - 1ull) {
-    const int cc = __builtin_ctzll(m);
-    const int i = nscalar + 3 * cc;
-    const int h = uni(s.hdr[i]);
-    const int rs = h & 0xFF, pa = (h >> 8) & 0xF, pb = (h >> 12) & 0xF;
-    const bool has_r = rs != HDR_NONE;
-    const int h1 = has_r ? h + 1 : h, h2 = has_r ? h + 2 : h;  // robot slots of rows 1, 2
-    const float J0 = nw_Jl(s, i, h, l, lp, lk), J1 = nw_Jl(s, i + 1, h1, l, lp, lk),
-                J2 = nw_Jl(s, i + 2, h2, l, lp, lk);
-    const float H00 = s.hc[cc][0], H01 = s.hc[cc][1], H02 = s.hc[cc][2], H11 = s.hc[cc][3],
-                H12 = s.hc[cc][4], H22 = s.hc[cc][5];
-    const float t0 = H00 * J0 + H01 * J1 + H02 * J2, t1 = H01 * J0 + H11 * J1 + H12 * J2,
-                t2 = H02 * J0 + H12 * J1 + H22 * J2;
-    nw_rank1(hh, t0, J0, has_r, pa, pb);
-    nw_rank1(hh, t1, J1, has_r, pa, pb);
-    nw_rank1(hh, t2, J2, has_r, pa, pb);
   }
   MRE_DBG_STAMP(4, 1);
   // symbolic elimination over the blocks (node 0 robot, node 1 + p cube p), cubes last to first
