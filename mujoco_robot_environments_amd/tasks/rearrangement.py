@@ -144,6 +144,9 @@ class BatchedRearrangementEnv:
         self._place_count = 0
         self._place_counts = np.zeros(self.num_envs, np.int64)  # prop_place calls per env (RNG key)
         self._zones = None  # [N, 4, 4] colour zone of every cube (set when the colours are drawn)
+        # pose of the reference's mocap target body (tasks/rearrangement.py:130-140; simulation_tuning_mode)
+        self.mocap_pos = np.tile(np.array([0.4, 0.0, 0.6]), (self.num_envs, 1))
+        self.mocap_quat = np.tile(home_quat(), (self.num_envs, 1))
         self._robot: Optional[RobotArm] = None
         self.mode = None
         self.eef_home_pose = None
@@ -257,6 +260,29 @@ class BatchedRearrangementEnv:
         self.failed_phase[newly] = name
         self.last_converged &= conv
         return conv
+
+    def interactive_tuning(self, mocap_pos=None, mocap_quat=None):
+        """One tick of the reference's tuning loop (tasks/rearrangement.py:753-779): the OSC target follows
+        the mocap body (position + [0, 0, 0.175], its quaternion, zero velocities), the arm and gripper commands
+        are computed once and held for 5 physics steps.  There is no viewer to drag a mocap body here, so its
+        pose is state of the env (``mocap_pos`` [N, 3] / ``mocap_quat`` [N, 4], initialised like the reference's
+        body at (0.4, 0, 0.6), gripper down) that the caller may move, per env, through the arguments."""
+        if mocap_pos is not None:
+            self.mocap_pos[:] = np.asarray(mocap_pos, np.float64)
+        if mocap_quat is not None:
+            self.mocap_quat[:] = np.asarray(mocap_quat, np.float64)
+        self._robot.arm_controller.set_target(position=self.mocap_pos + np.array([0.0, 0.0, 0.175]),
+                                              quat=self.mocap_quat, velocity=np.zeros(3),
+                                              angular_velocity=np.zeros(3))
+        # compute_control_output() + 5 x (set_control, step) = one control tick of the fused launch
+        self._physics.run_controller(1, self._robot.control_steps)
+        for _ in range(self._robot.control_steps):
+            self._robot.time += self._robot.timestep
+
+    def time_limit_exceeded(self) -> bool:
+        """tasks/rearrangement.py:216-217 (the reference reads a module-level ``cfg.time_limit`` that its config
+        tree does not define; absent means no limit)."""
+        return self._robot.time >= float(self._cfg.get("time_limit", float("inf")))
 
     def _pose2d(self, pose):
         pose = np.asarray(pose)

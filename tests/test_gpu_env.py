@@ -226,3 +226,39 @@ def test_rendered_observations_bboxes_and_pixel_round_trip():
     assert obs["overhead_camera/depth"].shape == (480, 640) and obs["overhead_camera/depth"].dtype == np.float32
     assert len(one.props_info) == int(one.nprops[0])
     one.close()
+
+
+def test_interactive_tuning_tick_follows_the_mocap_target_like_the_oracle(compiled_model, oracle_model):
+    """tasks/rearrangement.py:753-779: target = mocap pose + (0, 0, 0.175), one command held for 5 steps per
+    call.  8 envs with different mocap poses, 300 calls, against the oracle running the same tick loop."""
+    from mujoco_robot_environments_amd.tasks.rearrangement import BatchedRearrangementEnv, colour_separator_task_config, home_quat
+    from oracle import oracle as O
+    N, T = 8, 300
+    env = BatchedRearrangementEnv(cfg=colour_separator_task_config(), num_envs=N, seed=2, solver="Newton")
+    env.reset()
+    q0 = env.physics.qpos().astype(np.float64)
+    assert np.allclose(env.mocap_pos, [0.4, 0.0, 0.6]) and np.allclose(env.mocap_quat, home_quat())
+    mp = np.array([[0.4 + 0.02 * (i % 3), -0.1 + 0.03 * i, 0.55 + 0.01 * i] for i in range(N)])
+    t0 = env._robot.time
+    for _ in range(T):
+        env.interactive_tuning(mocap_pos=mp)
+    assert abs(env._robot.time - t0 - T * 5 * 0.001) < 1e-9 and not env.time_limit_exceeded()
+    gq = env.physics.qpos().astype(np.float64)
+    _, eef, _ = env.physics.sites()
+    assert np.abs(eef[:, :3] - (mp + [0.0, 0.0, 0.175])).max() < 0.02, "the controller site tracks the mocap target"
+    worst = 0.0
+    for i in range(N):
+        e = O.Env(oracle_model, int(env.nprops[i]), env.prop_half_size[i].astype(np.float32).astype(np.float64))
+        e.set_solver("Newton")
+        e.arr("qpos")[:43] = q0[i, :43]
+        e.forward()
+        p = O.make_osc()
+        p.target_pos[:] = mp[i] + [0.0, 0.0, 0.175]
+        p.target_quat[:] = home_quat()
+        for _ in range(T):
+            e.run_controller(p, 0.0, 1, 5)
+        n = int(env.nprops[i])
+        worst = max(worst, float(np.abs(gq[i, :15 + 7 * n] - e.arr("qpos")[:15 + 7 * n]).max()))
+    print(f"interactive_tuning: {N} envs x {T} ticks, max |dq| vs oracle {worst:.2e}")
+    assert worst < 1e-4
+    env.close()
