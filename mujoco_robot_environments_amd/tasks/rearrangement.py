@@ -161,6 +161,16 @@ class BatchedRearrangementEnv:
     def physics(self) -> BatchedPhysics:
         return self._physics
 
+    @property
+    def model(self) -> dict:
+        """tasks/rearrangement.py:219-221: the compiled model (arrays of model/compile.py; there is no MjModel)."""
+        return self._model
+
+    @property
+    def data(self) -> BatchedPhysics:
+        """tasks/rearrangement.py:223-225: the batched state holder (qpos / qvel / ctrl / contacts accessors)."""
+        return self._physics
+
     def _zeros_obs(self):
         h, w = self.overhead_camera_height, self.overhead_camera_width
         n = self.num_envs
