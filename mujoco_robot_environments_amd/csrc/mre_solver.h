@@ -314,11 +314,10 @@ MRE_PHASE_FN void assemble_constraints(ModelP M, Sm& s, int l) {
     if (q - M->jnt_range[l][0] < 0.f) { lim = 1; lim_side = -1; }
     else if (M->jnt_range[l][1] - q < 0.f) { lim = 1; lim_side = 1; }
   }
-  s.iscr[l] = lim;
-  MRE_SYNC();
-  int lim_idx = 0;
-  for (int k = 0; k < l; k++) lim_idx += s.iscr[k];
-  if (l == 63) s.nl = lim_idx + lim;
+  // (rows in joint order: the row index of a violated limit is the number of violated limits on the lanes below)
+  const unsigned long long limm = __ballot(lim != 0);
+  const int lim_idx = __popcll(limm & ((1ull << l) - 1ull));
+  if (l == 0) s.nl = __popcll(limm);
   if (lim) s.lim_info[lim_idx] = l | ((lim_side > 0 ? 1 : 0) << 8);
   // bodies of every contact's geoms (lane = contact): the serial loops below then read LDS only
   // instead of chasing pair -> geom -> body through the model tables once per contact
@@ -328,35 +327,46 @@ MRE_PHASE_FN void assemble_constraints(ModelP M, Sm& s, int l) {
     s.con_b2[l] = (uint8_t)M->geom_body[M->pair_g2[pr]];
   }
   MRE_SYNC();
-  // ---- robot-slot assignment and capacity (serial, lane 0)
-  if (l == 0) {
-    const int base = 7 + s.nl;
-    int rnext = base, ncon = s.ncon, kept = 0, bnext = 0;
-    for (int c = 0; c < ncon; c++) {
-      const int cb1 = s.con_b1[c], cb2 = s.con_b2[c];
-      const bool rob = cb1 < NRB && cb1 > 0;
-      const bool rob2 = cb2 < NRB && cb2 > 0;
-      const bool two_props = cb1 >= NRB && cb2 >= NRB;
-      if (base + 3 * (c + 1) > NEFC_MAX || ((rob || rob2) && rnext + 3 > NRROW_MAX) ||
-          (two_props && bnext >= NPP_MAX)) {
-        s.overflow = 1;
-        break;
-      }
-      s.con_rslot[c] = (rob || rob2) ? rnext : HDR_NONE;
-      if (rob || rob2) rnext += 3;
-      s.con_bslot[c] = two_props ? bnext : 0;
-      if (two_props) bnext++;
-      kept++;
-    }
-    s.ncon = kept;
-    s.nefc = base + 3 * kept;
-    s.nrrow = rnext;
-    s.npp = bnext;
-#ifdef MRE_NEWTON
-    s.nsched = 0; s.nblk = 0;  // (contact lists of the Newton solver: nw_build_lists, mre_newton.h)
-#else
-    build_schedule(M, s);
+#ifndef MRE_NEWTON
+  {
+    static_assert(sizeof(s.sched) % 4 == 0, "schedule cleared by words");
+    unsigned* w = reinterpret_cast<unsigned*>(&s.sched[0][0]);
+    for (int e = l; e < (int)(sizeof(s.sched) / 4); e += 64) w[e] = 0x01010101u * (unsigned)SCHED_NONE;
+  }
 #endif
+  // ---- robot-slot assignment and capacity (lane = contact; slots are prefix counts over the contacts below,
+  // the list is cut at the first contact that does not fit, exactly as a contact-by-contact loop would)
+  {
+    const int base = 7 + s.nl, ncon0 = s.ncon;
+    const bool on = l < ncon0;
+    const int cb1 = on ? s.con_b1[l] : 0, cb2 = on ? s.con_b2[l] : 0;
+    const bool rob_any = on && ((cb1 < NRB && cb1 > 0) || (cb2 < NRB && cb2 > 0));
+    const bool two_props = on && cb1 >= NRB && cb2 >= NRB;
+    const unsigned long long lt = (1ull << l) - 1ull;
+    const unsigned long long rmask = __ballot(rob_any), tmask = __ballot(two_props);
+    const int my_r = base + 3 * __popcll(rmask & lt), my_b = __popcll(tmask & lt);
+    const bool fail = on && (base + 3 * (l + 1) > NEFC_MAX || (rob_any && my_r + 3 > NRROW_MAX) ||
+                             (two_props && my_b >= NPP_MAX));
+    const unsigned long long fmask = __ballot(fail);
+    const int kept = fmask != 0ull ? (int)__builtin_ctzll(fmask) : ncon0;
+    if (l < kept) {
+      s.con_rslot[l] = rob_any ? my_r : HDR_NONE;
+      s.con_bslot[l] = two_props ? my_b : 0;
+    }
+    MRE_SYNC();
+    if (l == 0) {
+      const unsigned long long below = kept >= 64 ? ~0ull : ((1ull << kept) - 1ull);
+      if (fmask != 0ull) s.overflow = 1;
+      s.ncon = kept;
+      s.nefc = base + 3 * kept;
+      s.nrrow = base + 3 * __popcll(rmask & below);
+      s.npp = __popcll(tmask & below);
+#ifdef MRE_NEWTON
+      s.nsched = 0; s.nblk = 0;  // (contact lists of the Newton solver: nw_build_lists, mre_newton.h)
+#else
+      build_schedule(M, s);
+#endif
+    }
   }
   MRE_SYNC();
   const int nefc = s.nefc, nl = s.nl;
@@ -621,8 +631,7 @@ MRE_DEV void build_schedule(ModelP M, Sm& s) {
   for (int k = 0; k < 5; k++) last[k] = 0;
   const int nscalar = 7 + s.nl;
   int nb = 0, nst = 0;
-  for (int st = 0; st < MAXBLK; st++)
-    for (int k = 0; k < 5; k++) s.sched[st][k] = SCHED_NONE;
+  // (every entry of s.sched was set to SCHED_NONE by the whole wave before this lane-0 routine)
   for (int i = 0; i < nscalar; i += 3) {
     Blk b;
     b.row0 = (uint16_t)i; b.type = 0; b.nrows = (uint8_t)((nscalar - i) < 3 ? (nscalar - i) : 3);
