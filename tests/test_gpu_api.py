@@ -317,3 +317,30 @@ def test_bench_two_rank_rehearsal_on_one_gpu():
     assert d["config"]["envs_per_gpu"] == 4096
     # value = units all ranks processed / max-over-ranks time
     assert abs(d["value"] - 2 * 4096 * 5 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+
+
+def test_launch_info_reports_high_water_marks_and_durations(compiled_model):
+    """mre_get_launch_info: the per-env record of the last stepping launch that the capacity fallback and the
+    longest-first dispatch read -- overflow flag, high-water marks, the env's own duration."""
+    import torch
+    from mujoco_robot_environments_amd import rng
+    from mujoco_robot_environments_amd.physics import BatchedPhysics
+    A, _ = compiled_model
+    N = 128
+    ids = np.arange(N)
+    phys = BatchedPhysics(N, model=A, solver="Newton")
+    nprops, sizes = rng.prop_params(3, ids)
+    phys.set_props(nprops, sizes)
+    phys.reset()
+    phys.place_props(3, np.array([0.35, -0.4, 0.43], np.float32), np.array([0.55, 0.4, 0.435], np.float32), settle_steps=300)
+    seq = torch.from_numpy(rng.random_actions(3, ids, np.arange(4), scale=0.1).astype(np.float32)).to(phys.device).contiguous()
+    for t in range(4):
+        phys.rollout(seq[t:t + 1], control_steps=5)
+    li = phys.launch_info()
+    st = phys.solver_stats()
+    assert (li["overflow"] == 0).all() and (li["duration"] > 0).all()
+    # resting cubes: 4 table contacts each, 7 equality rows + 3 rows per contact; the marks bound the last step's counts
+    assert (li["ncon"] >= st[:, 0]).all() and (li["nefc"] >= st[:, 1]).all()
+    assert (li["ncon"] >= 4 * nprops).all() and (li["nefc"] >= 7 + 3 * li["ncon"] - 3).all()
+    assert (li["nrrow"] >= 7).all() and (li["npp"] == 0).all()
+    phys.close()
