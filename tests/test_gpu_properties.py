@@ -170,3 +170,33 @@ def test_gpu_arm_energy_balance(compiled_model):
     residual = (e[:, 0] + e[:, 1] + diss) - (e0[:, 0] + e0[:, 1])
     assert (np.abs(residual) < 0.03 * converted).all(), (residual, converted)
     phys.close()
+
+
+def test_configs3_shards_of_a_32768_env_job_equal_the_single_batch():
+    """BASELINE.json configs[3]: 32768 envs sharded over 8 ranks by global env id (rank r owns
+    [4096 r, 4096 (r + 1)), distributed.shard_env_ids), no data-path collective, one gather at the end.  The
+    eight per-rank workloads run here one after the other on one GPU and their gathered final state must be,
+    bit for bit, the state of the same 32768 envs stepped as one batch (Newton, 10 ticks)."""
+    import torch
+    import bench
+    from mujoco_robot_environments_amd import distributed as D, rng
+    from mujoco_robot_environments_amd.physics import BatchedPhysics
+    world, per, ticks, seed = 8, 4096, 10, 0
+
+    def run(ids):
+        phys = BatchedPhysics(len(ids), solver="Newton")
+        bench.setup_envs(phys, seed, ids)
+        acts = torch.from_numpy(rng.random_actions(seed, ids, np.arange(ticks)).astype(np.float32)).to(phys.device)
+        for t in range(ticks):
+            phys.rollout(acts[t:t + 1].contiguous(), control_steps=5)
+        qp, qv = phys.get_state()
+        out = D.pack_final_state(qp[:, :43], qv[:, :39], phys.status()).numpy()
+        phys.close()
+        return out
+    whole = run(np.arange(world * per))
+    assert np.isfinite(whole).all() and whole.shape[0] == world * per
+    for r in range(world):
+        ids = D.shard_env_ids(world * per, r, world)
+        assert ids[0] == r * per and len(ids) == per
+        part = run(ids)
+        assert np.array_equal(part, whole[r * per:(r + 1) * per]), f"rank {r}"
