@@ -230,23 +230,29 @@ struct NwPoint { float alpha, cost, d1, d2; };
 // fixed the kept contacts and their robot slots).  A phase of its own: the row assembly is at the
 // edge of its register budget.
 MRE_PHASE_FN void nw_build_lists(Sm& s, int l) {
-  if (l == 0) {
-    int cnt[NPROP] = {0, 0, 0, 0};
-    unsigned cr = 0u, cc = 0u;
-    const int kept = s.ncon;
-    for (int c = 0; c < kept; c++) {
-      const int cb1 = s.con_b1[c], cb2 = s.con_b2[c];
-      int pa = -1, pb = -1;
-      if (cb1 >= NRB) pa = cb1 - NRB;
-      if (cb2 >= NRB) { if (pa < 0) pa = cb2 - NRB; else pb = cb2 - NRB; }
-      if (pa >= 0) s.clist[pa][cnt[pa]++] = (uint8_t)c;
-      if (pb >= 0) s.clist[pb][cnt[pb]++] = (uint8_t)(c | 0x80);
-      if (s.con_rslot[c] != HDR_NONE && pa >= 0) cr |= 1u << pa;
-      if (pb >= 0) cc |= 1u << cube_pair_bit(pa, pb);
-    }
-    for (int p = 0; p < NPROP; p++) s.ccount[p] = (uint8_t)cnt[p];
-    s.cpl_robot = (uint8_t)cr; s.cpl_cubes = (uint8_t)cc;
+  // lane = contact; a cube's list is the ascending run of the contacts that touch it (ballot prefix counts)
+  const int kept = s.ncon;
+  const bool on = l < kept;
+  const int cb1 = on ? s.con_b1[l] : 0, cb2 = on ? s.con_b2[l] : 0;
+  int pa = -1, pb = -1;
+  if (cb1 >= NRB) pa = cb1 - NRB;
+  if (cb2 >= NRB) { if (pa < 0) pa = cb2 - NRB; else pb = cb2 - NRB; }
+  const unsigned long long lt = (1ull << l) - 1ull;
+  const bool rob = on && pa >= 0 && s.con_rslot[on ? l : 0] != HDR_NONE;
+  unsigned cr = 0u, cc = 0u;
+#pragma unroll
+  for (int p = 0; p < NPROP; p++) {
+    const bool mine = on && (pa == p || pb == p);
+    const unsigned long long m = __ballot(mine);
+    if (mine) s.clist[p][__popcll(m & lt)] = (uint8_t)(pb == p ? (l | 0x80) : l);
+    if (l == 0) s.ccount[p] = (uint8_t)__popcll(m);
+    if (__ballot(rob && pa == p) != 0ull) cr |= 1u << p;
   }
+  const int pairbit = (on && pb >= 0) ? cube_pair_bit(pa, pb) : -1;
+#pragma unroll
+  for (int b = 0; b < 6; b++)
+    if (__ballot(pairbit == b) != 0ull) cc |= 1u << b;
+  if (l == 0) { s.cpl_robot = (uint8_t)cr; s.cpl_cubes = (uint8_t)cc; }
   MRE_SYNC();
 }
 
