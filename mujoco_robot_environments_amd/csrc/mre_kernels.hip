@@ -670,6 +670,23 @@ MRE_PHASE_FN void solve_robot_par(ModelP M, const float* LD, const float* dinv, 
   }
 }
 
+// One right-hand side through the register-resident solve: every lane runs mj_solveLD on its own copy (the
+// factor entries are broadcast LDS reads at constant offsets, issued ahead of the dependent chain) and lane i
+// keeps component i.  Same operations in the same order as solve_robot_par and as the serial routine -- and a
+// third of its instructions, with no level-by-level LDS round trips.
+MRE_PHASE_FN void solve_robot_one(const float* LD, const float* dinv, float* xv, int l) {
+  float x[NRV];
+#pragma unroll
+  for (int i = 0; i < NRV; i++) x[i] = xv[i];
+  solve_robot_regs(LD, dinv, x);
+  MRE_SYNC();
+  float mine = 0.f;
+#pragma unroll
+  for (int i = 0; i < NRV; i++) mine = (l == i) ? x[i] : mine;
+  if (l < NRV) xv[l] = mine;
+  MRE_SYNC();
+}
+
 }  // namespace mre
 #include "mre_solver.h"
 #ifdef MRE_NEWTON
@@ -793,7 +810,7 @@ MRE_DEV bool smooth_forces(ModelP M, Sm& s, int l) {
     s.qacc_smooth[l] = f;
   }
   MRE_SYNC();
-  solve_robot_par(M, s.qLD, s.qLDinv, s.qacc_smooth, 0, 1, l);
+  solve_robot_one(s.qLD, s.qLDinv, s.qacc_smooth, l);
   if (l >= NRV && l < NV) {
     const int p = (l - NRV) / 6, k = (l - NRV) % 6;
     const float md = (k < 3) ? s.prop_mass[p] : s.prop_inertia[p][k - 3];
@@ -1003,7 +1020,7 @@ MRE_DEV void step_body(const StepArgs& a, Sm& s) {
 
     integrate_setup(M, s, l, clamped);
     factor_robot_regs(s.qLD, s.qLD, s.qLDinv);
-    solve_robot_par(M, s.qLD, s.qLDinv, s.scratch, 0, 1, l);
+    solve_robot_one(s.qLD, s.qLDinv, s.scratch, l);
     integrate(M, s, l, a.flags);
     steps_done = step + 1;
     if ((a.flags & F_SETTLE_EXIT) != 0) {
