@@ -87,7 +87,7 @@ struct DevModel {
   int M_i[NMR], M_j[NMR];        // entry e = M(i, j), j ancestor-or-self of i
   int fac_n[NRV];                // elimination step k: number of (i,j) updates
   uint8_t fac_dst[NRV][MAXFAC], fac_a[NRV][MAXFAC], fac_b[NRV][MAXFAC];
-  // level-parallel L'DL solve (solve_robot_par): per dof its depth in the dof tree, its
+  // (tables of a former level-parallel L'DL solve, still filled and checked by the host:) per dof its depth in the dof tree, its
   // descendants in descending order and its ancestors nearest first, each entry packed as
   // dof | (address of the L entry in qLD) << 8, two entries per word (0xFFFF = none)
   int sol_depth[NRV + 1], sol_maxdepth;

@@ -624,56 +624,10 @@ MRE_DEV void factor_robot_regs(const float* src_, float* LD_, float* dinv_) {
   MRE_SYNC();
 }
 
-// x <- M^-1 x for up to four right-hand sides at once, level-parallel: lane = (group g = l / 16,
-// dof i = l % 16), group g works on xb + g * xstride (LDS).  Backward pass from the deepest dofs
-// up (a dof folds in all its descendants, which are final), scaling, forward pass from the roots
-// down; the terms of every sum are applied in mj_solveLD's order, so the result is bit-identical
-// to the serial algorithm.  The dof tree is at most sol_maxdepth + 1 levels deep (9 for this robot).
-MRE_PHASE_FN void solve_robot_par(ModelP M, const float* LD, const float* dinv, float* xb, int xstride,
-                                  int ngroups, int l) {
-  const int g = l >> 4, i = l & 15;
-  const bool on = i < NRV && g < ngroups;
-  float* x = xb + g * xstride;
-  const int ii = on ? i : NRV;  // row NRV of the tables is empty
-  const int depth = M->sol_depth[ii];
-  uint32_t dw[7], aw[4];
-#pragma unroll
-  for (int k = 0; k < 7; k++) dw[k] = M->sol_desc[ii][k];
-#pragma unroll
-  for (int k = 0; k < 4; k++) aw[k] = M->sol_anc[ii][k];
-  const int maxd = M->sol_maxdepth;
-  for (int d = maxd; d >= 0; --d) {
-    if (depth == d) {
-      float acc = x[i];
-#pragma unroll
-      for (int k = 0; k < 14; k++) {
-        const uint32_t e = (dw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
-        if (e != 0xFFFFu) acc -= LD[e >> 8] * x[e & 0xFFu];
-      }
-      x[i] = acc;
-    }
-    MRE_SYNC();
-  }
-  if (on) x[i] *= dinv[i];
-  MRE_SYNC();
-  for (int d = 1; d <= maxd; ++d) {
-    if (depth == d) {
-      float acc = x[i];
-#pragma unroll
-      for (int k = 0; k < 8; k++) {
-        const uint32_t e = (aw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
-        if (e != 0xFFFFu) acc -= LD[e >> 8] * x[e & 0xFFu];
-      }
-      x[i] = acc;
-    }
-    MRE_SYNC();
-  }
-}
-
 // One right-hand side through the register-resident solve: every lane runs mj_solveLD on its own copy (the
 // factor entries are broadcast LDS reads at constant offsets, issued ahead of the dependent chain) and lane i
-// keeps component i.  Same operations in the same order as solve_robot_par and as the serial routine -- and a
-// third of its instructions, with no level-by-level LDS round trips.
+// keeps component i.  Same operations in the same order as the serial routine; it replaced a level-parallel
+// form (lane = dof, 9 tree levels up and 9 down, an LDS round trip per level) at a third of the instructions.
 MRE_PHASE_FN void solve_robot_one(const float* LD, const float* dinv, float* xv, int l) {
   float x[NRV];
 #pragma unroll
