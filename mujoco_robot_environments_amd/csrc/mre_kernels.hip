@@ -191,14 +191,17 @@ MRE_DEV void kinematics(ModelP M, Sm& s, int l, BodyRegs& br) {
         m3mulv(tmp, s.xmat[p], bpos);
         v3add(xp, s.xpos[p], tmp);
         qmul(q0, s.xquat[p], bquat);
-        qrotv(tmp, q0, jpos);
-        v3add(br.anchor, xp, tmp);
+        // (a joint at its body's origin -- every hinge of this robot but the two finger followers -- has
+        //  anchor = body position before and after the rotation: the two rotations of a zero vector are skipped,
+        //  x + 0 and x - 0 being x)
+        const bool off = jpos[0] != 0.f || jpos[1] != 0.f || jpos[2] != 0.f;
+        v3copy(br.anchor, xp);
+        if (off) { qrotv(tmp, q0, jpos); v3add(br.anchor, xp, tmp); }
         qrotv(br.axis, q0, jaxis);
         axisangle2q(ql, jaxis, s.qpos[qa] - qref);
         qmul(xq, q0, ql);
         qnormalize(xq);
-        qrotv(tmp, xq, jpos);
-        v3sub(xp, br.anchor, tmp);
+        if (off) { qrotv(tmp, xq, jpos); v3sub(xp, br.anchor, tmp); }
       }
       float xm[9], qi[4], tmp[3];
       q2mat(xm, xq);
