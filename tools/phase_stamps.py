@@ -19,7 +19,8 @@ NAMES = ["position+crb+factor", "velocity", "collide", "assemble", "control", "s
 if sys.argv[1] == "build":
     os.makedirs(DIAG, exist_ok=True)
     for k in ([int(x) for x in sys.argv[2:]] or (0, 1, 2, 3, 4, 5, 6, 7)):
-        base = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-ffp-contract=on"]
+        base = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-ffp-contract=on",
+                "-fno-hip-fp32-correctly-rounded-divide-sqrt"]
         objs = []
         for name, src, flags in (("k", "mre_kernels.hip", [f"-DMRE_PHASE_STAMPS={k}"]),
                                  ("kl", "mre_kernels.hip", ["-DMRE_LARGE_CAPS", f"-DMRE_PHASE_STAMPS={k}"]),
