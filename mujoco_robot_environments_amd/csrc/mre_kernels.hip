@@ -155,66 +155,91 @@ MRE_DEV bool body_is_active(ModelP M, const Sm& s, int b) {
 }
 
 // ------------------------------------------------------------ mj_kinematics
+// A body frame in registers, and mj_kinematics' step for one hinge body: parent frame -> own frame, joint
+// anchor and axis.
+struct Frame { float p[3], q[4], m[9]; };
+MRE_DEV void hinge_body(const Frame& F, const float* bpos, const float* bquat, const float* jpos,
+                        const float* jaxis, float angle, Frame& out, float* anchor, float* axis) {
+  float tmp[3], q0[4], ql[4];
+  m3mulv(tmp, F.m, bpos);
+  v3add(out.p, F.p, tmp);
+  qmul(q0, F.q, bquat);
+  // (a joint at its body's origin -- every hinge of this robot but the two finger followers -- has
+  //  anchor = body position before and after the rotation: the two rotations of a zero vector are skipped,
+  //  x + 0 and x - 0 being x)
+  const bool off = jpos[0] != 0.f || jpos[1] != 0.f || jpos[2] != 0.f;
+  v3copy(anchor, out.p);
+  if (off) { qrotv(tmp, q0, jpos); v3add(anchor, out.p, tmp); }
+  qrotv(axis, q0, jaxis);
+  axisangle2q(ql, jaxis, angle);
+  qmul(out.q, q0, ql);
+  qnormalize(out.q);
+  if (off) { qrotv(tmp, out.q, jpos); v3sub(out.p, anchor, tmp); }
+  q2mat(out.m, out.q);
+}
+
+// The tree is walked in registers, not level by level through LDS: the arm is a chain (body k hangs off body
+// k - 1, one hinge each: mre_create checks the dof tree against ROBOT_DOF_PARENT), so every lane computes links
+// 1..7 itself -- the same values in all lanes, model constants at compile-time indices -- and keeps the frame of
+// the link it owns; a finger body sits one or two hinges below link 7 and its lane adds those; a cube's frame is
+// its free joint's qpos.  Same operations per body as the level-by-level form it replaces (same bits), without
+// its nine LDS round trips and ordering points.
 // writeback: store the normalised free-joint quaternions in qpos (mj_kinematics does); the
 // query-only pass at the end of a launch must leave the state bits alone
 template <bool WRITEBACK>
 MRE_DEV void kinematics(ModelP M, Sm& s, int l, BodyRegs& br) {
-  if (l == 0) {
-    v3zero(s.xpos[0]);
-    s.xquat[0][0] = 1.f; s.xquat[0][1] = s.xquat[0][2] = s.xquat[0][3] = 0.f;
-    for (int k = 0; k < 9; k++) s.xmat[0][k] = (k % 4 == 0) ? 1.f : 0.f;
+  constexpr int LINK7 = GRIP_BODY0 - 1;
+  Frame F;   // running parent frame, starts as the world
+  v3zero(F.p);
+  F.q[0] = 1.f; F.q[1] = F.q[2] = F.q[3] = 0.f;
+#pragma unroll
+  for (int k = 0; k < 9; k++) F.m[k] = (k % 4 == 0) ? 1.f : 0.f;
+  Frame mine = F;
+  v3zero(br.anchor); v3zero(br.axis);
+#pragma unroll
+  for (int k = 1; k <= LINK7; k++) {
+    Frame G;
+    float an[3], ax[3];
+    hinge_body(F, M->body_pos[k], M->body_quat[k], M->jnt_pos[k], M->jnt_axis[k], s.qpos[k - 1] - M->qpos0[k - 1],
+               G, an, ax);
+    if (l == k) { mine = G; v3copy(br.anchor, an); v3copy(br.axis, ax); }
+    F = G;
+  }
+  const int b = l < NB ? l : 0;
+  if (l >= GRIP_BODY0 && l < NRB) {
+    const int par = M->body_parent[b];
+    Frame P = F;
+    if (par != LINK7) {   // the parent is a finger body itself: its frame first
+      float an[3], ax[3];
+      const int qp = M->body_qposadr[par];
+      hinge_body(F, M->body_pos[par], M->body_quat[par], M->jnt_pos[par], M->jnt_axis[par], s.qpos[qp] - M->qpos0[qp],
+                 P, an, ax);
+    }
+    const int qa = M->body_qposadr[b];
+    hinge_body(P, M->body_pos[b], M->body_quat[b], M->jnt_pos[b], M->jnt_axis[b], s.qpos[qa] - M->qpos0[qa],
+               mine, br.anchor, br.axis);
+  }
+  if (l >= NRB && l < NB) {   // cubes: free joints
+    const int qa = M->body_qposadr[b];
+    v3copy(mine.p, &s.qpos[qa]);
+    for (int k = 0; k < 4; k++) mine.q[k] = s.qpos[qa + 3 + k];
+    qnormalize(mine.q);
+    if (WRITEBACK) for (int k = 0; k < 4; k++) s.qpos[qa + 3 + k] = mine.q[k];
+    q2mat(mine.m, mine.q);
+    v3copy(br.anchor, mine.p);
+    br.axis[0] = 0.f; br.axis[1] = 0.f; br.axis[2] = 1.f;
+  }
+  if (l < NB) {
+    v3copy(s.xpos[b], mine.p);
+    for (int k = 0; k < 4; k++) s.xquat[b][k] = mine.q[k];
+    for (int k = 0; k < 9; k++) s.xmat[b][k] = mine.m[k];
+    float tmp[3], qi[4];
+    m3mulv(tmp, mine.m, M->body_ipos[b]);
+    v3add(br.xipos, mine.p, tmp);
+    qmul(qi, mine.q, M->body_iquat[b]);
+    q2mat(br.ximat, qi);
   }
   MRE_SYNC();
-  // the lane's body constants are fetched before the level loop: one batch of global loads whose latency
-  // is paid once, instead of one dependent fetch per level behind a fence
-  const int b = l < NB ? l : 0;
-  const int lvl = (l < NB) ? M->body_level[b] : -1;
-  const int qa = M->body_qposadr[b], jtype = M->body_jnttype[b], par = M->body_parent[b];
-  float bpos[3], bquat[4], jpos[3], jaxis[3], ipos[3], iquat[4];
-  v3copy(bpos, M->body_pos[b]); v3copy(jpos, M->jnt_pos[b]); v3copy(jaxis, M->jnt_axis[b]);
-  v3copy(ipos, M->body_ipos[b]);
-  for (int k = 0; k < 4; k++) { bquat[k] = M->body_quat[b][k]; iquat[k] = M->body_iquat[b][k]; }
-  const float qref = M->qpos0[qa];
-  for (int level = 1; level <= MAXCHAIN; ++level) {
-    if (lvl == level) {
-      float xp[3], xq[4];
-      if (jtype == 2) {
-        v3copy(xp, &s.qpos[qa]);
-        for (int k = 0; k < 4; k++) xq[k] = s.qpos[qa + 3 + k];
-        qnormalize(xq);
-        if (WRITEBACK) for (int k = 0; k < 4; k++) s.qpos[qa + 3 + k] = xq[k];
-        v3copy(br.anchor, xp);
-        br.axis[0] = 0.f; br.axis[1] = 0.f; br.axis[2] = 1.f;
-      } else {
-        const int p = par;
-        float tmp[3], q0[4], ql[4];
-        m3mulv(tmp, s.xmat[p], bpos);
-        v3add(xp, s.xpos[p], tmp);
-        qmul(q0, s.xquat[p], bquat);
-        // (a joint at its body's origin -- every hinge of this robot but the two finger followers -- has
-        //  anchor = body position before and after the rotation: the two rotations of a zero vector are skipped,
-        //  x + 0 and x - 0 being x)
-        const bool off = jpos[0] != 0.f || jpos[1] != 0.f || jpos[2] != 0.f;
-        v3copy(br.anchor, xp);
-        if (off) { qrotv(tmp, q0, jpos); v3add(br.anchor, xp, tmp); }
-        qrotv(br.axis, q0, jaxis);
-        axisangle2q(ql, jaxis, s.qpos[qa] - qref);
-        qmul(xq, q0, ql);
-        qnormalize(xq);
-        if (off) { qrotv(tmp, xq, jpos); v3sub(xp, br.anchor, tmp); }
-      }
-      float xm[9], qi[4], tmp[3];
-      q2mat(xm, xq);
-      v3copy(s.xpos[b], xp);
-      for (int k = 0; k < 4; k++) s.xquat[b][k] = xq[k];
-      for (int k = 0; k < 9; k++) s.xmat[b][k] = xm[k];
-      m3mulv(tmp, xm, ipos);
-      v3add(br.xipos, xp, tmp);
-      qmul(qi, xq, iquat);
-      q2mat(br.ximat, qi);
-    }
-    MRE_SYNC();
-  }
   // sites (lane = site)
   if (l < NSITE) {
     const int b = M->site_body[l];
