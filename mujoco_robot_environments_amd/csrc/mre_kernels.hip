@@ -656,7 +656,7 @@ MRE_DEV void factor_robot_regs(const float* src_, float* LD_, float* dinv_) {
 // factor entries are broadcast LDS reads at constant offsets, issued ahead of the dependent chain) and lane i
 // keeps component i.  Same operations in the same order as the serial routine; it replaced a level-parallel
 // form (lane = dof, 9 tree levels up and 9 down, an LDS round trip per level) at a third of the instructions.
-MRE_PHASE_FN void solve_robot_one(const float* LD, const float* dinv, float* xv, int l) {
+MRE_DEV void solve_robot_one(const float* LD, const float* dinv, float* xv, int l) {
   float x[NRV];
 #pragma unroll
   for (int i = 0; i < NRV; i++) x[i] = xv[i];
