@@ -259,7 +259,7 @@ MRE_DEV void com_pos(ModelP M, Sm& s, int l, const BodyRegs& br) {
   float c0 = robot ? mass * br.xipos[0] : 0.f;
   float c1 = robot ? mass * br.xipos[1] : 0.f;
   float c2 = robot ? mass * br.xipos[2] : 0.f;
-  c0 = wave_sum(c0); c1 = wave_sum(c1); c2 = wave_sum(c2);
+  wave_sum3(c0, c1, c2);
   const float inv = 1.0f / M->robot_mass;
   float com[3] = {c0 * inv, c1 * inv, c2 * inv};
   if (l == 0) v3copy(s.com_robot, com);

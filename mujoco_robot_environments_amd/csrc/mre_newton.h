@@ -572,9 +572,8 @@ MRE_PHASE_FN float nw_search_move(ModelP M, Sm& s, int l) {
   float alpha = 0.f;
   if (snorm >= kMinVal) {
     const float gtol = tol * NW_LS_TOL * snorm / c.scale;
-    const float g0 = wave_sum(0.5f * (Ma - fs) * (qa - as));
-    const float g1 = wave_sum(sv * (Ma - fs));
-    const float g2 = wave_sum(0.5f * sv * Mv);
+    float g0 = 0.5f * (Ma - fs) * (qa - as), g1 = sv * (Ma - fs), g2 = 0.5f * sv * Mv;
+    wave_sum3(g0, g1, g2);
     // per-lane terms: one scalar row and one contact
     float sq0 = 0.f, sq1 = 0.f, sq2 = 0.f, sj = 0.f, svv = 0.f;
     const bool s_on = l < nscalar, s_eq = l < 7;
@@ -626,9 +625,11 @@ MRE_PHASE_FN float nw_search_move(ModelP M, Sm& s, int l) {
       }
       NwPoint p;
       p.alpha = a;
-      p.cost = wave_sum(ec + q0 + a * (q1 + a * q2)) + g0 + a * (g1 + a * g2);
-      p.d1 = wave_sum(e1 + q1 + 2.f * a * q2) + g1 + 2.f * a * g2;
-      p.d2 = wave_sum(e2 + 2.f * q2) + 2.f * g2;
+      float s0 = ec + q0 + a * (q1 + a * q2), s1 = e1 + q1 + 2.f * a * q2, s2 = e2 + 2.f * q2;
+      wave_sum3(s0, s1, s2);
+      p.cost = s0 + g0 + a * (g1 + a * g2);
+      p.d1 = s1 + g1 + 2.f * a * g2;
+      p.d2 = s2 + 2.f * g2;
       return p;
     };
     const NwPoint p0 = eval(0.f);
