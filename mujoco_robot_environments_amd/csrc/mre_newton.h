@@ -352,6 +352,7 @@ MRE_PHASE_FN void nw_direction(ModelP M, Sm& s, int l) {
   // issue: operand lane 16 k + m holds row r0 + k at tile dof m (A = J D, B = J), and the six tiles of the lower
   // triangle accumulate in 24 registers.  Per chunk of four rows a lane fetches its row's header, state and 1 / R
   // and ONE Jacobian word per tile -- no per-row branches, no cross-lane traffic.  Rows in any other state enter with D = 0.
+  MRE_DBG_STAMP(4, 0);
   typedef float v4f __attribute__((ext_vector_type(4)));
   v4f c00 = {0.f, 0.f, 0.f, 0.f}, c10 = c00, c11 = c00, c20 = c00, c21 = c00, c22 = c00;
   {
@@ -359,56 +360,64 @@ MRE_PHASE_FN void nw_direction(ModelP M, Sm& s, int l) {
     const int tp = m16 < 12 ? m16 / 6 : -1;   // cube of this lane's dof in tile 1 (tile 2: tp + 2)
     const int tk = m16 % 6;
     // (the metadata of the next chunk is fetched while the Jacobian words of this one are on their way)
-    auto meta = [&](int r0, int& ii, int& st, int& h, float& R) {
+    auto meta = [&](int r0, int& ii, int& st, int& h, float& R, int& bs) {
       const int i = r0 + g;
       ii = i < nefc ? i : 0;
       st = i < nefc ? (int)s.rstate[ii] : NW_SAT;
       h = s.hdr[ii];
       R = s.efc_R[ii];
+      const int cr = ii - nscalar;
+      bs = s.con_bslot[cr > 0 ? cr / 3 : 0];   // slot of the contact's second-cube rows (0 where it has none)
     };
-    int iiN, stN, hN;
+    int iiN, stN, hN, bsN;
     float RN;
-    meta(0, iiN, stN, hN, RN);
-    // J of constraint row (contact-row index crx, robot slot rsx) at this lane's dof of the three tiles
-    auto gather = [&](int crx, int rsx, int pa, int pb, float& w0, float& w1, float& w2) {
-      w0 = 0.f; w1 = 0.f; w2 = 0.f;
-      if (rsx != HDR_NONE && m16 < NRV) w0 = s.Jr[rsx][m16];
-      if (tp >= 0) {
-        if (pa == tp) w1 = s.JpA[crx][tk];
-        else if (pb == tp) w1 = s.JpB[3 * s.con_bslot[crx / 3] + crx % 3][tk];
-        if (nprops > 2) {
-          if (pa == tp + 2) w2 = s.JpA[crx][tk];
-          else if (pb == tp + 2) w2 = s.JpB[3 * s.con_bslot[crx / 3] + crx % 3][tk];
-        }
-      }
+    meta(0, iiN, stN, hN, RN, bsN);
+    // J of constraint row (contact-row index crx, robot slot rsx, second-cube row bx) at this lane's dof of the
+    // three tiles: the three candidate words are read unconditionally (clamped addresses) and selected, so
+    // the reads of a chunk -- nine for a row in the cone's middle zone -- are in flight together
+    auto gather = [&](int crx, int rsx, int bx, int pa, int pb, float& w0, float& w1, float& w2) {
+      const float jr = s.Jr[rsx != HDR_NONE ? rsx : 0][m16 < NRV ? m16 : 0];
+      const float ja = s.JpA[crx > 0 ? crx : 0][tk];
+      const float jb = s.JpB[bx][tk];
+      w0 = (rsx != HDR_NONE && m16 < NRV) ? jr : 0.f;
+      w1 = tp < 0 ? 0.f : (pa == tp ? ja : (pb == tp ? jb : 0.f));
+      w2 = (tp < 0 || nprops <= 2) ? 0.f : (pa == tp + 2 ? ja : (pb == tp + 2 ? jb : 0.f));
     };
     for (int r0 = 0; r0 < nefc; r0 += 4) {
-      const int ii = iiN, h = hN, st = stN;
+      const int ii = iiN, h = hN, st = stN, bs = bsN;
       const bool quad = st == NW_QUAD, cone = st == NW_CONE;
       const float D = quad ? 1.0f / RN : 0.f;
-      if (r0 + 4 < nefc) meta(r0 + 4, iiN, stN, hN, RN);
+      if (r0 + 4 < nefc) meta(r0 + 4, iiN, stN, hN, RN, bsN);
       const int rs = h & 0xFF, pa = (h >> 8) & 0xF, pb = (h >> 12) & 0xF;
       const int cr = ii - nscalar;   // contact row index (prop parts exist for contact rows only)
-      float v0 = 0.f, v1 = 0.f, v2 = 0.f;
-      if (quad || cone) gather(cr, rs, pa, pb, v0, v1, v2);
-      float a0 = v0 * D, a1 = v1 * D, a2 = v2 * D;
-      if (cone) {
+      const int k = cr > 0 ? cr % 3 : 0;
+      float v0 = 0.f, v1 = 0.f, v2 = 0.f, a0, a1, a2;
+      if (__any(cone)) {
         // a contact in the middle zone enters with its 3 x 3 Hessian: row k of the contact contributes
-        // (sum_m Hc[k][m] J_m)' J_k, so the A operand of this lane is the Hc-weighted mix of the contact's three
-        // rows at its dof (the robot slots and prop rows of one contact are consecutive)
-        const int k = cr % 3, cc = cr / 3, cr0 = cr - k;
-        const int rs0 = rs != HDR_NONE ? rs - k : HDR_NONE;
-        const float* hc = s.hc[cc];
-        const float H0 = k == 0 ? hc[0] : (k == 1 ? hc[1] : hc[2]);
-        const float H1 = k == 0 ? hc[1] : (k == 1 ? hc[3] : hc[4]);
-        const float H2 = k == 0 ? hc[2] : (k == 1 ? hc[4] : hc[5]);
+        // (sum_m Hc[k][m] J_m)' J_k, so the A operand of such a lane is the Hc-weighted mix of the contact's three
+        // rows at its dof (the robot slots and prop rows of one contact are consecutive); the other lanes of the
+        // chunk read their own row three times
+        const int cr0 = cone ? cr - k : cr, d1 = cone ? 1 : 0, d2 = cone ? 2 : 0, kk = cone ? k : 0;
+        const int rs0 = rs != HDR_NONE ? rs - kk : HDR_NONE;
         float x0, x1, x2, y0, y1, y2, z0, z1, z2;
-        gather(cr0, rs0, pa, pb, x0, x1, x2);
-        gather(cr0 + 1, rs0 != HDR_NONE ? rs0 + 1 : HDR_NONE, pa, pb, y0, y1, y2);
-        gather(cr0 + 2, rs0 != HDR_NONE ? rs0 + 2 : HDR_NONE, pa, pb, z0, z1, z2);
-        a0 = H0 * x0 + H1 * y0 + H2 * z0;
-        a1 = H0 * x1 + H1 * y1 + H2 * z1;
-        a2 = H0 * x2 + H1 * y2 + H2 * z2;
+        gather(cr0, rs0, 3 * bs + (cone ? 0 : k), pa, pb, x0, x1, x2);
+        gather(cr0 + d1, rs0 != HDR_NONE ? rs0 + d1 : HDR_NONE, 3 * bs + (cone ? 1 : k), pa, pb, y0, y1, y2);
+        gather(cr0 + d2, rs0 != HDR_NONE ? rs0 + d2 : HDR_NONE, 3 * bs + (cone ? 2 : k), pa, pb, z0, z1, z2);
+        const float* hcp = s.hc[cone ? cr / 3 : 0];
+        const float H0 = k == 0 ? hcp[0] : (k == 1 ? hcp[1] : hcp[2]);
+        const float H1 = k == 0 ? hcp[1] : (k == 1 ? hcp[3] : hcp[4]);
+        const float H2 = k == 0 ? hcp[2] : (k == 1 ? hcp[4] : hcp[5]);
+        const bool onr = quad || cone;
+        v0 = !onr ? 0.f : (kk == 0 ? x0 : (kk == 1 ? y0 : z0));
+        v1 = !onr ? 0.f : (kk == 0 ? x1 : (kk == 1 ? y1 : z1));
+        v2 = !onr ? 0.f : (kk == 0 ? x2 : (kk == 1 ? y2 : z2));
+        a0 = cone ? H0 * x0 + H1 * y0 + H2 * z0 : v0 * D;
+        a1 = cone ? H0 * x1 + H1 * y1 + H2 * z1 : v1 * D;
+        a2 = cone ? H0 * x2 + H1 * y2 + H2 * z2 : v2 * D;
+      } else {
+        gather(cr, rs, 3 * bs + k, pa, pb, v0, v1, v2);
+        if (!quad) { v0 = 0.f; v1 = 0.f; v2 = 0.f; }
+        a0 = v0 * D; a1 = v1 * D; a2 = v2 * D;
       }
       c00 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, v0, c00, 0, 0, 0);
       c10 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, v0, c10, 0, 0, 0);
@@ -419,6 +428,7 @@ MRE_PHASE_FN void nw_direction(ModelP M, Sm& s, int l) {
         c22 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, v2, c22, 0, 0, 0);
       }
     }
+    MRE_DBG_STAMP(4, 1);
     // Tiles -> rows: lane j needs row j of H.  One tile at a time through LDS (the factor's home, unused until
     // the elimination is over): the accumulator of lane 16 q + n holds C[4 q + v][n], v = 0..3.  The lanes that
     // own the tile's row dofs read a row, and for an off-diagonal tile the lanes that own its column dofs
@@ -464,7 +474,7 @@ MRE_PHASE_FN void nw_direction(ModelP M, Sm& s, int l) {
     }
 #undef NW_TILE
   }
-  MRE_DBG_STAMP(4, 1);
+  MRE_DBG_STAMP(4, 2);
   // symbolic elimination over the blocks (node 0 robot, node 1 + p cube p), cubes last to first
   unsigned adj[5];
   {
@@ -494,7 +504,7 @@ MRE_PHASE_FN void nw_direction(ModelP M, Sm& s, int l) {
   if (nprops > 1) nw_elim_range<NRV + 11, NRV + 6>(hh, g, y, dinv, l, adj[2] & 0x3u);
   if (nprops > 0) nw_elim_range<NRV + 5, NRV>(hh, g, y, dinv, l, adj[1] & 0x1u);
   nw_elim_range<NRV - 1, 0>(hh, g, y, dinv, l, 0u);
-  MRE_DBG_STAMP(4, 2);
+  MRE_DBG_STAMP(4, 3);
   // ---- W' x = y: columns of W through LDS (packed by columns: (j, k), j <= k at k(k+1)/2 + j)
 #pragma unroll
   for (int k = 0; k < NV; k++)

@@ -5,16 +5,17 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DIAG = os.path.join(ROOT, "tools", "_diag")
 NAMES = ["position+crb+factor", "velocity", "collide", "assemble", "control", "smooth", "solve", "integrate+io",
-         "newton: setup", "newton: direction", "newton: direction (re-used)", "newton: search"]
+         "newton: setup", "newton: direction", "newton: direction (re-used)", "newton: search",
+         "direction: init (M rows)", "direction: J'DJ (matrix cores)", "direction: tiles to rows", "direction: elimination + back solve"]
 if "MRE_LIB" not in os.environ:
     tick = sys.argv[1] if len(sys.argv) > 1 else "200"
     vals = []
-    for k in (0, 1, 2):
+    for k in (0, 1, 2, 4):
         env = dict(os.environ, MRE_LIB=os.path.join(DIAG, f"libmre_stamps{k}.so"))
         out = subprocess.check_output([sys.executable, __file__, tick], env=env)
         vals.append(np.frombuffer(out[-4096 * 4 * 4:], np.int32).reshape(4096, 4))
-    v = np.concatenate(vals, axis=1).astype(np.float64)   # [N, 12]
-    tot = v.sum(axis=1)
+    v = np.concatenate(vals, axis=1).astype(np.float64)   # [N, 16]
+    tot = v[:, :12].sum(axis=1)
     order = np.argsort(-tot)
     top = order[:40]
     print(f"tick {tick}: total per env mean {tot.mean():.0f} max {tot.max():.0f}; slowest 40 envs mean {tot[top].mean():.0f}")
