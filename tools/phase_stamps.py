@@ -11,7 +11,7 @@ DIAG = os.path.join(ROOT, "tools", "_diag")
 NAMES = ["position+crb+factor", "velocity", "collide", "assemble", "control", "smooth", "solve", "integrate+io",
          "newton: setup", "newton: direction (H, factor, solves)", "newton: direction (factor re-used)", "newton: line search + move + update",
          "  position: kinematics + comPos", "  position: gripper_pose (fp64)", "  position: gripper_local + connect rows (fp64)", "  position: crb + factor",
-         "  (unused)", "  direction: H assembly (matrix cores, tiles to rows)", "  direction: elimination + forward solve", "  direction: W to LDS, back solve, decrement",
+         "  direction: M rows", "  direction: J'DJ on the matrix cores", "  direction: tiles to rows", "  direction: elimination, both solves, decrement",
          "  position_stage: kinematics", "  position_stage: comPos", "  (unused)", "  (unused)",
          "  collide: broad phase", "  collide: geom frames", "  collide: box-box / plane-box", "  collide: filter, prefix, write-out",
          "  search: M v, J v", "  search: line search", "  search: move, update, J'f, gradient", "  (unused)"]
