@@ -187,6 +187,28 @@ MRE_DEV void nw_rank1(float (&hh)[NV], float t, float J, bool has_r, int pa, int
 // One elimination step of H = W W' (columns NV-1 .. 0) with the solve W y = g riding along.
 // Lane j holds row j; after the step hh[K] = W[j][K].  nbm = earlier blocks (bit 0 robot, bit
 // 1 + p cube p) that column K reaches, fill-in included.
+// hh[c] -= u * u[lane c] for c = HI .. LO: the lane values are read eight at a time into scalar registers before the
+// eight multiply-adds that use them -- a v_readlane followed at once by the VALU instruction that takes its result
+// costs two wait states (an s_nop per column entry in the straightforward loop)
+template <int HI, int LO>
+MRE_DEV void nw_elim_update(float (&hh)[NV], float u) {
+  constexpr int n = HI - LO + 1;
+  if constexpr (n > 0) {
+#pragma unroll
+    for (int g0 = 0; g0 < n; g0 += 8) {
+      float t[8];
+#pragma unroll
+      for (int q = 0; q < 8; q++)
+        if (g0 + q < n) t[q] = rdlane(u, HI - g0 - q);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < 8; q++)
+        if (g0 + q < n) hh[HI - g0 - q] = fmaf(-u, t[q], hh[HI - g0 - q]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
 template <int K>
 MRE_DEV void nw_elim_col(float (&hh)[NV], float& g, float& y, float& dinv, int l, unsigned nbm) {
   constexpr int blk = K < NRV ? 0 : 1 + (K - NRV) / 6;
@@ -199,23 +221,12 @@ MRE_DEV void nw_elim_col(float (&hh)[NV], float& g, float& y, float& dinv, int l
   g = fmaf(-u, yk, g);
   y = (l == K) ? yk : y;
   dinv = (l == K) ? d : dinv;
-#pragma unroll
-  for (int c = K - 1; c >= b0; c--) hh[c] = fmaf(-u, rdlane(u, c), hh[c]);
+  nw_elim_update<K - 1, b0>(hh, u);
   if constexpr (blk > 0) {
-#pragma unroll
-    for (int q = blk - 1; q >= 1; q--) {
-      if (nbm & (1u << q)) {
-#pragma unroll
-        for (int k = 5; k >= 0; k--) {
-          const int c = NRV + 6 * (q - 1) + k;
-          hh[c] = fmaf(-u, rdlane(u, c), hh[c]);
-        }
-      }
-    }
-    if (nbm & 1u) {
-#pragma unroll
-      for (int c = NRV - 1; c >= 0; c--) hh[c] = fmaf(-u, rdlane(u, c), hh[c]);
-    }
+    if constexpr (blk > 3) { if (nbm & (1u << 3)) nw_elim_update<NRV + 17, NRV + 12>(hh, u); }
+    if constexpr (blk > 2) { if (nbm & (1u << 2)) nw_elim_update<NRV + 11, NRV + 6>(hh, u); }
+    if constexpr (blk > 1) { if (nbm & (1u << 1)) nw_elim_update<NRV + 5, NRV>(hh, u); }
+    if (nbm & 1u) nw_elim_update<NRV - 1, 0>(hh, u);
   }
 }
 template <int K, int KEND>
