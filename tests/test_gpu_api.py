@@ -192,7 +192,8 @@ def test_dispatch_order_does_not_change_results(compiled_model):
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
 
 
-def test_fallback_reproduces_the_large_kernel_bit_for_bit(compiled_model):
+@pytest.mark.parametrize("solver", ["PGS", "Newton"])
+def test_fallback_reproduces_the_large_kernel_bit_for_bit(compiled_model, solver):
     """Closing the gripper on a cube with the pads pressed onto the table (pick height 1 cm too low:
     pad-table plus pad-cube contacts) overflows the compact capacities.  Running the envs
     compact-first with re-runs (the default) must give exactly the bits of running every env on the
@@ -205,6 +206,7 @@ def test_fallback_reproduces_the_large_kernel_bit_for_bit(compiled_model):
     out = {}
     for mode in (1, 2):
         phys = _phys(N, A)
+        phys.set_solver(solver)
         phys.set_fallback(mode)
         bench.setup_envs(phys, 7, np.arange(N))
         if mode == 2:
