@@ -128,6 +128,9 @@ int mre_set_warmstart(mre_env*, const float* qacc_warmstart);
 int mre_get_warmstart(mre_env*, float* qacc_warmstart);
 /* Physics.set_control(u) (models/robot_arm.py:78): rows [N][MRE_NU] */
 int mre_set_ctrl(mre_env*, const float* ctrl);
+/* physics.bind(arm_actuators).ctrl (tasks/lasa_draw.py:349): the controls last applied, rows [N][MRE_NU]
+ * (after mre_run_controller: the OSC torques and gripper command of its last tick) */
+int mre_get_ctrl(mre_env*, float* ctrl);
 /* Physics.step() x nsubsteps with ctrl held (models/robot_arm.py:77-81);
  * dm_control legacy order step2->step1 is preserved (results identical to
  * nsubsteps reference steps).  flags: bit0 = disable constraints (test only),

@@ -55,6 +55,14 @@ _CAMERAS = {
     "transporter_data_collection": [dict(name="overhead_camera", pos=[0.7, 0.0, 1.3],
                                          quat=[0.707, 0.0, 0.0, -0.707], height=480, width=640, fovy=61)],
 }
+# config/arena/cameras/lasa.yaml
+_CAMERAS["lasa"] = [
+    dict(name="main_camera", pos=[0.363, -0.919, 1.663], quat=[0.94215352, 0.3349722, -0.00401909, -0.01114498],
+         height=640, width=640, fovy=61),
+    dict(name="front_camera", pos=[2.5, 0.0, 1.4], quat=[0.6133964, 0.3514872, 0.3512074, 0.6138851],
+         height=640, width=640, fovy=61),
+    dict(name="left_camera", pos=[0.4, 1.6, 1.4], quat=[0, 0, 0.5, 0.8660254], height=640, width=640, fovy=61),
+]
 _WORKSPACE = dict(seed=1, workspace=dict(min_pose=[0.35, -0.4, 0.43], max_pose=[0.55, 0.4, 0.435]),
                   gripper=dict(min_pose=[0.4, -0.0, 0.7, 3.14, 0.0, 0.0], max_pose=[0.5, 0.0, 0.7, 3.14, 0.0, 0.0]))
 
@@ -98,6 +106,24 @@ _ARM = dict(
     default_configurations=dict(home=[0, -0.785, 0, -2.356, 0, 1.571, 0.785]),
     arm=dict(_target_="mujoco_robot_environments.models.arms.franka_emika.FER"),
 )
+# config/robots/arm/actuator_config/position.yaml (`general` actuators: kp, kv per joint; LasaDrawEnv's
+# deployment config, tasks/lasa_draw.py:45-56)
+def _position_joint(ctrlrange="-2.8973 2.8973", forcerange="-87 87", kp=4500, kv=450):
+    return dict(dyntype="none", biastype="affine", ctrlrange=ctrlrange, forcerange=forcerange,
+                gainprm=str(kp), biasprm=f"0 -{kp} -{kv}")
+
+
+_ACTUATORS = {
+    "motor": _ARM["actuator_config"],
+    "position": dict(
+        type="general", default=_position_joint(),
+        joint1=_position_joint(), joint2=_position_joint(ctrlrange="-1.7628 1.7628"),
+        joint3=_position_joint(kp=3500, kv=350), joint4=_position_joint(ctrlrange="-3.0718 -0.0698", kp=3500, kv=350),
+        joint5=_position_joint(forcerange="-12 12", kp=2000, kv=200),
+        joint6=_position_joint(ctrlrange="-0.0175 3.7525", forcerange="-12 12", kp=2000, kv=200),
+        joint7=_position_joint(forcerange="-12 12", kp=2000, kv=200),
+        joint_actuator_mapping={f"joint{i}": f"joint{i}" for i in range(1, 8)}),
+}
 # config/robots/end_effector/*.yaml
 _EEF = dict(controller_config=dict(controller=dict(_target_="mujoco_controllers.min_max.MinMax",
                                                    min_val=0.0, max_val=255.0)),
@@ -107,7 +133,12 @@ _EEF = dict(controller_config=dict(controller=dict(_target_="mujoco_controllers.
 _ROOT = dict(physics_dt=0.001, control_dt=0.005, gravity=[0.0, 0.0, -9.8], nconmax=1000, njmax=2000,
              offheight=640, offwidth=640, znear=0.0005, viewer=False, simulation_tuning_mode=False,
              dataset=dict(num_episodes=1000, max_steps=10, max_episodes_per_file=10))
-_DEFAULTS = {"arena/cameras": "transporter_data_collection", "arena/props": None, "task": "rearrangement"}
+_DEFAULTS = {"arena/cameras": "transporter_data_collection", "arena/props": None, "task": "rearrangement",
+             "robots/arm/actuator_config": "motor"}
+# config/lasa.yaml: physics_dt 0.01 (> control_dt), arena: lasa (cameras: lasa, no props group)
+_ROOT_LASA = dict(_ROOT, physics_dt=0.01)
+_DEFAULTS_LASA = {"arena/cameras": "lasa", "arena/props": "single_block", "task": "rearrangement",
+                  "robots/arm/actuator_config": "motor"}
 
 
 def _set_path(tree: dict, path: str, value: Any, must_exist: bool):
@@ -152,9 +183,9 @@ def _interpolate(node, root):
 
 
 def compose(config_name: str = "rearrangement", overrides: Optional[List[str]] = None) -> Cfg:
-    if config_name != "rearrangement":
-        raise ValueError(f"unknown config '{config_name}' (only the RearrangementEnv tree is mirrored)")
-    groups = dict(_DEFAULTS)
+    if config_name not in ("rearrangement", "lasa"):
+        raise ValueError(f"unknown config '{config_name}' (mirrored: rearrangement, lasa)")
+    groups = dict(_DEFAULTS if config_name == "rearrangement" else _DEFAULTS_LASA)
     assigns = []
     for ov in overrides or []:
         key, _, val = ov.partition("=")
@@ -167,10 +198,11 @@ def compose(config_name: str = "rearrangement", overrides: Optional[List[str]] =
     if groups["arena/props"] is None:
         # config/arena/rearrangement_table.yaml:3 points at a non-existent `props: default`
         raise ValueError("arena/props has no default in the reference tree: pass 'arena/props=<option>'")
-    tree: Dict[str, Any] = copy.deepcopy(_ROOT)
+    tree: Dict[str, Any] = copy.deepcopy(_ROOT if config_name == "rearrangement" else _ROOT_LASA)
     tree["arena"] = dict(cameras=copy.deepcopy(_CAMERAS[groups["arena/cameras"]]),
                          props=copy.deepcopy(_PROPS[groups["arena/props"]]))
     tree["robots"] = dict(arm=copy.deepcopy(_ARM), end_effector=copy.deepcopy(_EEF))
+    tree["robots"]["arm"]["actuator_config"] = copy.deepcopy(_ACTUATORS[groups["robots/arm/actuator_config"]])
     tree["task"] = copy.deepcopy(_TASK[groups["task"]])
     for key, val, add in assigns:
         _set_path(tree, key, val, must_exist=not add)
@@ -179,6 +211,21 @@ def compose(config_name: str = "rearrangement", overrides: Optional[List[str]] =
 
 def default_config() -> Cfg:
     """tasks/rearrangement.py:34-40 DEFAULT_CONFIG."""
+    return compose("rearrangement", ["arena/props=colour_splitter", "simulation_tuning_mode=False"])
+
+
+def lasa_default_config() -> Cfg:
+    """tasks/lasa_draw.py:31-41 generate_default_config."""
+    return compose("lasa", ["simulation_tuning_mode=True"])
+
+
+def lasa_deployment_config() -> Cfg:
+    """tasks/lasa_draw.py:45-56 generate_deployment_config."""
+    return compose("lasa", ["simulation_tuning_mode=False", "robots/arm/actuator_config=position"])
+
+
+def push_default_config() -> Cfg:
+    """tasks/push.py:31-41 generate_default_config."""
     return compose("rearrangement", ["arena/props=colour_splitter", "simulation_tuning_mode=False"])
 
 

@@ -333,6 +333,13 @@ static int build_model(const void* blob, size_t nbytes, DevModel& m) {
   RI("act_dof", m.act_dof, NU); RF("act_ctrlrange", m.act_ctrlrange, NU * 2);
   RF("grip_gainprm", &m.grip_gainprm, 1); RF("grip_biasprm", m.grip_biasprm, 3);
   RF("grip_forcerange", m.grip_forcerange, 2);
+  // arm actuators: motors (gain 1, no bias, unlimited force) unless the blob says otherwise
+  for (int a = 0; a < NU; a++) { m.act_gain[a] = 1.f; m.act_forcelimited[a] = 0; }
+  { uint32_t c, cnt; uint64_t off;
+    if (b.find("act_gainprm", &c, &cnt, &off)) {
+      RF("act_gainprm", m.act_gain, NU); RF("act_biasprm", m.act_bias, NU * 3);
+      RF("act_forcerange", m.act_forcerange, NU * 2); RI("act_forcelimited", m.act_forcelimited, NU);
+    } }
   RF("opt_timestep", &m.timestep, 1); RF("opt_gravity", m.gravity, 3); RF("opt_impratio", &m.impratio, 1);
   RF("opt_tolerance", &m.tolerance, 1); RI("opt_iterations", &m.iterations, 1);
   m.solver = MRE_SOLVER_PGS;  // older blobs carry no opt_solver
@@ -825,6 +832,11 @@ extern "C" int mre_set_state(mre_env* e, const float* qpos, const float* qvel) {
   if (!rc && qvel) rc = copy_in(e, e->qvel, qvel, (size_t)e->N * NVP * 4);
   return rc;
 }
+extern "C" int mre_get_ctrl(mre_env* e, float* ctrl) {
+  if (!e || !ctrl) return fail(MRE_ERR_ARG, "mre_get_ctrl: null");
+  return copy_out(e, ctrl, e->ctrl, (size_t)e->N * NU * 4);
+}
+
 extern "C" int mre_get_state(mre_env* e, float* qpos, float* qvel) {
   if (!e) return fail(MRE_ERR_ARG, "null handle");
   int rc = MRE_OK;

@@ -110,6 +110,11 @@ struct DevModel {
   float ten_coef[2];
   int act_dof[NU];
   float act_ctrlrange[NU][2], grip_gainprm, grip_biasprm[3], grip_forcerange[2];
+  // arm actuators 0..6 as MuJoCo `general` actuators on their joint: force = gain ctrl + bias0 + bias1 q +
+  // bias2 qvel, clamped to forcerange when limited.  motor.yaml: gain 1, bias 0, unlimited;
+  // position.yaml (LasaDrawEnv deployment config): gain kp, bias (0, -kp, -kv), forcerange +-87 / +-12
+  float act_gain[NU], act_bias[NU][3], act_forcerange[NU][2];
+  int act_forcelimited[NU];
   // ---- options
   float timestep, gravity[3], impratio, tolerance;
   int iterations;

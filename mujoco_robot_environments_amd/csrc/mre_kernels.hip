@@ -767,8 +767,27 @@ MRE_PHASE_FN void velocity_stage(ModelP M, Sm& s, int l) {
 }
 
 // ------------------------- mj_fwdActuation + mj_passive + mj_fwdAcceleration
-// returns (wave-uniform) whether the finger actuator force is clamped
-MRE_DEV bool smooth_forces(ModelP M, Sm& s, int l) {
+// arm actuators (lanes 0..6) as `general` actuators on their joint: force -> qfrc_smooth[lane] (read back by
+// the same lane in smooth_forces); returns (wave-uniform) the mask of the actuators clamped by forcerange.
+// A function of its own so that the model reads stay out of the step loop's register budget.
+MRE_PHASE_FN unsigned arm_actuation(ModelP M, Sm& s, int l) {
+  bool arm_clamped = false;
+  if (l < 7) {
+    float fa = M->act_gain[l] * clampf(s.ctrl[l], M->act_ctrlrange[l][0], M->act_ctrlrange[l][1]) + M->act_bias[l][0] +
+               M->act_bias[l][1] * s.qpos[l] + M->act_bias[l][2] * s.qvel[l];
+    if (M->act_forcelimited[l]) {
+      if (fa <= M->act_forcerange[l][0]) { fa = M->act_forcerange[l][0]; arm_clamped = true; }
+      if (fa >= M->act_forcerange[l][1]) { fa = M->act_forcerange[l][1]; arm_clamped = true; }
+    }
+    s.qfrc_smooth[l] = fa;
+  }
+  return (unsigned)__ballot(arm_clamped) & 0x7Fu;
+}
+
+// returns (wave-uniform) the actuators whose force is clamped by forcerange: bit a = arm actuator a, bit
+// NU - 1 = the finger actuator (mjd_actuator_vel skips those in the implicit integrator)
+MRE_DEV unsigned smooth_forces(ModelP M, Sm& s, int l) {
+  const unsigned arm_mask = arm_actuation(M, s, l);
   const float ten_len = M->ten_coef[0] * s.qpos[M->ten_dof[0]] + M->ten_coef[1] * s.qpos[M->ten_dof[1]];
   const float ten_vel = M->ten_coef[0] * s.qvel[M->ten_dof[0]] + M->ten_coef[1] * s.qvel[M->ten_dof[1]];
   const float cg = clampf(s.ctrl[NU - 1], M->act_ctrlrange[NU - 1][0], M->act_ctrlrange[NU - 1][1]);
@@ -782,7 +801,7 @@ MRE_DEV bool smooth_forces(ModelP M, Sm& s, int l) {
     if (b < NRB) {
       // passive: spring + damper of the hinge
       f = -M->jnt_stiffness[b] * (s.qpos[l] - M->jnt_springref[b]) - M->dof_damping[l] * s.qvel[l];
-      if (l < 7) f += clampf(s.ctrl[l], M->act_ctrlrange[l][0], M->act_ctrlrange[l][1]);
+      if (l < 7) f += s.qfrc_smooth[l];
       if (l == M->ten_dof[0]) f += M->ten_coef[0] * fg;
       if (l == M->ten_dof[1]) f += M->ten_coef[1] * fg;
     }
@@ -799,13 +818,14 @@ MRE_DEV bool smooth_forces(ModelP M, Sm& s, int l) {
     s.qacc_smooth[l] = s.qacc_smooth[l] / md;
   }
   MRE_SYNC();
-  return clamped;
+  return arm_mask | (clamped ? 1u << (NU - 1) : 0u);
 }
 
 // ------------------------------------------- mj_implicit (implicitfast) + advance
 // part 1: MH and the right-hand side; the kernel body then factors MH (factor_robot_regs, inlined
 // there: a kernel has no callee-saved registers to spill) and calls part 2
-MRE_PHASE_FN void integrate_setup(ModelP M, Sm& s, int l, bool grip_clamped) {
+MRE_PHASE_FN void integrate_setup(ModelP M, Sm& s, int l, unsigned act_clamped) {
+  const bool grip_clamped = (act_clamped >> (NU - 1)) & 1u;
   const float h = M->timestep;
   if (l < NVP) s.qacc_ws[l] = (l < NV) ? s.qacc[l] : 0.f;
   // MH = M - h*dF/dv restricted to M's pattern (diagonal terms only here)
@@ -814,6 +834,7 @@ MRE_PHASE_FN void integrate_setup(ModelP M, Sm& s, int l, bool grip_clamped) {
     const int i = M->M_i[e];
     if (i == M->M_j[e]) {
       v += h * M->dof_damping[i];
+      if (i < 7 && ((act_clamped >> i) & 1u) == 0u) v -= h * M->act_bias[i][2];
       if (!grip_clamped) {
         if (i == M->ten_dof[0]) v -= h * M->grip_biasprm[2] * M->ten_coef[0] * M->ten_coef[0];
         if (i == M->ten_dof[1]) v -= h * M->grip_biasprm[2] * M->ten_coef[1] * M->ten_coef[1];
@@ -984,7 +1005,7 @@ MRE_DEV void step_body(const StepArgs& a, Sm& s) {
     }
     // ------------------------------------------------ S2
     MRE_STAMP(4);
-    const bool clamped = smooth_forces(M, s, l);
+    const unsigned clamped = smooth_forces(M, s, l);
     MRE_STAMP(5);
     if (constrained) {
 #if defined(MRE_NEWTON) && defined(MRE_PHASE_STAMPS)

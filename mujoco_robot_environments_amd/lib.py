@@ -21,7 +21,7 @@ MRE_NQ, MRE_NV, MRE_NU, MRE_NQ_PAD, MRE_NV_PAD, MRE_MAX_PROPS = 43, 39, 8, 44, 4
 
 EXPORTS = [
     "mre_create", "mre_destroy", "mre_last_error", "mre_num_envs", "mre_stream", "mre_sync",
-    "mre_set_props", "mre_reset", "mre_place_props", "mre_set_state", "mre_get_state",
+    "mre_set_props", "mre_reset", "mre_place_props", "mre_set_state", "mre_get_state", "mre_get_ctrl",
     "mre_set_warmstart", "mre_get_warmstart", "mre_set_ctrl", "mre_step", "mre_rollout",
     "mre_set_trace", "mre_osc_set_target", "mre_osc_configure", "mre_gripper_set",
     "mre_run_controller", "mre_get_sites", "mre_get_status", "mre_get_solver_stats",
@@ -106,6 +106,7 @@ def lib() -> C.CDLL:
     L.mre_place_props.argtypes = [vp, fp, C.c_uint64, fp, fp, ci, ci]
     L.mre_set_state.argtypes = [vp, fp, fp]
     L.mre_get_state.argtypes = [vp, fp, fp]
+    L.mre_get_ctrl.argtypes = [vp, fp]
     L.mre_set_warmstart.argtypes = [vp, fp]
     L.mre_get_warmstart.argtypes = [vp, fp]
     L.mre_set_ctrl.argtypes = [vp, fp]

@@ -123,7 +123,10 @@ def _geom_inertia(g):
         return None
     m = float(g["mass"])
     a, b, c = g["size"]
-    I = np.diag([m / 3 * (b * b + c * c), m / 3 * (a * a + c * c), m / 3 * (a * a + b * b)])
+    if g.get("inertia_shape") == "cylinder":   # radius a (= b), half height c, axis z
+        I = np.diag([m * (3 * a * a + 4 * c * c) / 12, m * (3 * a * a + 4 * c * c) / 12, m * a * a / 2])
+    else:
+        I = np.diag([m / 3 * (b * b + c * c), m / 3 * (a * a + c * c), m / 3 * (a * a + b * b)])
     R = q2m(qnorm(g["quat"]))
     return m, np.asarray(g["pos"], dtype=np.float64), R @ I @ R.T
 
@@ -400,6 +403,32 @@ def compile_scene(scene: dict = None) -> Dict[str, np.ndarray]:
         for s in b.sites:
             sites.append(s)
             site_body.append(i)
+    layout = scene.get("layout")
+    if layout:
+        # the kernels index the cube geoms from a fixed id and read a fixed geom count: disabled
+        # placeholder boxes (no collision bits, 5 m under the floor) fill the ids a scene leaves free
+        def placeholder(k):
+            g = _spec.box(f"unused_{k}", (1e-3, 1e-3, 1e-3), pos=(0.0, 0.0, -5.0), contype=0, conaffinity=0,
+                          group="none")
+            g["late"] = False
+            return g
+        first_prop = min(i for i, g in enumerate(geoms) if g["group"] == "prop")
+        n_world = next((i for i, b in enumerate(geom_body) if b != 0), len(geoms))   # world geoms come first
+        pad = layout["prop_geom0"] - first_prop
+        if pad < 0:
+            raise ValueError(f"{first_prop} geoms precede the cubes, the kernels allow {layout['prop_geom0']}")
+        for k in range(pad):
+            geoms.insert(n_world, placeholder(k))
+            geom_body.insert(n_world, 0)
+        k = pad
+        while len(geoms) < layout["ngeom"]:
+            g = placeholder(k)
+            g["late"] = True
+            geoms.append(g)
+            geom_body.append(0)
+            k += 1
+        if len(geoms) != layout["ngeom"]:
+            raise ValueError(f"{len(geoms)} geoms, the kernels are compiled for {layout['ngeom']}")
     n_early = sum(1 for g in geoms if not g.get("late", False))
     # MuJoCo sorts nothing; keep spec order but put the plane first for pair typing
     ng = len(geoms)
@@ -443,7 +472,8 @@ def compile_scene(scene: dict = None) -> Dict[str, np.ndarray]:
             if ra and rc:
                 continue
             # robot vs ground: unreachable (ground is 0.4 m below the base)
-            if (ra and gc["group"] == "ground") or (rc and ga["group"] == "ground"):
+            if not scene.get("robot_ground_pairs", False) and \
+                    ((ra and gc["group"] == "ground") or (rc and ga["group"] == "ground")):
                 continue
             g1, g2 = (a, c)
             if gtype[g1] > gtype[g2]:
@@ -522,6 +552,13 @@ def compile_scene(scene: dict = None) -> Dict[str, np.ndarray]:
     A["grip_gainprm"] = np.array([ga["gainprm"]])
     A["grip_biasprm"] = np.asarray(ga["biasprm"], dtype=np.float64)
     A["grip_forcerange"] = np.asarray(ga["forcerange"], dtype=np.float64)
+    # joint actuators as `general` actuators: motors are gain 1 / no bias / unlimited force
+    A["act_gainprm"] = np.array([a.get("gainprm", 1.0) if a["kind"] == "motor" else 0.0 for a in acts])
+    A["act_biasprm"] = np.array([a.get("biasprm", (0.0, 0.0, 0.0)) if a["kind"] == "motor" else (0.0, 0.0, 0.0)
+                                 for a in acts], dtype=np.float64)
+    A["act_forcerange"] = np.array([a.get("forcerange", (0.0, 0.0)) if a["kind"] == "motor" else (0.0, 0.0)
+                                    for a in acts], dtype=np.float64)
+    A["act_forcelimited"] = np.array([int(a["kind"] == "motor" and "forcerange" in a) for a in acts], np.int32)
 
     # ---- qpos0 constants (mj_setConst): invweight0, meaninertia
     xpos0, xquat0 = forward_kinematics(A, qpos0)

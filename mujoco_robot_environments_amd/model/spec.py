@@ -123,20 +123,27 @@ _PANDA_HULLS = {
 }
 
 
-def panda_spec(gripper: Optional[dict] = None) -> dict:
-    """Body tree of the arm, rooted at link0 (welded to the robot base site)."""
+def panda_spec(gripper: Optional[dict] = None, tool: Optional[dict] = None,
+               late_links: Optional[Sequence[str]] = None, skip_links: Sequence[str] = ()) -> dict:
+    """Body tree of the arm, rooted at link0 (welded to the robot base site).
+
+    ``tool``: a geom added to the attachment body (tasks/push.py:156-163, tasks/lasa_draw.py:113-120);
+    ``late_links``: the link hulls that take geom ids after the cubes (default: links 1..4, see
+    _PANDA_HULLS); ``skip_links``: link hulls left out (pairs that can never touch in that scene).
+    """
     attachment = body("attachment", pos=(0, 0, 0.107),
                       quat=(0.3826834, 0, 0, 0.9238795),
+                      geoms=[tool] if tool is not None else [],
                       sites=[dict(name="attachment_site", pos=(0, 0, 0), quat=(1, 0, 0, 0))],
                       children=[gripper] if gripper is not None else [])
     child = attachment
     for i in range(6, -1, -1):
         name, pos, quat, mass, com, full = _PANDA_LINKS[i]
         geoms = []
-        if name in _PANDA_HULLS:
+        if name in _PANDA_HULLS and name not in skip_links:
             h = _PANDA_HULLS[name]
             g = box(f"{name}_hull", h["size"], pos=h["pos"], hull=True)
-            g["late"] = bool(h.get("late", False))
+            g["late"] = bool(h.get("late", False)) if late_links is None else name in late_links
             geoms.append(g)
         child = body(name, pos=pos, quat=quat,
                      inertial=inertial(mass, com, fullinertia=full),
@@ -212,7 +219,21 @@ def _finger(side: str, mirrored: bool) -> List[dict]:
     return [driver, spring_link]
 
 
-def robotiq_spec() -> dict:
+def _make_inert(node: dict) -> dict:
+    """The same subtree with no mass, no geoms, no springs / dampers and wide joint ranges (armature kept)."""
+    j = node["joint"]
+    if j is not None:
+        j = dict(j, stiffness=0.0, springref=0.0, damping=0.0, range=(-3.0, 3.0))
+    return dict(node, inertial=None, geoms=[], joint=j, children=[_make_inert(c) for c in node["children"]])
+
+
+def robotiq_spec(inert: bool = False) -> dict:
+    """``inert``: the gripper's bodies and joints without mass, geoms or passive forces -- the
+    placeholder that lets an arm-only scene (PushEnv, LasaDrawEnv) run on the kernels compiled for the
+    arm + gripper topology: massless bodies add nothing to the arm rows of M or to its bias forces, the
+    eight finger dofs keep M_ii = armature and see no force, so they stay at rest."""
+    if inert:
+        return _make_inert(robotiq_spec())
     base = body("base", pos=(0, 0, 0.0038), quat=(SQ2, 0, 0, -SQ2),
                 inertial=inertial(0.777441, (0, -2.70394e-05, 0.0354675),
                                   quat=(1, -0.00152849, 0, 0),
@@ -294,5 +315,152 @@ def default_scene(cfg: Optional[Dict] = None, max_props: int = 4) -> dict:
         eef_site="attachment_site",   # models/robot_arm.py:38
         tcp_site="pinch",             # models/robot_arm.py:57
         home=tuple(cfg.get("home", (0, -0.785, 0, -2.356, 0, 1.571, 0.785))),
+        unverified=True,
+    )
+
+
+# --------------------------------------------------------------------------
+# The reference's other tasks (tasks/base.py, tasks/push.py, tasks/lasa_draw.py) on the same kernels
+# --------------------------------------------------------------------------
+def tool_cylinder() -> dict:
+    """The cylinder added to the arm's attachment body for non-prehensile work (tasks/push.py:156-163,
+    tasks/lasa_draw.py:113-120): radius 0.015, half height 0.05, centre 0.05 above the attachment site,
+    default density 1000 (mass and inertia are the cylinder's).  Its collision shape is the box hull of
+    the cylinder -- the repo's stated deviation for every convex shape MuJoCo hands to its general convex
+    collider (one contact per pair)."""
+    r, hh = 0.015, 0.05
+    g = box("tool_cylinder", (r, r, hh), pos=(0.0, 0.0, 0.05), hull=True)
+    g["mass"] = 1000.0 * math.pi * r * r * 2 * hh
+    g["inertia_shape"] = "cylinder"
+    return g
+
+
+_POSITION_ACTUATORS = [
+    # config/robots/arm/actuator_config/position.yaml: ctrlrange, forcerange, kp, kv per joint
+    ((-2.8973, 2.8973), 87.0, 4500.0, 450.0), ((-1.7628, 1.7628), 87.0, 4500.0, 450.0),
+    ((-2.8973, 2.8973), 87.0, 3500.0, 350.0), ((-3.0718, -0.0698), 87.0, 3500.0, 350.0),
+    ((-2.8973, 2.8973), 12.0, 2000.0, 200.0), ((-0.0175, 3.7525), 12.0, 2000.0, 200.0),
+    ((-2.8973, 2.8973), 12.0, 2000.0, 200.0),
+]
+
+
+def _arm_actuators(kind: str, motor, position_rows=None) -> List[dict]:
+    acts = []
+    position_rows = position_rows or _POSITION_ACTUATORS
+    for i in range(7):
+        if kind == "motor":      # config/robots/arm/actuator_config/motor.yaml
+            acts.append(dict(name=f"actuator{i + 1}", kind="motor", joint=f"joint{i + 1}",
+                             ctrlrange=(-motor[i], motor[i])))
+        elif kind == "position":  # models/arms/franka_emika.py `general` branch of _add_actuators
+            cr, fr, kp, kv = position_rows[i]
+            acts.append(dict(name=f"actuator{i + 1}", kind="motor", joint=f"joint{i + 1}", ctrlrange=cr,
+                             gainprm=kp, biasprm=(0.0, -kp, -kv), forcerange=(-fr, fr)))
+        else:
+            raise ValueError(f"actuator config {kind!r}: motor | position")
+    return acts
+
+
+def other_task_scene(task: str, cfg: Optional[Dict] = None, embed: bool = True, max_props: int = 4) -> dict:
+    """Scenes of the reference's other environments.
+
+    ``task``:
+      * ``"base"`` -- BaseEnv (tasks/base.py:78-87): arm + gripper on the arena floor (robot base at the
+        origin), no table, no props;
+      * ``"push"`` -- PushEnv (tasks/push.py:83-221): nine table slabs (one 0.5 m wide under the robot, eight
+        0.1 m wide in front of it; all boxes of half height 0.2 centred at z = 0.2), the arm WITHOUT a
+        gripper but with the tool cylinder, one free block of half size 0.025 and mass 0.05.  Quirk
+        preserved: ``Rectangle._build`` does not forward its ``friction`` argument to ``_make``
+        (environment/props.py:226-260), so the friction gradient of tasks/push.py:112-125 never reaches the
+        geoms -- every slab and the block keep MuJoCo's default (1, 0.005, 0.0001);
+        ``cfg["forward_friction"] = True`` applies the gradient the author meant;
+      * ``"lasa"`` -- LasaDrawEnv (tasks/lasa_draw.py:83-128): one table (half size 1, 1, 0.2 at
+        (0.4, 0, 0.2)), the arm with the tool cylinder, no props; config/lasa.yaml: physics_dt 0.01;
+        ``cfg["actuator"] = "position"`` is the deployment config (tasks/lasa_draw.py:45-56).
+
+    ``embed``: True gives the scene in the topology the kernels are compiled for (an inert gripper below
+    the attachment body when the task has none, four cube slots); False gives the task's own body tree
+    (used by the oracle cross-check of the embedding and by tools/emit_mjcf.py).
+
+    Without the 2F-85 nothing sets ``cone`` / ``impratio``: MuJoCo's defaults there are pyramidal / 1.
+    The kernels implement elliptic cones only, so push / lasa run ``cone=elliptic impratio=1`` (stated
+    deviation).
+    """
+    cfg = cfg or {}
+    motor = cfg.get("motor_ctrlrange", [87.0, 87.0, 87.0, 87.0, 12.0, 12.0, 12.0])
+    has_gripper = task == "base"
+    if has_gripper:
+        gripper = robotiq_spec()
+    else:
+        gripper = robotiq_spec(inert=True) if embed else None
+    tool = None if has_gripper else tool_cylinder()
+    statics, props, robot_z = [], [], 0.4
+    if task == "base":
+        robot_z = 0.0                                  # tasks/base.py:81-85
+        arm = panda_spec(gripper=gripper)
+    elif task == "push":
+        frictions = [DEFAULT_FRICTION] * 9
+        if cfg.get("forward_friction", False):
+            frictions = [DEFAULT_FRICTION] + [(0.4 + 0.4 * k / 7.0, 0.005, 0.0001) for k in range(8)]
+        centers = [-0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8, 0.9]   # tasks/push.py:98-101,128-149
+        halfx = [0.25] + [0.05] * 8
+        for k in range(9):
+            statics.append(body(f"table_{k}", pos=(centers[k], 0.0, 0.2), geoms=[
+                box(f"table_{k}", (halfx[k], 1.0, 0.2), priority=10, margin=0.0, gap=0.0, mass=10.0,
+                    friction=frictions[k], group="table")]))
+        # links 1..3 stay above z = 0.6: they reach neither the slabs nor the block
+        arm = panda_spec(gripper=gripper, tool=tool, late_links=("link4", "link5", "link6"),
+                         skip_links=("link1", "link2", "link3"))
+    elif task == "lasa":
+        statics.append(body("table", pos=(0.4, 0.0, 0.2), geoms=[
+            box("table", (1.0, 1.0, 0.2), priority=10, margin=0.0, gap=0.0, mass=10.0, group="table")]))
+        arm = panda_spec(gripper=gripper, tool=tool)
+    else:
+        raise ValueError(f"task {task!r}: base | push | lasa")
+    nslots = max_props if embed else (1 if task == "push" else 0)
+    for i in range(nslots):
+        if task == "push":   # tasks/push.py:190-204 (friction not forwarded, see above)
+            fr = (0.01, 0.005, 0.0001) if cfg.get("forward_friction", False) else DEFAULT_FRICTION
+            g = box(f"prop_{i}", (0.025, 0.025, 0.025), priority=10, margin=0.0, gap=0.0, mass=0.05,
+                    friction=fr, group="prop")
+        else:
+            g = box(f"prop_{i}", (0.0155, 0.0155, 0.0155), priority=10, margin=0.15, gap=0.15, mass=0.1,
+                    group="prop")
+        props.append(body(f"prop_{i}", joint=free(f"prop_{i}_free"), geoms=[g]))
+    robot_base = body("robot_base", pos=(0, 0, robot_z), children=[arm])
+    world = body("world", geoms=[plane("ground", friction=(0.4, 0.005, 0.0001))],
+                 children=statics + [robot_base] + props)
+    actuators = _arm_actuators(cfg.get("actuator", "motor"), motor, cfg.get("position_actuators"))
+    if has_gripper:
+        actuators.append(dict(name="fingers_actuator", kind="general_tendon", tendon="split",
+                              gainprm=0.3137255, biasprm=(0.0, -100.0, -10.0),
+                              ctrlrange=(0.0, 255.0), forcerange=(-1.5, 1.5)))
+        equality, tendon = ROBOTIQ_EQUALITY, ROBOTIQ_TENDON
+    elif embed:   # the inert gripper keeps its (force-free) loop closures; its actuator has zero gain
+        actuators.append(dict(name="fingers_actuator", kind="general_tendon", tendon="split",
+                              gainprm=0.0, biasprm=(0.0, 0.0, 0.0),
+                              ctrlrange=(0.0, 255.0), forcerange=(-1.5, 1.5)))
+        equality, tendon = ROBOTIQ_EQUALITY, ROBOTIQ_TENDON
+    else:         # the oracle's blob reader has eight actuator slots: the last one is a null actuator
+        actuators.append(dict(name="null_actuator", kind="general_tendon", tendon="null",
+                              gainprm=0.0, biasprm=(0.0, 0.0, 0.0),
+                              ctrlrange=(0.0, 255.0), forcerange=(-1.5, 1.5)))
+        equality, tendon = [], dict(name="null", joints=("joint1", "joint1"), coef=(0.0, 0.0))
+    default_dt = 0.01 if task == "lasa" else 0.001    # config/lasa.yaml:2, config/rearrangement.yaml:2
+    return dict(
+        world=world, equality=equality, tendon=tendon, actuators=actuators,
+        option=dict(
+            timestep=float(cfg.get("physics_dt", default_dt)),
+            gravity=tuple(cfg.get("gravity", (0.0, 0.0, -9.8))),
+            integrator="implicitfast", cone="elliptic", impratio=10.0 if has_gripper else 1.0,
+            solver=str(cfg.get("solver", "Newton")),   # MuJoCo's default: these tasks set no solver either
+            iterations=100, tolerance=1e-8, ls_iterations=50, ls_tolerance=0.01,
+        ),
+        arm_joints=[f"joint{i + 1}" for i in range(7)],
+        eef_site="attachment_site",
+        tcp_site="pinch" if (has_gripper or embed) else "attachment_site",
+        home=tuple(cfg.get("home", (0, -0.785, 0, -2.356, 0, 1.571, 0.785))),
+        robot_ground_pairs=(task == "base"),
+        layout=dict(prop_geom0=12, ngeom=20) if embed else None,
+        task=task,
         unverified=True,
     )

@@ -15,7 +15,7 @@ from ..controllers import OSC, MinMax
 
 
 class RobotArm:
-    def __init__(self, physics, controller_params=None, gripper_cfg=None, gripper: bool = True):
+    def __init__(self, physics, controller_params=None, gripper_cfg=None, gripper: bool = True, strict: bool = True):
         self.physics = physics
         self.arm_controller = OSC(physics, controller_config=controller_params)
         self.end_effector = "robotiq_2f85" if gripper else None
@@ -27,7 +27,7 @@ class RobotArm:
         self.timestep = physics.timestep
         # robot_arm.py:53
         self.control_steps = int(control_dt // self.timestep)
-        if self.control_steps < 1:
+        if self.control_steps < 1 and strict:
             raise ValueError("control_dt < physics_dt gives control_steps = 0: the reference's "
                              "run_controller would never advance time (SURVEY.md App. D.9)")
         self.time = 0.0  # physics.data.time (fp64, += timestep per step)
@@ -47,6 +47,8 @@ class RobotArm:
         return ticks
 
     def run_controller(self, duration: float):
+        if self.control_steps < 1:  # LasaDrawEnv's config (physics_dt 0.01 > control_dt 0.005): the reference spins forever
+            raise ValueError("control_steps = 0: run_controller would never advance time (SURVEY.md App. D.9)")
         ticks = self.ticks_for(duration)
         conv = self.physics.run_controller(ticks, self.control_steps)
         for _ in range(ticks * self.control_steps):

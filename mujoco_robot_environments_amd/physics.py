@@ -202,6 +202,12 @@ class BatchedPhysics:
         if not isinstance(ctrl, torch.Tensor):
             self.sync()
 
+    def ctrl(self) -> np.ndarray:
+        """physics.data.ctrl [N, 8]: the controls last applied (after run_controller: its last tick's)."""
+        c = np.empty((self.num_envs, MRE_NU), np.float32)
+        check(_lib.lib().mre_get_ctrl(self._h, _ptr(c)), "mre_get_ctrl")
+        return c
+
     # ---------------------------------------------------------------- step
     def step(self, nsubsteps: int = 1, flags: int = 0) -> None:
         check(_lib.lib().mre_step(self._h, int(nsubsteps), int(flags)), "mre_step")

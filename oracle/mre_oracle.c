@@ -57,6 +57,10 @@ struct mro_model {
   double ten_coef[2];
   int act_dof[MRO_NU];
   double act_ctrlrange[MRO_NU][2], grip_gainprm, grip_biasprm[3], grip_forcerange[2];
+  /* joint actuators as mjGAIN_FIXED / mjBIAS_AFFINE `general` actuators (motor.yaml: gain 1, no bias;
+   * position.yaml: gain kp, bias 0 -kp -kv, forcerange) */
+  double act_gain[MRO_NU], act_bias[MRO_NU][3], act_forcerange[MRO_NU][2];
+  int act_forcelimited[MRO_NU];
   double timestep, gravity[3], impratio, tolerance, ls_tolerance;
   int iterations, solver, ls_iterations; /* solver: 0 = PGS, 2 = Newton (mjtSolver) */
   int arm_dof[7], eef_site, tcp_site, prop_bodyid[MRO_MAXPROP];
@@ -100,7 +104,7 @@ struct mro_data {
   /* acceleration stage */
   double actuator_force[MRO_NU], qfrc_actuator[MRO_MAXV], qfrc_smooth[MRO_MAXV],
       qacc_smooth[MRO_MAXV], qfrc_constraint[MRO_MAXV], qacc[MRO_MAXV];
-  int grip_clamped;
+  int grip_clamped, act_clamped[MRO_NU];
   int solver_iters;
   /* solver selection overrides (-1 / 0 = take the model's) and Newton telemetry */
   int solver_override, iterations_override, ls_evals, efc_state[MRO_MAXEFC];
@@ -304,7 +308,13 @@ mro_model* mro_model_load(const void* blob, size_t nbytes) {
   { blob_entry e;
     if (blob_find(b, "opt_solver", &e)) blob_i(b, "opt_solver", &m->solver, 1);
     if (blob_find(b, "opt_ls_iterations", &e)) blob_i(b, "opt_ls_iterations", &m->ls_iterations, 1);
-    if (blob_find(b, "opt_ls_tolerance", &e)) blob_d(b, "opt_ls_tolerance", &m->ls_tolerance, 1); }
+    if (blob_find(b, "opt_ls_tolerance", &e)) blob_d(b, "opt_ls_tolerance", &m->ls_tolerance, 1);
+    for (int a = 0; a < MRO_NU; a++) m->act_gain[a] = 1.0;
+    if (blob_find(b, "act_gainprm", &e)) {
+      blob_d(b, "act_gainprm", m->act_gain, MRO_NU); blob_d(b, "act_biasprm", &m->act_bias[0][0], MRO_NU * 3);
+      blob_d(b, "act_forcerange", &m->act_forcerange[0][0], MRO_NU * 2);
+      blob_i(b, "act_forcelimited", m->act_forcelimited, MRO_NU);
+    } }
   LI(arm_dof, 7); LI1(eef_site, "eef_site"); LI1(tcp_site, "tcp_site");
   if (blob_i(b, "prop_bodyid", m->prop_bodyid, MRO_MAXPROP) < 0) goto fail;
   LD(home_qpos, 7);
@@ -1124,8 +1134,16 @@ static void fwd_actuation(const mro_model* m, mro_data* d) {
     if (c < m->act_ctrlrange[a][0]) c = m->act_ctrlrange[a][0];
     if (c > m->act_ctrlrange[a][1]) c = m->act_ctrlrange[a][1];
     if (m->act_dof[a] >= 0) {
-      d->actuator_force[a] = c; /* motor: gain 1, no bias */
-      d->qfrc_actuator[m->act_dof[a]] += c;
+      /* joint transmission: length = qpos, velocity = qvel of the joint's dof */
+      const int j = m->act_dof[a];
+      double f = m->act_gain[a] * c + m->act_bias[a][0] + m->act_bias[a][1] * d->qpos[j] + m->act_bias[a][2] * d->qvel[j];
+      d->act_clamped[a] = 0;
+      if (m->act_forcelimited[a]) {
+        if (f <= m->act_forcerange[a][0]) { f = m->act_forcerange[a][0]; d->act_clamped[a] = 1; }
+        if (f >= m->act_forcerange[a][1]) { f = m->act_forcerange[a][1]; d->act_clamped[a] = 1; }
+      }
+      d->actuator_force[a] = f;
+      d->qfrc_actuator[j] += f;
     } else {
       double f = m->grip_gainprm * c + m->grip_biasprm[0] + m->grip_biasprm[1] * d->ten_length +
                  m->grip_biasprm[2] * d->ten_velocity;
@@ -1688,6 +1706,8 @@ static void integrate(const mro_model* m, mro_data* d) {
    * not an ancestor pair, hence outside M's pattern); clamped actuator: no derivative */
   memcpy(MH, d->qM, sizeof(double) * m->nM);
   for (int i = 0; i < nv; i++) MH[m->dof_Madr[i]] += h * m->dof_damping[i];
+  for (int a = 0; a < MRO_NU; a++) /* mjd_actuator_vel: affine bias of an unclamped joint actuator */
+    if (m->act_dof[a] >= 0 && !d->act_clamped[a]) MH[m->dof_Madr[m->act_dof[a]]] += -h * m->act_bias[a][2];
   if (!d->grip_clamped)
     for (int k = 0; k < 2; k++)
       MH[m->dof_Madr[m->ten_dof[k]]] += -h * m->grip_biasprm[2] * m->ten_coef[k] * m->ten_coef[k];

@@ -28,7 +28,7 @@ extern "C" {
 #define MRO_MAXM 200
 #define MRO_MAXG 24
 #define MRO_MAXS 4
-#define MRO_MAXPAIR 96
+#define MRO_MAXPAIR 128
 #define MRO_MAXCON 96
 #define MRO_MAXEFC 360
 #define MRO_MAXEQ 4

@@ -91,7 +91,7 @@ class Model:
             raise RuntimeError("oracle: bad model blob")
 
     def __del__(self):
-        if getattr(self, "ptr", None):
+        if getattr(self, "ptr", None) and lib is not None:   # (module globals are gone at interpreter exit)
             lib().mro_model_free(self.ptr)
             self.ptr = None
 
@@ -106,7 +106,7 @@ class Env:
         self.ptr = lib().mro_data_new(model.ptr, int(nprops), _dp(self._ps))
 
     def __del__(self):
-        if getattr(self, "ptr", None):
+        if getattr(self, "ptr", None) and lib is not None:
             lib().mro_data_free(self.ptr)
             self.ptr = None
 

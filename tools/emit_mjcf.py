@@ -9,6 +9,7 @@ it at run time) genuine ``mj_step`` can be run on it and compared with the oracl
 dependency, never installed; nothing of the reference is read.
 
     python tools/emit_mjcf.py [--nprops 4] [--solver Newton] > scene.xml
+    python tools/emit_mjcf.py --task push|lasa|base [--actuator position] > scene.xml   # the other tasks' own body trees
 """
 from __future__ import annotations
 
@@ -39,8 +40,8 @@ def _v(x) -> str:
     return " ".join(repr(_r(t)) for t in x)
 
 
-def _geom(g: dict, size=None) -> str:
-    ct, ca = _MASKS[g["group"]]
+def _geom(g: dict, size=None, masks=None) -> str:
+    ct, ca = (masks or _MASKS)[g["group"]]
     a = [f"name={quoteattr(g['name'])}", f'contype="{ct}"', f'conaffinity="{ca}"',
          f'friction="{_v(g["friction"])}"', f'priority="{int(g["priority"])}"', f'condim="{int(g["condim"])}"',
          f'margin="{float(g["margin"])!r}"', f'gap="{float(g["gap"])!r}"', f'solref="{_v(g["solref"])}"',
@@ -73,7 +74,15 @@ def _inertial(i: dict) -> str:
             f"diaginertia=\"{_v(i['diaginertia'])}\"/>")
 
 
-def _body(node: dict, out: list, depth: int, prop_sizes, nprops: int) -> None:
+def _tool_inertial(g: dict) -> str:
+    """A hull box that stands for a cylinder keeps the CYLINDER's mass and inertia (model/compile.py)."""
+    m, (a, _, c) = float(g["mass"]), g["size"]
+    ixx = m * (3 * a * a + 4 * c * c) / 12
+    return (f"<inertial mass=\"{m!r}\" pos=\"{_v(g['pos'])}\" quat=\"{_v(g['quat'])}\" "
+            f"diaginertia=\"{_v((ixx, ixx, m * a * a / 2))}\"/>")
+
+
+def _body(node: dict, out: list, depth: int, prop_sizes, nprops: int, masks=None) -> None:
     name = node["name"]
     if name.startswith("prop_"):
         p = int(name.split("_")[1])
@@ -82,9 +91,9 @@ def _body(node: dict, out: list, depth: int, prop_sizes, nprops: int) -> None:
     pad = "  " * depth
     if name == "world":
         for g in node["geoms"]:
-            out.append(pad + _geom(g))
+            out.append(pad + _geom(g, masks=masks))
         for ch in node["children"]:
-            _body(ch, out, depth, prop_sizes, nprops)
+            _body(ch, out, depth, prop_sizes, nprops, masks)
         return
     out.append(f"{pad}<body name={quoteattr(name)} pos=\"{_v(node['pos'])}\" quat=\"{_v(node['quat'])}\">")
     if node["joint"] is not None:
@@ -92,14 +101,17 @@ def _body(node: dict, out: list, depth: int, prop_sizes, nprops: int) -> None:
     if node["inertial"] is not None:
         out.append(pad + "  " + _inertial(node["inertial"]))
     for g in node["geoms"]:
+        if node["inertial"] is None and g.get("inertia_shape") == "cylinder":
+            out.append(pad + "  " + _tool_inertial(g))
+    for g in node["geoms"]:
         size = None
         if name.startswith("prop_") and prop_sizes is not None:
             size = prop_sizes[int(name.split("_")[1])]
-        out.append(pad + "  " + _geom(g, size))   # (a body with <inertial> ignores its geoms' masses)
+        out.append(pad + "  " + _geom(g, size, masks))   # (a body with <inertial> ignores its geoms' masses)
     for s in node["sites"]:
         out.append(f"{pad}  <site name={quoteattr(s['name'])} pos=\"{_v(s['pos'])}\" quat=\"{_v(s['quat'])}\"/>")
     for ch in node["children"]:
-        _body(ch, out, depth + 1, prop_sizes, nprops)
+        _body(ch, out, depth + 1, prop_sizes, nprops, masks)
     out.append(f"{pad}</body>")
 
 
@@ -116,7 +128,10 @@ def emit(scene: Optional[dict] = None, nprops: int = 4, prop_sizes: Optional[Seq
            f'iterations="{int(o["iterations"])}" tolerance="{float(o["tolerance"])!r}" '
            f'ls_iterations="{int(o.get("ls_iterations", 50))}" ls_tolerance="{float(o.get("ls_tolerance", 0.01))!r}"/>',
            '  <worldbody>']
-    _body(scene["world"], out, 2, prop_sizes, nprops)
+    masks = dict(_MASKS)
+    if scene.get("robot_ground_pairs", False):   # BaseEnv: the robot stands on the floor
+        masks["ground"] = (0, 3)
+    _body(scene["world"], out, 2, prop_sizes, nprops, masks)
     out.append('  </worldbody>')
     out.append('  <equality>')
     for e in scene["equality"]:
@@ -128,15 +143,22 @@ def emit(scene: Optional[dict] = None, nprops: int = 4, prop_sizes: Optional[Seq
                        f'solref="{_v(e["solref"])}" solimp="{_v(e["solimp"])}"/>')
     out.append('  </equality>')
     t = scene["tendon"]
-    out.append('  <tendon>')
-    out.append(f'    <fixed name={quoteattr(t["name"])}>')
-    for j, c in zip(t["joints"], t["coef"]):
-        out.append(f'      <joint joint={quoteattr(j)} coef="{float(c)!r}"/>')
-    out.append('    </fixed>')
-    out.append('  </tendon>')
+    if t["name"] != "null":   # (an arm-only scene fills the blob's tendon / eighth actuator slot with nulls)
+        out.append('  <tendon>')
+        out.append(f'    <fixed name={quoteattr(t["name"])}>')
+        for j, c in zip(t["joints"], t["coef"]):
+            out.append(f'      <joint joint={quoteattr(j)} coef="{float(c)!r}"/>')
+        out.append('    </fixed>')
+        out.append('  </tendon>')
     out.append('  <actuator>')
     for a in scene["actuators"]:
-        if a["kind"] == "motor":
+        if a["kind"] == "motor" and "gainprm" in a:   # position.yaml
+            out.append(f'    <general name={quoteattr(a["name"])} joint={quoteattr(a["joint"])} gaintype="fixed" biastype="affine" '
+                       f'gainprm="{float(a["gainprm"])!r} 0 0" biasprm="{_v(a["biasprm"])}" ctrlrange="{_v(a["ctrlrange"])}" '
+                       f'ctrllimited="true" forcerange="{_v(a["forcerange"])}" forcelimited="true"/>')
+        elif a.get("tendon") == "null":
+            continue
+        elif a["kind"] == "motor":
             out.append(f'    <motor name={quoteattr(a["name"])} joint={quoteattr(a["joint"])} gear="1" '
                        f'ctrlrange="{_v(a["ctrlrange"])}" ctrllimited="true"/>')
         else:
@@ -152,8 +174,15 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--nprops", type=int, default=4)
     ap.add_argument("--solver", choices=["PGS", "Newton"], default=None)
+    ap.add_argument("--task", choices=["rearrangement", "base", "push", "lasa"], default="rearrangement")
+    ap.add_argument("--actuator", choices=["motor", "position"], default="motor")
     args = ap.parse_args()
-    sys.stdout.write(emit(nprops=args.nprops, solver=args.solver))
+    if args.task == "rearrangement":
+        sys.stdout.write(emit(nprops=args.nprops, solver=args.solver))
+    else:
+        scene = S.other_task_scene(args.task, dict(actuator=args.actuator), embed=False)
+        sizes = [[0.025] * 3] * 4 if args.task == "push" else None
+        sys.stdout.write(emit(scene, nprops=1 if args.task == "push" else 0, prop_sizes=sizes, solver=args.solver))
 
 
 if __name__ == "__main__":
