@@ -25,6 +25,10 @@ namespace mre {
 constexpr int NW_QUAD = 0, NW_SAT = 1, NW_CONE = 4;
 constexpr int NW_LS_MAX = 20;       // line-search evaluations at most (opt.ls_iterations = 50 in fp64)
 constexpr float NW_LS_TOL = 0.01f;  // opt.ls_tolerance
+#ifndef NW_LS_REL_VALUE
+#define NW_LS_REL_VALUE 1e-5f
+#endif
+constexpr float NW_LS_REL = NW_LS_REL_VALUE;  // slope reduction at which the fp32 line search stops
 
 MRE_DEV float rdlane(float v, int lane) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
@@ -591,8 +595,11 @@ MRE_PHASE_FN float nw_search_move(ModelP M, Sm& s, int l) {
   MRE_DBG_STAMP(7, 0);
   const float snorm = sqrtf(wave_sum(sv * sv));
   float alpha = 0.f;
+#if defined(MRE_PHASE_STAMPS) && MRE_PHASE_STAMPS == 7
+  int dbg_nev = 0;   // diagnostic build 7: evaluations per tick go to the set's fourth word
+#endif
   if (snorm >= kMinVal) {
-    const float gtol = tol * NW_LS_TOL * snorm / c.scale;
+    const float gtol_abs = tol * NW_LS_TOL * snorm / c.scale;
     float g0 = 0.5f * (Ma - fs) * (qa - as), g1 = sv * (Ma - fs), g2 = 0.5f * sv * Mv;
     wave_sum3(g0, g1, g2);
     // per-lane terms: one scalar row and one contact
@@ -619,7 +626,13 @@ MRE_PHASE_FN float nw_search_move(ModelP M, Sm& s, int l) {
       UU = U1 * U1 + U2 * U2; UV = U1 * V1 + U2 * V2; VV = V1 * V1 + V2 * V2;
       Dm = (1.0f / s.efc_R[i]) / fmaxf(mu * mu * (1.f + mu * mu), kMinVal);
     }
+#if defined(MRE_PHASE_STAMPS) && MRE_PHASE_STAMPS == 7
+#define NW_DBG_EVAL() dbg_nev++
+#else
+#define NW_DBG_EVAL() do {} while (0)
+#endif
     auto eval = [&](float a) {  // PrimalEval
+      NW_DBG_EVAL();
       float q0 = 0.f, q1 = 0.f, q2 = 0.f, ec = 0.f, e1 = 0.f, e2 = 0.f;
       if (s_on && (s_eq || sj + a * svv < 0.f)) { q0 = sq0; q1 = sq1; q2 = sq2; }
       if (c_on) {
@@ -655,6 +668,9 @@ MRE_PHASE_FN float nw_search_move(ModelP M, Sm& s, int l) {
     };
     const NwPoint p0 = eval(0.f);
     if (p0.d2 >= kMinVal) {
+      // fp32: the slope is a sum of terms of the size of the initial slope and cannot be resolved much below
+      // NW_LS_REL of it; MuJoCo's absolute threshold (reachable in fp64) would only be met by alpha stalling
+      const float gtol = fmaxf(gtol_abs, NW_LS_REL * fabsf(p0.d1));
       NwPoint p1 = eval(-p0.d1 / p0.d2);
       if (!(p1.cost <= p0.cost)) p1 = p0;
       if (fabsf(p1.d1) < gtol) {
@@ -682,6 +698,9 @@ MRE_PHASE_FN float nw_search_move(ModelP M, Sm& s, int l) {
   }
   if (l == 0) { s.scratch[0] = alpha; s.scratch[1] = 0.f; }
   MRE_DBG_STAMP(7, 1);
+#if defined(MRE_PHASE_STAMPS) && MRE_PHASE_STAMPS == 7
+  if (threadIdx.x == 0) dbg_acc[3] += (unsigned long long)dbg_nev << 4;
+#endif
   if (alpha == 0.f) { MRE_SYNC(); return 0.f; }
   qa = fmaf(alpha, sv, qa);
   Ma = fmaf(alpha, Mv, Ma);
