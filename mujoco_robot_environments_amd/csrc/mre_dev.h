@@ -47,8 +47,8 @@ static_assert(robot_dof_madr(NRV) == NMR, "robot mass-matrix size");
 #if defined(MRE_LARGE_CAPS) && defined(MRE_NEWTON)
 // the Newton kernels carry no M^-1 J' pool and no block records: the same LDS (6 workgroups per CU)
 // holds more rows
-constexpr int NCON_MAX = 50;
-constexpr int NEFC_MAX = 166;
+constexpr int NCON_MAX = 48;
+constexpr int NEFC_MAX = 160;
 constexpr int NRROW_MAX = 100;
 constexpr int NPP_MAX = 16;
 constexpr int MAXBLK = 58;

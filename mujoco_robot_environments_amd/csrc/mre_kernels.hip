@@ -122,6 +122,10 @@ struct Sm {
   uint8_t rstate[NEFC_MAX];                    // row state after the last constraint update
   uint8_t clist[NPROP][NCON_MAX];              // contacts touching cube p (bit 7: the cube is part B)
   uint8_t ccount[NPROP], cpl_robot, cpl_cubes; // coupling of the Hessian blocks (robot-cube p, cube p-q)
+  // per row, for every cube c: byte offset (from the start of Sm) of the row's six Jacobian words on that cube's
+  // dofs -- its JpA row, its JpB row, or `zrow` where the row does not touch the cube (nw_build_lists)
+  alignas(8) uint16_t jdesc[NEFC_MAX][4];
+  float zrow[24];                              // zeros (three consecutive "rows" of a part that does not exist)
 #else
   float Br[NRROW_MAX][NRV];
   // one 64-byte record per constraint block (scalar-row triple g -> record g, contact c -> record
@@ -914,6 +918,9 @@ MRE_DEV void step_body(const StepArgs& a, Sm& s) {
   }
   if (l < NU) s.ctrl[l] = a.ctrl[(size_t)env * NU + l];
   if (l == 0) { s.nprops = a.nprops[env]; s.overflow = 0; s.ncon = 0; s.nefc = 0; s.solver_iters = 0; }
+#ifdef MRE_NEWTON
+  if (l < 24) s.zrow[l] = 0.f;
+#endif
   if (l < NPROP * 3) {
     const float sz = a.prop_size[(size_t)env * NPROP * 3 + l];
     s.prop_size[l / 3][l % 3] = sz;

@@ -268,6 +268,18 @@ MRE_PHASE_FN void nw_build_lists(Sm& s, int l) {
   for (int b = 0; b < 6; b++)
     if (__ballot(pairbit == b) != 0ull) cc |= 1u << b;
   if (l == 0) { s.cpl_robot = (uint8_t)cr; s.cpl_cubes = (uint8_t)cc; }
+  // lane = row: where the row's Jacobian words of every cube live (read by the matrix-core pass of nw_direction)
+  const int nscalar = 7 + s.nl;
+  const unsigned zoff = (unsigned)offsetof(Sm, zrow);
+  for (int i = l; i < s.nefc; i += 64) {
+    const int h = s.hdr[i], ra = (h >> 8) & 0xF, rb = (h >> 12) & 0xF;
+    const int crow = i - nscalar;   // contact row (scalar rows carry no cube part: ra = rb = 0xF)
+    const unsigned offA = crow >= 0 ? (unsigned)offsetof(Sm, JpA) + 24u * (unsigned)crow : zoff;
+    const unsigned offB = (crow >= 0 && rb != 0xF)
+                              ? (unsigned)offsetof(Sm, JpB) + 24u * (unsigned)(3 * s.con_bslot[crow / 3] + crow % 3) : zoff;
+#pragma unroll
+    for (int cb = 0; cb < NPROP; cb++) s.jdesc[i][cb] = (uint16_t)(ra == cb ? offA : (rb == cb ? offB : zoff));
+  }
   MRE_SYNC();
 }
 
@@ -368,70 +380,79 @@ MRE_PHASE_FN void nw_direction(ModelP M, Sm& s, int l) {
   // triangle accumulate in 24 registers.  Per chunk of four rows a lane fetches its row's header, state and 1 / R
   // and ONE Jacobian word per tile -- no per-row branches, no cross-lane traffic.  Rows in any other state enter with D = 0.
   MRE_DBG_STAMP(4, 0);
+#if defined(MRE_PHASE_STAMPS) && MRE_PHASE_STAMPS == 5
+  {  // diagnostic build 5, words 2 and 3: rows in the cone / quadratic state over the direction calls of the launch
+    int nc_ = 0, nq_ = 0;
+    for (int r0 = 0; r0 < nefc; r0 += 64) {
+      const int st_ = r0 + l < nefc ? (int)s.rstate[r0 + l] : NW_SAT;
+      nc_ += __popcll(__ballot(st_ == NW_CONE)); nq_ += __popcll(__ballot(st_ == NW_QUAD));
+    }
+    if (threadIdx.x == 0) { dbg_acc[2] += (unsigned long long)nc_ << 4; dbg_acc[3] += (unsigned long long)nq_ << 4; }
+  }
+#endif
   typedef float v4f __attribute__((ext_vector_type(4)));
   v4f c00 = {0.f, 0.f, 0.f, 0.f}, c10 = c00, c11 = c00, c20 = c00, c21 = c00, c22 = c00;
   {
     const int g = l >> 4, m16 = l & 15;
-    const int tp = m16 < 12 ? m16 / 6 : -1;   // cube of this lane's dof in tile 1 (tile 2: tp + 2)
-    const int tk = m16 % 6;
-    // (the metadata of the next chunk is fetched while the Jacobian words of this one are on their way)
-    auto meta = [&](int r0, int& ii, int& st, int& h, float& R, int& bs) {
+    // Per chunk of four rows a lane reads its row's descriptor (jdesc: one 8-byte word), header, state and R one
+    // chunk ahead, then ONE Jacobian word per tile at descriptor offset + lane offset: no compares, no per-row
+    // branches.  Lanes past a tile's dofs (m16 = 15; m16 >= 12 in the cube tiles) read whatever lies there: they
+    // only feed accumulator rows / columns that are never read.  Rows outside the quadratic state enter with A = 0.
+    const char* const sb = reinterpret_cast<const char*>(&s);
+    const unsigned zoff = (unsigned)offsetof(Sm, zrow), jr0 = (unsigned)offsetof(Sm, Jr);
+    const unsigned sh = m16 < 12 ? 16u * (unsigned)(m16 / 6) : 0u;   // which half of a descriptor dword
+    const unsigned lo = 4u * (unsigned)(m16 % 6), lr = 4u * (unsigned)m16;
+    auto ldw = [&](unsigned off) { return *reinterpret_cast<const float*>(sb + off); };
+    auto meta = [&](int r0, int& ii, int& st, int& h, float& R, uint2& d) {
       const int i = r0 + g;
       ii = i < nefc ? i : 0;
       st = i < nefc ? (int)s.rstate[ii] : NW_SAT;
       h = s.hdr[ii];
       R = s.efc_R[ii];
-      const int cr = ii - nscalar;
-      bs = s.con_bslot[cr > 0 ? cr / 3 : 0];   // slot of the contact's second-cube rows (0 where it has none)
+      d = *reinterpret_cast<const uint2*>(&s.jdesc[ii][0]);
     };
-    int iiN, stN, hN, bsN;
+    // the row's words at this lane's dof of the three tiles
+    auto gather = [&](int h, uint2 d, float& w0, float& w1, float& w2) {
+      const int rs = h & 0xFF;
+      w0 = ldw((rs != HDR_NONE ? jr0 + 60u * (unsigned)rs : zoff) + lr);
+      w1 = ldw(((d.x >> sh) & 0xFFFFu) + lo);
+      w2 = nprops > 2 ? ldw(((d.y >> sh) & 0xFFFFu) + lo) : 0.f;
+    };
+    static_assert(sizeof(s.Jr[0]) == 60 && sizeof(s.JpA[0]) == 24 && sizeof(s.JpB[0]) == 24, "row strides of the gathers");
+    int iiN, stN, hN;
     float RN;
-    meta(0, iiN, stN, hN, RN, bsN);
-    // J of constraint row (contact-row index crx, robot slot rsx, second-cube row bx) at this lane's dof of the
-    // three tiles: the three candidate words are read unconditionally (clamped addresses) and selected, so
-    // the reads of a chunk -- nine for a row in the cone's middle zone -- are in flight together
-    auto gather = [&](int crx, int rsx, int bx, int pa, int pb, float& w0, float& w1, float& w2) {
-      const float jr = s.Jr[rsx != HDR_NONE ? rsx : 0][m16 < NRV ? m16 : 0];
-      const float ja = s.JpA[crx > 0 ? crx : 0][tk];
-      const float jb = s.JpB[bx][tk];
-      w0 = (rsx != HDR_NONE && m16 < NRV) ? jr : 0.f;
-      w1 = tp < 0 ? 0.f : (pa == tp ? ja : (pb == tp ? jb : 0.f));
-      w2 = (tp < 0 || nprops <= 2) ? 0.f : (pa == tp + 2 ? ja : (pb == tp + 2 ? jb : 0.f));
-    };
+    uint2 dN;
+    meta(0, iiN, stN, hN, RN, dN);
     for (int r0 = 0; r0 < nefc; r0 += 4) {
-      const int ii = iiN, h = hN, st = stN, bs = bsN;
+      const int ii = iiN, h = hN, st = stN;
+      const uint2 d = dN;
       const bool quad = st == NW_QUAD, cone = st == NW_CONE;
-      const float D = quad ? 1.0f / RN : 0.f;
-      if (r0 + 4 < nefc) meta(r0 + 4, iiN, stN, hN, RN, bsN);
-      const int rs = h & 0xFF, pa = (h >> 8) & 0xF, pb = (h >> 12) & 0xF;
-      const int cr = ii - nscalar;   // contact row index (prop parts exist for contact rows only)
-      const int k = cr > 0 ? cr % 3 : 0;
-      float v0 = 0.f, v1 = 0.f, v2 = 0.f, a0, a1, a2;
+      const float D = quad ? __builtin_amdgcn_rcpf(RN) : 0.f;   // (1 ulp; the IEEE division is 12 instructions)
+      if (r0 + 4 < nefc) meta(r0 + 4, iiN, stN, hN, RN, dN);
+      float v0, v1, v2, a0, a1, a2;
       if (__any(cone)) {
         // a contact in the middle zone enters with its 3 x 3 Hessian: row k of the contact contributes
         // (sum_m Hc[k][m] J_m)' J_k, so the A operand of such a lane is the Hc-weighted mix of the contact's three
-        // rows at its dof (the robot slots and prop rows of one contact are consecutive); the other lanes of the
-        // chunk read their own row three times
-        const int cr0 = cone ? cr - k : cr, d1 = cone ? 1 : 0, d2 = cone ? 2 : 0, kk = cone ? k : 0;
-        const int rs0 = rs != HDR_NONE ? rs - kk : HDR_NONE;
+        // rows (consecutive rows, slots and parts) at its dof; the other lanes of the chunk read their own row
+        const int cr = ii - nscalar;
+        const int k = cone ? cr % 3 : 0;
+        const int i0 = ii - k, i1 = cone ? i0 + 1 : ii, i2 = cone ? i0 + 2 : ii;
         float x0, x1, x2, y0, y1, y2, z0, z1, z2;
-        gather(cr0, rs0, 3 * bs + (cone ? 0 : k), pa, pb, x0, x1, x2);
-        gather(cr0 + d1, rs0 != HDR_NONE ? rs0 + d1 : HDR_NONE, 3 * bs + (cone ? 1 : k), pa, pb, y0, y1, y2);
-        gather(cr0 + d2, rs0 != HDR_NONE ? rs0 + d2 : HDR_NONE, 3 * bs + (cone ? 2 : k), pa, pb, z0, z1, z2);
+        gather(s.hdr[i0], *reinterpret_cast<const uint2*>(&s.jdesc[i0][0]), x0, x1, x2);
+        gather(s.hdr[i1], *reinterpret_cast<const uint2*>(&s.jdesc[i1][0]), y0, y1, y2);
+        gather(s.hdr[i2], *reinterpret_cast<const uint2*>(&s.jdesc[i2][0]), z0, z1, z2);
         const float* hcp = s.hc[cone ? cr / 3 : 0];
         const float H0 = k == 0 ? hcp[0] : (k == 1 ? hcp[1] : hcp[2]);
         const float H1 = k == 0 ? hcp[1] : (k == 1 ? hcp[3] : hcp[4]);
         const float H2 = k == 0 ? hcp[2] : (k == 1 ? hcp[4] : hcp[5]);
-        const bool onr = quad || cone;
-        v0 = !onr ? 0.f : (kk == 0 ? x0 : (kk == 1 ? y0 : z0));
-        v1 = !onr ? 0.f : (kk == 0 ? x1 : (kk == 1 ? y1 : z1));
-        v2 = !onr ? 0.f : (kk == 0 ? x2 : (kk == 1 ? y2 : z2));
+        v0 = k == 0 ? x0 : (k == 1 ? y0 : z0);
+        v1 = k == 0 ? x1 : (k == 1 ? y1 : z1);
+        v2 = k == 0 ? x2 : (k == 1 ? y2 : z2);
         a0 = cone ? H0 * x0 + H1 * y0 + H2 * z0 : v0 * D;
         a1 = cone ? H0 * x1 + H1 * y1 + H2 * z1 : v1 * D;
         a2 = cone ? H0 * x2 + H1 * y2 + H2 * z2 : v2 * D;
       } else {
-        gather(cr, rs, 3 * bs + k, pa, pb, v0, v1, v2);
-        if (!quad) { v0 = 0.f; v1 = 0.f; v2 = 0.f; }
+        gather(h, d, v0, v1, v2);
         a0 = v0 * D; a1 = v1 * D; a2 = v2 * D;
       }
       c00 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, v0, c00, 0, 0, 0);

@@ -7,11 +7,12 @@ DIAG = os.path.join(ROOT, "tools", "_diag")
 NAMES = ["position+crb+factor", "velocity", "collide", "assemble", "control", "smooth", "solve", "integrate+io",
          "newton: setup", "newton: direction", "newton: direction (re-used)", "newton: search",
          "direction: init (M rows)", "direction: J'DJ (matrix cores)", "direction: tiles to rows", "direction: elimination + back solve",
+         "position_stage: kinematics", "position_stage: comPos", "direction: cone rows (count)", "direction: quad rows (count)",
          "search: M v, J v", "search: line search evaluations", "search: move, update, J'f, gradient", "search: evaluations (count)"]
 if "MRE_LIB" not in os.environ:
     tick = sys.argv[1] if len(sys.argv) > 1 else "200"
     vals = []
-    for k in (0, 1, 2, 4, 7):
+    for k in (0, 1, 2, 4, 5, 7):
         env = dict(os.environ, MRE_LIB=os.path.join(DIAG, f"libmre_stamps{k}.so"))
         out = subprocess.check_output([sys.executable, __file__, tick], env=env)
         vals.append(np.frombuffer(out[-4096 * 4 * 4:], np.int32).reshape(4096, 4))
