@@ -341,9 +341,9 @@ def main():
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "valu_issue": valu_issue(avg_launch_s, solver) if pmc else None,
                          "note": ("HBM is not the bound: per-env state stays in LDS across the 5 fused steps. PGS: VALU "
-                                  "issue (see valu_issue; the 100 sweeps are 82 % of a tick)" if solver == "PGS" else
+                                  "issue (see valu_issue; the 100 sweeps are 87 % of a tick, profiles/*_phase_stamps_pgs.log)" if solver == "PGS" else
                                   "HBM is not the bound: per-env state stays in LDS across the 5 fused steps. Newton: "
-                                  "dependent LDS round trips at 2 waves/SIMD (waves parked in s_waitcnt 43 % of their "
+                                  "dependent LDS round trips at 2 waves/SIMD (waves parked in s_waitcnt 41 % of their "
                                   "cycles, SQ_WAIT_ANY; VALU issue in valu_issue)")},
             "health": {"nan_envs": int(((status & 2) != 0).sum()), "overflow_envs": int(((status & 4) != 0).sum()),
                        "mean_ncon": float(stats[:, 0].mean()), "mean_nefc": float(stats[:, 1].mean()),
