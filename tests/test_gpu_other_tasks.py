@@ -10,7 +10,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _oracle_twin(env, i, rounded=False):
+def _oracle_twin(env, i):
     from mujoco_robot_environments_amd.model import compile as MC
     from oracle import oracle as O
     if not hasattr(env, "_omodel"):
@@ -131,7 +131,7 @@ def test_lasa_draw_targets_match_oracle():
     tw = [_oracle_twin(env, i) for i in range(N)]
     tw32 = [_oracle_twin(env, i) for i in range(N)]
     p = O.make_osc()
-    air, D, B = 0.0, np.zeros((T, N)), np.zeros((T, N))
+    D, B = np.zeros((T, N)), np.zeros((T, N))
     for k in range(T):
         w = 0.02 * k
         z = 0.45 if k < 150 else 0.45 - 0.0006 * (k - 150)     # table top at 0.4
