@@ -71,7 +71,9 @@ def pmc_traffic(solver="PGS"):
 
 def valu_issue(avg_launch_s, solver="PGS"):
     """What actually bounds the kernel: VALU issue slots.  A wave64 VALU instruction occupies its
-    SIMD for 4 cycles (16 lanes per SIMD), so  util = SQ_INSTS_VALU * 4 / (SIMDs * clock * time)."""
+    SIMD for 4 cycles (16 lanes per SIMD), so  util = SQ_INSTS_VALU * 4 / (SIMDs * clock * time).
+    ``avg_launch_s``: wall time per launch (tick time / launches per tick): launches of different env groups
+    overlap on the GPU, so their individual durations do not add up to the time the SIMDs were available."""
     d, name = pmc_summary(solver)
     n = d.get("SQ_INSTS_VALU_per_launch")
     if not n or avg_launch_s <= 0:
@@ -317,7 +319,7 @@ def main():
     assert K % F == 0 and W % F == 0, "--fused must divide --steps and --warmup"
     acts = rng.random_actions(args.seed, env_ids, np.arange(W + K)).astype(np.float32)
     seq = torch.from_numpy(acts).to(phys.device).contiguous()  # resident in HBM before timing
-    bytes_per_launch = algorithmic_bytes_per_env_step(nprops) * n_local * CONTROL_STEPS * F
+    bytes_per_tick = algorithmic_bytes_per_env_step(nprops) * n_local * CONTROL_STEPS * F
     total_env_steps = world * n_local * K * CONTROL_STEPS
     pmc = (F == 1 and n_local == ENVS_PER_GPU)
 
@@ -330,7 +332,12 @@ def main():
         elapsed, kern_ms, launches, gather_ms = timed_run(phys, seq, K, W, F, world, backend, dist, torch, n_local)
         status, stats = phys.status(), phys.solver_stats()
         avg_launch_s = (kern_ms / max(launches, 1)) * 1e-3
+        # the library steps the batch as env groups on separate streams (launches of different groups overlap on
+        # the GPU, csrc/mre_api.cpp launch_step): one tick = `per_tick` launches of N / per_tick envs each
+        per_tick = max(1, round(launches / max(K // F, 1)))
+        bytes_per_launch = bytes_per_tick / per_tick
         achieved = bytes_per_launch / avg_launch_s / 1e9
+        wall_per_launch_s = elapsed / max(K // F, 1) / per_tick   # overlapping launches: use wall time for utilisation
         kname = "mre::k_step" if solver == "PGS" else "mre::k_step_newton"
         return {
             "solver": solver, "value": total_env_steps / elapsed, "ms_per_step": elapsed / K * 1e3, "gather_ms": gather_ms,
@@ -338,8 +345,10 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic(solver)[0] if pmc else None, "traffic_source": pmc_traffic(solver)[1],
                          "kernel": kname, "avg_launch_ms": avg_launch_s * 1e3, "launches": launches,
+                         "launches_per_tick": per_tick, "envs_per_launch": n_local // per_tick,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "valu_issue": valu_issue(avg_launch_s, solver) if pmc else None,
+                         "achieved_over_wall_time": bytes_per_tick / (elapsed / max(K // F, 1)) / 1e9,
+                         "valu_issue": valu_issue(wall_per_launch_s, solver) if pmc else None,
                          "note": ("HBM is not the bound: per-env state stays in LDS across the 5 fused steps. PGS: VALU "
                                   "issue (see valu_issue; the 100 sweeps are 87 % of a tick, profiles/*_phase_stamps_pgs.log)" if solver == "PGS" else
                                   "HBM is not the bound: per-env state stays in LDS across the 5 fused steps. Newton: "

@@ -23,12 +23,12 @@ extern "C" void mre_launch_step_newton(const StepArgs* args, hipStream_t stream)
 extern "C" void mre_launch_settle_newton(const StepArgs* args, hipStream_t stream);
 extern "C" void mre_launch_step_large_newton(const StepArgs* args, hipStream_t stream);
 extern "C" void mre_launch_render(const RenderArgs* args, int row_groups, hipStream_t stream);
-extern "C" void mre_launch_prepare(const uint8_t* user_mask, const uint8_t* large, int N, uint8_t* mask_compact,
+extern "C" void mre_launch_prepare(const uint8_t* user_mask, const uint8_t* large, int env0, int N, uint8_t* mask_compact,
                                    uint8_t* mask_large, int* launch_info, const float* qpos, float* sv_qpos,
                                    const float* qvel, float* sv_qvel, const float* qacc_ws, float* sv_qacc_ws,
                                    const float* ctrl, float* sv_ctrl, const uint32_t* status, uint32_t* sv_status,
                                    const uint8_t* converged, uint8_t* sv_converged, hipStream_t stream);
-extern "C" void mre_launch_restore_rows(const uint8_t* sel, int N, float* qpos, const float* sv_qpos, float* qvel,
+extern "C" void mre_launch_restore_rows(const uint8_t* sel, int env0, int N, float* qpos, const float* sv_qpos, float* qvel,
                                         const float* sv_qvel, float* qacc_ws, const float* sv_qacc_ws, float* ctrl,
                                         const float* sv_ctrl, uint32_t* status, const uint32_t* sv_status,
                                         uint8_t* converged, const uint8_t* sv_converged, hipStream_t stream);
@@ -110,6 +110,26 @@ struct mre_env {
   int prop_geom0 = 12;           // geom id of cube 0 (cubes are the last NPROP geoms)
   int last_settle_max = 0;
   long long n_reruns = 0, n_promotions = 0, n_demotions = 0;
+  // ---- pipelined env groups (launch_step): the envs are cut into contiguous groups, each with its own stream
+  // pair; a stepping call enqueues every group's launch and returns, and a group's launch info is read -- and its
+  // fallback decisions taken -- only when the NEXT launch of that group is issued (or at the next call that
+  // touches the state: drain()).  The tail of one group's launch (its slowest envs) then overlaps the other
+  // group's next launch instead of leaving the GPU idle.
+  struct Group {
+    int lo = 0, n = 0;
+    hipStream_t st = nullptr, st2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_info = nullptr;
+    bool pending = false;
+    StepArgs args;   // of the pending launch (a re-run uses them)
+    hipEvent_t p0 = nullptr, p1 = nullptr;   // profiling bracket of the pending launch
+  };
+  std::vector<Group> groups;
+  int* grp_order = nullptr;     // device [N]: per group, its envs slowest first
+  int* h_grp_order = nullptr;   // pinned staging
+  hipEvent_t ev_main = nullptr; // orders the group streams after the handle's stream
+  float* seq_copy[2] = {nullptr, nullptr};  // own copies of the last two ctrl_seq arguments (re-runs read them later)
+  size_t seq_cap = 0;
+  unsigned seq_calls = 0;
 };
 
 // solver-specific instantiations of the step kernel (opt_solver of the model, mre_set_solver)
@@ -135,8 +155,157 @@ static void launch_large(const mre_env* e, const StepArgs& a, hipStream_t st) {
 //      capacities; it also moves envs whose high-water marks came within 1/8 of a compact capacity
 //      (no re-run needed at a launch boundary) and demotes large envs that fell below 5/8.
 // Only an overflow of the LARGE capacities is reported (MRE_ST_CONTACT_OVERFLOW).
+static int profile_events(mre_env* e, hipEvent_t* e0, hipEvent_t* e1) {
+  *e0 = *e1 = nullptr;
+  if (!e->profiling) return MRE_OK;
+  if (e->events_used == e->events.size()) {
+    hipEvent_t x, y;
+    HIPCHK(hipEventCreate(&x)); HIPCHK(hipEventCreate(&y));
+    e->events.emplace_back(x, y);
+  }
+  *e0 = e->events[e->events_used].first; *e1 = e->events[e->events_used].second;
+  e->events_used++;
+  return MRE_OK;
+}
+
+// Read the launch info of a group's pending launch and act on it (see launch_step): promotions / demotions,
+// dispatch order of the group's next launch, re-run of the envs that overflowed the compact kernel.
+static int finish_group(mre_env* e, mre_env::Group& G) {
+  if (!G.pending) return MRE_OK;
+  HIPCHK(hipEventSynchronize(G.ev_info));
+  G.pending = false;
+  int nrerun = 0;
+  bool changed = false;
+  int kmax = 0;
+  for (int i = G.lo; i < G.lo + G.n; i++) {
+    const int* li = e->h_launch_info + 4 * (size_t)i;
+    e->h_rerun[i] = 0;
+    if (li[0] < 0) continue;
+    const int hw_ncon = li[1] & 0xFFFF, hw_nefc = li[2], hw_nrrow = li[3] & 0xFFFF, hw_npp = li[3] >> 16;
+    if ((li[1] >> 16) > kmax) kmax = li[1] >> 16;
+    if (!e->h_large[i]) {
+      if (li[0] > 0) {
+        e->h_rerun[i] = 1; e->h_large[i] = 1; nrerun++; changed = true; e->n_large++; e->n_promotions++;
+      } else if (!e->compact_only && (8 * hw_ncon > 7 * NCON_MAX || 8 * hw_nefc > 7 * NEFC_MAX ||
+                                      8 * hw_nrrow > 7 * NRROW_MAX || 8 * hw_npp > 7 * NPP_MAX)) {
+        e->h_large[i] = 1; changed = true; e->n_large++; e->n_promotions++;
+      }
+    } else if (!e->large_only && li[0] == 0 && 8 * hw_ncon <= 5 * NCON_MAX && 8 * hw_nefc <= 5 * NEFC_MAX &&
+               8 * hw_nrrow <= 5 * NRROW_MAX && 8 * hw_npp <= 5 * NPP_MAX) {
+      e->h_large[i] = 0; changed = true; e->n_large--; e->n_demotions++;
+    }
+  }
+  if (kmax > 0) {   // longest processing time first within the group (counting sort, stable)
+    int count[258] = {0};
+    auto bucket = [&](int i) {
+      const int* li = e->h_launch_info + 4 * (size_t)i;
+      return (int)((long long)(li[0] < 0 ? 0 : (li[1] >> 16)) * 255 / kmax);
+    };
+    for (int i = G.lo; i < G.lo + G.n; i++) count[255 - bucket(i) + 1]++;
+    for (int k = 1; k <= 256; k++) count[k] += count[k - 1];
+    for (int i = G.lo; i < G.lo + G.n; i++) e->h_grp_order[G.lo + count[255 - bucket(i)]++] = i;
+    HIPCHK(hipMemcpyAsync(e->grp_order + G.lo, e->h_grp_order + G.lo, (size_t)G.n * 4, hipMemcpyHostToDevice, G.st));
+  }
+  if (nrerun > 0) {
+    HIPCHK(hipMemcpyAsync(e->mask_r + G.lo, e->h_rerun.data() + G.lo, (size_t)G.n, hipMemcpyHostToDevice, G.st));
+    mre_launch_restore_rows(e->mask_r, G.lo, G.n, e->qpos, e->sv_qpos, e->qvel, e->sv_qvel, e->qacc_ws, e->sv_qacc_ws,
+                            e->ctrl, e->sv_ctrl, e->status, e->sv_status, e->converged, e->sv_converged, G.st);
+    StepArgs ar = G.args;
+    ar.env_mask = e->mask_r; ar.launch_info = nullptr;
+    launch_large(e, ar, G.st);
+    HIPCHK(hipGetLastError());
+    e->n_reruns += nrerun;
+  }
+  if (changed) {
+    HIPCHK(hipMemcpyAsync(e->d_large + G.lo, e->h_large.data() + G.lo, (size_t)G.n, hipMemcpyHostToDevice, G.st));
+    HIPCHK(hipStreamSynchronize(G.st));   // (the staged bytes must outlive the upload)
+  } else if (nrerun > 0) {
+    HIPCHK(hipStreamSynchronize(G.st));
+  }
+  return MRE_OK;
+}
+
+// Complete every pending group launch: every entry point that reads or writes device state starts here.
+static int drain(mre_env* e) {
+  bool any = false;
+  for (auto& G : e->groups) any = any || G.pending;
+  if (!any) return MRE_OK;
+  HIPCHK(hipSetDevice(e->device));
+  for (auto& G : e->groups) {
+    int rc = finish_group(e, G);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(G.st));
+  }
+  return MRE_OK;
+}
+#define DRAIN(e) do { int rc_ = drain(e); if (rc_) return rc_; } while (0)
+
+// One group's part of a stepping call: finish its previous launch, enqueue the new one, do not wait.
+static int launch_group(mre_env* e, mre_env::Group& G, const StepArgs& a_full) {
+  int rc = finish_group(e, G);
+  if (rc) return rc;
+  StepArgs a = a_full;
+  a.N = G.n; a.env_order = e->grp_order + G.lo; a.seq_stride = e->N;
+  rc = profile_events(e, &G.p0, &G.p1);
+  if (rc) return rc;
+  HIPCHK(hipStreamWaitEvent(G.st, e->ev_main, 0));
+  if (G.p0) HIPCHK(hipEventRecord(G.p0, G.st));
+  mre_launch_prepare(nullptr, e->d_large, G.lo, G.n, e->mask_c, e->mask_l, e->launch_info, e->qpos, e->sv_qpos,
+                     e->qvel, e->sv_qvel, e->qacc_ws, e->sv_qacc_ws, e->ctrl, e->sv_ctrl, e->status, e->sv_status,
+                     e->converged, e->sv_converged, G.st);
+  StepArgs ac = a;
+  ac.env_mask = e->mask_c; ac.launch_info = e->launch_info;
+  bool run_large = false;
+  for (int i = G.lo; i < G.lo + G.n && !run_large; i++) run_large = e->h_large[i] != 0;
+  if (run_large) {
+    HIPCHK(hipEventRecord(G.ev_fork, G.st));
+    HIPCHK(hipStreamWaitEvent(G.st2, G.ev_fork, 0));
+    StepArgs al = a;
+    al.env_mask = e->mask_l; al.launch_info = e->launch_info;
+    launch_large(e, al, G.st2);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(G.ev_join, G.st2));
+  }
+  launch_compact(e, ac, G.st, false);
+  HIPCHK(hipGetLastError());
+  if (run_large) HIPCHK(hipStreamWaitEvent(G.st, G.ev_join, 0));
+  if (G.p1) HIPCHK(hipEventRecord(G.p1, G.st));
+  HIPCHK(hipMemcpyAsync(e->h_launch_info + 4 * (size_t)G.lo, e->launch_info + 4 * (size_t)G.lo, (size_t)G.n * 16,
+                        hipMemcpyDeviceToHost, G.st));
+  HIPCHK(hipEventRecord(G.ev_info, G.st));
+  G.args = a;
+  G.pending = true;
+  return MRE_OK;
+}
+
 static int launch_step(mre_env* e, const StepArgs& a, bool settle = false) {
   HIPCHK(hipSetDevice(e->device));  // the HIP current device is per thread; callers may have moved it
+  {
+    const bool guarded_ = e->fallback && a.nsteps > 0 && (a.flags & F_NO_CONSTRAINTS) == 0;
+    const bool pipelined = e->groups.size() > 1 && guarded_ && !settle && a.env_mask == nullptr && !e->use_order &&
+                           a.trace == nullptr && a.contacts == nullptr && a.settle_steps == nullptr && a.geoms == nullptr &&
+                           (a.flags & (F_DETECT | F_SETTLE_EXIT | F_OSC_EVAL)) == 0;
+    if (pipelined) {
+      HIPCHK(hipEventRecord(e->ev_main, e->stream));
+      // serve the groups in the order their previous launches complete
+      const size_t ng = e->groups.size();
+      bool done[8] = {false, false, false, false, false, false, false, false};
+      for (size_t left = ng; left > 0;) {
+        size_t pick = ng;
+        for (size_t g = 0; g < ng && pick == ng; g++)
+          if (!done[g] && (!e->groups[g].pending || hipEventQuery(e->groups[g].ev_info) == hipSuccess)) pick = g;
+        (void)hipGetLastError();   // (hipErrorNotReady of a query is not an error)
+        if (pick == ng) {          // none ready: wait for the first outstanding one
+          for (size_t g = 0; g < ng && pick == ng; g++) if (!done[g]) pick = g;
+        }
+        int rc = launch_group(e, e->groups[pick], a);
+        if (rc) return rc;
+        done[pick] = true; left--;
+      }
+      return MRE_OK;
+    }
+    DRAIN(e);
+  }
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (e->profiling) {
     if (e->events_used == e->events.size()) {
@@ -154,7 +323,7 @@ static int launch_step(mre_env* e, const StepArgs& a, bool settle = false) {
     HIPCHK(hipGetLastError());
   } else {
     const size_t N = (size_t)e->N;
-    mre_launch_prepare(a.env_mask, e->d_large, e->N, e->mask_c, e->mask_l, e->launch_info, e->qpos, e->sv_qpos,
+    mre_launch_prepare(a.env_mask, e->d_large, 0, e->N, e->mask_c, e->mask_l, e->launch_info, e->qpos, e->sv_qpos,
                        e->qvel, e->sv_qvel, e->qacc_ws, e->sv_qacc_ws, e->ctrl, e->sv_ctrl, e->status, e->sv_status,
                        e->converged, e->sv_converged, e->stream);
     StepArgs ac = a;
@@ -226,7 +395,7 @@ static int launch_step(mre_env* e, const StepArgs& a, bool settle = false) {
     }
     if (nrerun > 0) {
       HIPCHK(hipMemcpyAsync(e->mask_r, e->h_rerun.data(), N, hipMemcpyHostToDevice, e->stream));
-      mre_launch_restore_rows(e->mask_r, e->N, e->qpos, e->sv_qpos, e->qvel, e->sv_qvel, e->qacc_ws, e->sv_qacc_ws,
+      mre_launch_restore_rows(e->mask_r, 0, e->N, e->qpos, e->sv_qpos, e->qvel, e->sv_qvel, e->qacc_ws, e->sv_qacc_ws,
                               e->ctrl, e->sv_ctrl, e->status, e->sv_status, e->converged, e->sv_converged, e->stream);
       StepArgs ar = a;
       ar.env_mask = e->mask_r; ar.launch_info = nullptr;
@@ -480,6 +649,40 @@ static int create_buffers(mre_env* e, int num_envs, int device_id) {
   HIPCHK(hipHostMalloc((void**)&e->h_launch_info, N * 16, hipHostMallocDefault));
   HIPCHK(hipMemsetAsync(e->d_large, 0, N, e->stream));
   e->h_large.assign(N, 0); e->h_rerun.assign(N, 0);
+  {
+    // env groups of the pipelined stepping path (MRE_GROUPS = 1: every call completes before it returns)
+    int ng = 4, min_envs = 128;   // (measured on the bench: 2, 3 and 4 groups are within 1 % for Newton, 4 best for PGS)
+    if (const char* g = getenv("MRE_GROUPS")) ng = atoi(g);
+    if (const char* g = getenv("MRE_GROUP_MIN")) min_envs = atoi(g);   // test knob: smallest group worth a launch of its own
+    if (ng < 1) ng = 1;
+    if (ng > 8) ng = 8;
+    while (ng > 1 && num_envs < min_envs * ng) ng--;
+    HIPCHK(hipMalloc(&e->grp_order, N * 4));
+    HIPCHK(hipHostMalloc((void**)&e->h_grp_order, N * 4, hipHostMallocDefault));
+    for (int i = 0; i < num_envs; i++) e->h_grp_order[i] = i;
+    HIPCHK(hipMemcpy(e->grp_order, e->h_grp_order, N * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipEventCreateWithFlags(&e->ev_main, hipEventDisableTiming));
+    e->groups.resize(ng);
+    for (int g = 0; g < ng; g++) {
+      auto& G = e->groups[g];
+      G.lo = (int)((long long)num_envs * g / ng);
+      G.n = (int)((long long)num_envs * (g + 1) / ng) - G.lo;
+      // descending stream priorities stagger the groups: the first group's workgroups are dispatched first and the
+      // later groups fill the slots its slow envs leave idle (MRE_GROUP_PRIORITY=0: equal priorities)
+      int pr = 0;
+      {
+        int least = 0, greatest = 0;
+        HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        const char* gp = getenv("MRE_GROUP_PRIORITY");
+        if (!(gp && atoi(gp) == 0)) { pr = greatest + g; if (pr > least) pr = least; }
+      }
+      HIPCHK(hipStreamCreateWithPriority(&G.st, hipStreamNonBlocking, pr));
+      HIPCHK(hipStreamCreateWithPriority(&G.st2, hipStreamNonBlocking, pr));
+      HIPCHK(hipEventCreateWithFlags(&G.ev_fork, hipEventDisableTiming));
+      HIPCHK(hipEventCreateWithFlags(&G.ev_join, hipEventDisableTiming));
+      HIPCHK(hipEventCreateWithFlags(&G.ev_info, hipEventDisableTiming));
+    }
+  }
   if (const char* fb = getenv("MRE_NO_FALLBACK")) e->fallback = atoi(fb) == 0;  // profiling knob only
   if (const char* fl = getenv("MRE_FORCE_LARGE")) {  // profiling knob only: start every env on the large kernel
     if (atoi(fl) != 0) {
@@ -544,6 +747,18 @@ extern "C" int mre_create(const void* blob, size_t nbytes, int num_envs, int dev
 extern "C" int mre_destroy(mre_env* e) {
   if (!e) return MRE_OK;
   (void)hipSetDevice(e->device);
+  (void)drain(e);
+  for (auto& G : e->groups) {
+    if (G.st) { (void)hipStreamSynchronize(G.st); (void)hipStreamDestroy(G.st); }
+    if (G.st2) { (void)hipStreamSynchronize(G.st2); (void)hipStreamDestroy(G.st2); }
+    if (G.ev_fork) (void)hipEventDestroy(G.ev_fork);
+    if (G.ev_join) (void)hipEventDestroy(G.ev_join);
+    if (G.ev_info) (void)hipEventDestroy(G.ev_info);
+  }
+  if (e->ev_main) (void)hipEventDestroy(e->ev_main);
+  if (e->grp_order) (void)hipFree(e->grp_order);
+  if (e->h_grp_order) (void)hipHostFree(e->h_grp_order);
+  for (float* p : e->seq_copy) if (p) (void)hipFree(p);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   if (e->stream2) (void)hipStreamSynchronize(e->stream2);
   void* ptrs[] = {e->dM, e->qpos, e->qvel, e->qacc_ws, e->ctrl, e->nprops, e->prop_size, e->osc_target,
@@ -571,6 +786,7 @@ extern "C" void* mre_stream(mre_env* e) { return e ? (void*)e->stream : nullptr;
 extern "C" int mre_sync(mre_env* e) {
   if (!e) return fail(MRE_ERR_ARG, "null handle");
   HIPCHK(hipSetDevice(e->device));
+  DRAIN(e);
   HIPCHK(hipStreamSynchronize(e->stream));
   return MRE_OK;
 }
@@ -597,6 +813,7 @@ static int stage_mask(mre_env* e, const uint8_t* mask, const uint8_t** dmask) {
 
 extern "C" int mre_set_props(mre_env* e, const int32_t* nprops, const float* prop_half_size) {
   if (!e || !nprops || !prop_half_size) return fail(MRE_ERR_ARG, "mre_set_props: null");
+  DRAIN(e);
   int rc = copy_in(e, e->nprops, nprops, (size_t)e->N * 4);
   if (rc) return rc;
   return copy_in(e, e->prop_size, prop_half_size, (size_t)e->N * NPROP * 3 * 4);
@@ -604,6 +821,7 @@ extern "C" int mre_set_props(mre_env* e, const int32_t* nprops, const float* pro
 
 extern "C" int mre_reset(mre_env* e, const uint8_t* mask) {
   if (!e) return fail(MRE_ERR_ARG, "null handle");
+  DRAIN(e);
   HIPCHK(hipSetDevice(e->device));
   const uint8_t* dmask;
   int rc = stage_mask(e, mask, &dmask);
@@ -637,6 +855,7 @@ static bool is_device_ptr(const void* p) {
 
 extern "C" int mre_set_render_colours(mre_env* e, const uint8_t* prop_rgb, const float* geom_rgb) {
   if (!e) return fail(MRE_ERR_ARG, "null handle");
+  DRAIN(e);
   const size_t N = (size_t)e->N;
   if (!e->prop_rgb) {
     HIPCHK(hipMalloc(&e->prop_rgb, N * NPROP * 3));
@@ -652,6 +871,7 @@ extern "C" int mre_set_render_colours(mre_env* e, const uint8_t* prop_rgb, const
 extern "C" int mre_render(mre_env* e, const float* cam_pos, const float* cam_mat, float fovy_deg, int height, int width,
                           uint8_t* rgb, float* depth, uint8_t* seg, const uint8_t* mask) {
   if (!e || !cam_pos || !cam_mat) return fail(MRE_ERR_ARG, "mre_render: null argument");
+  DRAIN(e);
   HIPCHK(hipSetDevice(e->device));
   if (height <= 0 || width <= 0 || (width & 3) != 0 || width / 4 > 320 || !(fovy_deg > 0.f && fovy_deg < 180.f))
     return fail(MRE_ERR_ARG, "mre_render: width must be a multiple of 4 (<= 1280), 0 < fovy < 180");
@@ -753,6 +973,7 @@ extern "C" int mre_render(mre_env* e, const float* cam_pos, const float* cam_mat
 
 extern "C" int mre_set_fallback(mre_env* e, int mode) {
   if (!e) return fail(MRE_ERR_ARG, "null handle");
+  DRAIN(e);
   if (mode < 0 || mode > 2) return fail(MRE_ERR_ARG, "mre_set_fallback: mode is 0 (compact only), 1 (fallback) or 2 (large only)");
   e->fallback = mode != 0;
   e->large_only = mode == 2;
@@ -805,6 +1026,7 @@ extern "C" int mre_wait_stream(mre_env* e, void* stream) {
 
 extern "C" int mre_set_solver(mre_env* e, int solver) {
   if (!e) return fail(MRE_ERR_ARG, "null handle");
+  DRAIN(e);
   if (solver != MRE_SOLVER_PGS && solver != MRE_SOLVER_NEWTON)
     return fail(MRE_ERR_ARG, "mre_set_solver: solver is 0 (PGS) or 2 (Newton)");
   HIPCHK(hipSetDevice(e->device));
@@ -821,12 +1043,14 @@ extern "C" int mre_get_solver(mre_env* e) {
 
 extern "C" int mre_get_fallback_stats(mre_env* e, long long* out4) {
   if (!e || !out4) return fail(MRE_ERR_ARG, "mre_get_fallback_stats: null");
+  DRAIN(e);
   out4[0] = e->n_large; out4[1] = e->n_reruns; out4[2] = e->n_promotions; out4[3] = e->n_demotions;
   return MRE_OK;
 }
 
 extern "C" int mre_set_state(mre_env* e, const float* qpos, const float* qvel) {
   if (!e) return fail(MRE_ERR_ARG, "null handle");
+  DRAIN(e);
   int rc = MRE_OK;
   if (qpos) rc = copy_in(e, e->qpos, qpos, (size_t)e->N * NQP * 4);
   if (!rc && qvel) rc = copy_in(e, e->qvel, qvel, (size_t)e->N * NVP * 4);
@@ -834,11 +1058,13 @@ extern "C" int mre_set_state(mre_env* e, const float* qpos, const float* qvel) {
 }
 extern "C" int mre_get_ctrl(mre_env* e, float* ctrl) {
   if (!e || !ctrl) return fail(MRE_ERR_ARG, "mre_get_ctrl: null");
+  DRAIN(e);
   return copy_out(e, ctrl, e->ctrl, (size_t)e->N * NU * 4);
 }
 
 extern "C" int mre_get_state(mre_env* e, float* qpos, float* qvel) {
   if (!e) return fail(MRE_ERR_ARG, "null handle");
+  DRAIN(e);
   int rc = MRE_OK;
   if (qpos) rc = copy_out(e, qpos, e->qpos, (size_t)e->N * NQP * 4);
   if (!rc && qvel) rc = copy_out(e, qvel, e->qvel, (size_t)e->N * NVP * 4);
@@ -846,20 +1072,23 @@ extern "C" int mre_get_state(mre_env* e, float* qpos, float* qvel) {
 }
 extern "C" int mre_set_warmstart(mre_env* e, const float* w) {
   if (!e || !w) return fail(MRE_ERR_ARG, "null");
+  DRAIN(e);
   return copy_in(e, e->qacc_ws, w, (size_t)e->N * NVP * 4);
 }
 extern "C" int mre_get_warmstart(mre_env* e, float* w) {
   if (!e || !w) return fail(MRE_ERR_ARG, "null");
+  DRAIN(e);
   return copy_out(e, w, e->qacc_ws, (size_t)e->N * NVP * 4);
 }
 extern "C" int mre_set_ctrl(mre_env* e, const float* ctrl) {
   if (!e || !ctrl) return fail(MRE_ERR_ARG, "null");
+  DRAIN(e);
   return copy_in(e, e->ctrl, ctrl, (size_t)e->N * NU * 4);
 }
 
 static void fill_args(mre_env* e, StepArgs& a) {
   memset(&a, 0, sizeof(a));
-  a.M = e->dM; a.N = e->N;
+  a.M = e->dM; a.N = e->N; a.seq_stride = e->N;
   a.qpos = e->qpos; a.qvel = e->qvel; a.qacc_ws = e->qacc_ws; a.ctrl = e->ctrl;
   a.nprops = e->nprops; a.prop_size = e->prop_size;
   a.control_steps = 1; a.mode = CTRL_HELD;
@@ -894,6 +1123,19 @@ extern "C" int mre_rollout(mre_env* e, const float* ctrl_seq, int nticks, int co
   a.nsteps = nticks * control_steps; a.control_steps = control_steps; a.mode = CTRL_SEQ;
   a.ctrl_seq = ctrl_seq; a.flags = flags;
   a.sites = nullptr;  // (as in mre_step)
+  if (e->groups.size() > 1 && nticks > 0) {
+    // a pipelined launch may be re-run (capacity fallback) after this call has returned: it reads the controls
+    // from the handle's own copy (two buffers: the copy of call k is needed until call k + 1 has been issued)
+    const size_t n = (size_t)nticks * (size_t)e->N * NU;
+    if (n > e->seq_cap) {
+      DRAIN(e);
+      for (float*& p : e->seq_copy) { if (p) HIPCHK(hipFree(p)); p = nullptr; HIPCHK(hipMalloc(&p, n * 4)); }
+      e->seq_cap = n;
+    }
+    float* dst = e->seq_copy[e->seq_calls++ & 1u];
+    HIPCHK(hipMemcpyAsync(dst, ctrl_seq, n * 4, hipMemcpyDeviceToDevice, e->stream));
+    a.ctrl_seq = dst;
+  }
   int rc = launch_step(e, a);
   if (rc) return rc;
   if (e->trace) e->trace_pos += a.nsteps;
@@ -902,6 +1144,7 @@ extern "C" int mre_rollout(mre_env* e, const float* ctrl_seq, int nticks, int co
 
 extern "C" int mre_set_trace(mre_env* e, float* out, int nenv, int max_steps) {
   if (!e) return fail(MRE_ERR_ARG, "null handle");
+  DRAIN(e);
   if (out) {
     hipPointerAttribute_t at;
     if (hipPointerGetAttributes(&at, out) != hipSuccess || at.type != hipMemoryTypeDevice) {
@@ -917,6 +1160,7 @@ extern "C" int mre_set_trace(mre_env* e, float* out, int nenv, int max_steps) {
 extern "C" int mre_osc_configure(mre_env* e, const float* gains, const float* null_q, const float* thr,
                                  int pinv_always) {
   if (!e) return fail(MRE_ERR_ARG, "null handle");
+  DRAIN(e);
   if (gains) {
     e->osc.kp_pos = gains[0]; e->osc.kd_pos = gains[1]; e->osc.kp_ori = gains[2];
     e->osc.kd_ori = gains[3]; e->osc.kp_null = gains[4]; e->osc.kd_null = gains[5];
@@ -934,6 +1178,7 @@ extern "C" int mre_osc_configure(mre_env* e, const float* gains, const float* nu
 // shared configuration's values; mre_osc_configure afterwards returns to one shared set
 extern "C" int mre_osc_configure_env(mre_env* e, const float* gains, const float* null_q, const float* thr) {
   if (!e) return fail(MRE_ERR_ARG, "null handle");
+  DRAIN(e);
   const size_t N = (size_t)e->N;
   std::vector<OscConfig> h(N, e->osc);
   for (size_t i = 0; i < N; i++) {
@@ -954,11 +1199,13 @@ extern "C" int mre_osc_configure_env(mre_env* e, const float* gains, const float
 
 extern "C" int mre_gripper_set(mre_env* e, const uint8_t* closed) {
   if (!e || !closed) return fail(MRE_ERR_ARG, "null");
+  DRAIN(e);
   return copy_in(e, e->grip_closed, closed, (size_t)e->N);
 }
 
 extern "C" int mre_get_sites(mre_env* e, float* tcp_pos, float* eef_pose, float* prop_pose) {
   if (!e) return fail(MRE_ERR_ARG, "null handle");
+  DRAIN(e);
   HIPCHK(hipSetDevice(e->device));
   // refresh site poses for the current state (0 physics steps = kinematics only)
   StepArgs a;
@@ -992,16 +1239,19 @@ extern "C" int mre_get_sites(mre_env* e, float* tcp_pos, float* eef_pose, float*
 
 extern "C" int mre_get_status(mre_env* e, uint32_t* status) {
   if (!e || !status) return fail(MRE_ERR_ARG, "null");
+  DRAIN(e);
   return copy_out(e, status, e->status, (size_t)e->N * 4);
 }
 extern "C" int mre_get_solver_stats(mre_env* e, int32_t* stats) {
   if (!e || !stats) return fail(MRE_ERR_ARG, "null");
+  DRAIN(e);
   return copy_out(e, stats, e->stats, (size_t)e->N * 16);
 }
 
 extern "C" int mre_osc_set_target(mre_env* e, const float* pos, const float* quat, const float* vel,
                                   const float* angvel, const uint8_t* mask) {
   if (!e) return fail(MRE_ERR_ARG, "null handle");
+  DRAIN(e);
   // small host-side merge: targets persist per env, NULL keeps the old value
   const size_t N = (size_t)e->N;
   std::vector<float> t(N * 16);
@@ -1045,6 +1295,7 @@ extern "C" int mre_run_controller(mre_env* e, int nticks, int control_steps, uin
     if (const char* c = getenv("MRE_RUN_CHUNK")) { const int v = atoi(c); chunk = v > 0 ? v : nticks; }  // tuning knob
   }
   if (chunk <= 0 || chunk > nticks) chunk = nticks;
+  DRAIN(e);
   if (nticks > 0 && e->converged) HIPCHK(hipMemsetAsync(e->converged, 0, (size_t)e->N, e->stream));
   int t0 = 0;
   do {
@@ -1060,7 +1311,7 @@ extern "C" int mre_run_controller(mre_env* e, int nticks, int control_steps, uin
     if (e->trace) e->trace_pos += a.nsteps;
     t0 += n;
   } while (t0 < nticks);
-  if (converged_out) return copy_out(e, converged_out, e->converged, (size_t)e->N);
+  if (converged_out) { DRAIN(e); return copy_out(e, converged_out, e->converged, (size_t)e->N); }
   return MRE_OK;
 }
 
@@ -1068,6 +1319,7 @@ extern "C" int mre_run_controller(mre_env* e, int nticks, int control_steps, uin
 // (models/robot_arm.py:71-73): tau[N][7] arm torques, grip[N] gripper command (either may be NULL)
 extern "C" int mre_osc_compute(mre_env* e, float* tau, float* grip) {
   if (!e) return fail(MRE_ERR_ARG, "null handle");
+  DRAIN(e);
   StepArgs a;
   fill_args(e, a);
   a.nsteps = 0; a.control_steps = 1; a.mode = CTRL_OSC; a.flags = F_OSC_EVAL; a.trace = nullptr;
@@ -1123,6 +1375,7 @@ static int detect_contacts(mre_env* e, const uint8_t* dmask) {
 
 extern "C" int mre_get_contacts(mre_env* e, int32_t* count, float* contacts) {
   if (!e || !count || !contacts) return fail(MRE_ERR_ARG, "mre_get_contacts: null");
+  DRAIN(e);
   HIPCHK(hipSetDevice(e->device));
   int rc = detect_contacts(e, nullptr);
   if (rc) return rc;
@@ -1154,6 +1407,7 @@ extern "C" int mre_get_contacts(mre_env* e, int32_t* count, float* contacts) {
 extern "C" int mre_place_props(mre_env* e, const uint8_t* mask, uint64_t seed, const float* ws_min,
                                const float* ws_max, int max_attempts, int settle_steps) {
   if (!e || !ws_min || !ws_max || max_attempts < 1) return fail(MRE_ERR_ARG, "mre_place_props: bad argument");
+  DRAIN(e);
   const size_t N = (size_t)e->N;
   std::vector<uint8_t> hm(N, 1);
   int rc;
@@ -1230,6 +1484,7 @@ extern "C" int mre_place_props(mre_env* e, const uint8_t* mask, uint64_t seed, c
 
 extern "C" int mre_get_settle_steps(mre_env* e, int32_t* steps) {
   if (!e || !steps) return fail(MRE_ERR_ARG, "mre_get_settle_steps: null");
+  DRAIN(e);
   if (!e->settle_steps) return fail(MRE_ERR_ARG, "mre_get_settle_steps: no settle has run");
   return copy_out(e, steps, e->settle_steps, (size_t)e->N * 4);
 }
@@ -1244,6 +1499,7 @@ extern "C" int mre_prop_place(mre_env* e, uint64_t seed, const int32_t* prop, co
                               int max_attempts, float max_dist, double* pose, int32_t* attempts) {
   if (!e || !prop || !bounds || !tick || !pose || !attempts || max_attempts < 1)
     return fail(MRE_ERR_ARG, "mre_prop_place: bad argument");
+  DRAIN(e);
   HIPCHK(hipSetDevice(e->device));
   const size_t N = (size_t)e->N;
   int rc = search_buffers(e);
@@ -1274,6 +1530,7 @@ extern "C" int mre_sort_colours(mre_env* e, uint64_t seed, const int32_t* call_c
                                 int32_t* attempts) {
   if (!e || !call_counts || !zones || !which || !pick || !place || !attempts || max_attempts < 1)
     return fail(MRE_ERR_ARG, "mre_sort_colours: bad argument");
+  DRAIN(e);
   HIPCHK(hipSetDevice(e->device));
   const size_t N = (size_t)e->N;
   int rc = search_buffers(e);
@@ -1307,6 +1564,7 @@ extern "C" int mre_sort_colours(mre_env* e, uint64_t seed, const int32_t* call_c
 // ticks >> 10), max constraint rows, max robot rows | max cube-cube contacts << 16}.
 extern "C" int mre_get_launch_info(mre_env* e, int32_t* info) {
   if (!e || !info) return fail(MRE_ERR_ARG, "mre_get_launch_info: null");
+  DRAIN(e);
   HIPCHK(hipSetDevice(e->device));
   HIPCHK(hipStreamSynchronize(e->stream));
   return copy_out(e, info, e->h_launch_info, (size_t)e->N * 16);
@@ -1314,6 +1572,7 @@ extern "C" int mre_get_launch_info(mre_env* e, int32_t* info) {
 
 extern "C" int mre_set_env_ids(mre_env* e, const long long* ids) {
   if (!e) return fail(MRE_ERR_ARG, "null handle");
+  DRAIN(e);
   if (ids) e->env_ids.assign(ids, ids + e->N); else e->env_ids.clear();
   if (e->d_env_ids) { HIPCHK(hipFree(e->d_env_ids)); e->d_env_ids = nullptr; }
   if (ids) {
@@ -1326,6 +1585,7 @@ extern "C" int mre_set_env_ids(mre_env* e, const long long* ids) {
 
 extern "C" int mre_set_env_id_offset(mre_env* e, long long offset) {
   if (!e) return fail(MRE_ERR_ARG, "null handle");
+  DRAIN(e);
   e->env_ids.clear();
   if (e->d_env_ids) { (void)hipFree(e->d_env_ids); e->d_env_ids = nullptr; }
   e->env_id_offset = offset;
@@ -1334,12 +1594,14 @@ extern "C" int mre_set_env_id_offset(mre_env* e, long long offset) {
 
 extern "C" int mre_profile_enable(mre_env* e, int on) {
   if (!e) return fail(MRE_ERR_ARG, "null handle");
+  DRAIN(e);
   e->profiling = on != 0;
   e->events_used = 0;
   return MRE_OK;
 }
 extern "C" int mre_profile_read(mre_env* e, float* total_ms, int* launches) {
   if (!e || !total_ms || !launches) return fail(MRE_ERR_ARG, "null");
+  DRAIN(e);
   HIPCHK(hipStreamSynchronize(e->stream));
   float tot = 0.f;
   for (size_t k = 0; k < e->events_used; k++) {
@@ -1354,6 +1616,7 @@ extern "C" int mre_profile_read(mre_env* e, float* total_ms, int* launches) {
 
 extern "C" int mre_set_env_order(mre_env* e, const int32_t* order) {
   if (!e) return fail(MRE_ERR_ARG, "null handle");
+  DRAIN(e);
   if (!order) { e->use_order = false; return MRE_OK; }
   int rc = copy_in(e, e->order, order, (size_t)e->N * 4);
   if (rc) return rc;

@@ -150,7 +150,8 @@ struct StepArgs {
   float* qvel;            // [N][NVP]
   float* qacc_ws;         // [N][NVP]
   float* ctrl;            // [N][NU]  (held control / last applied control)
-  const float* ctrl_seq;  // [T][N][NU] or null
+  const float* ctrl_seq;  // [T][seq_stride][NU] or null
+  int seq_stride;         // envs per tick of ctrl_seq (the handle's env count; N may be a group of them)
   const int* nprops;      // [N]
   const float* prop_size; // [N][NPROP][3]
   int nsteps, control_steps, mode;

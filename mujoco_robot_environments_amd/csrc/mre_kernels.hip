@@ -999,7 +999,7 @@ MRE_DEV void step_body(const StepArgs& a, Sm& s) {
     // ------------------------------------------------ control at tick boundary
     if (a.mode == CTRL_SEQ && (step % a.control_steps) == 0) {
       const int tick = step / a.control_steps;
-      if (l < NU) s.ctrl[l] = a.ctrl_seq[((size_t)tick * a.N + env) * NU + l];
+      if (l < NU) s.ctrl[l] = a.ctrl_seq[((size_t)tick * a.seq_stride + env) * NU + l];
       MRE_SYNC();
     }
     if (a.mode == CTRL_OSC && (step % a.control_steps) == 0) {
@@ -1379,14 +1379,14 @@ __global__ __launch_bounds__(64) void k_sort_select(SortArgs a) {
 // one pass before a guarded launch (one workgroup per env): copy the env's state rows aside, mark its
 // launch info "not part of this launch", and split the launch between the two kernels -- envs flagged
 // `large` run on the large-capacity kernel
-__global__ __launch_bounds__(64) void k_prepare(const uint8_t* user_mask, const uint8_t* large, int N,
+__global__ __launch_bounds__(64) void k_prepare(const uint8_t* user_mask, const uint8_t* large, int env0, int N,
                                                 uint8_t* mask_compact, uint8_t* mask_large, int* launch_info,
                                                 const float* qpos, float* sv_qpos, const float* qvel, float* sv_qvel,
                                                 const float* qacc_ws, float* sv_qacc_ws, const float* ctrl,
                                                 float* sv_ctrl, const uint32_t* status, uint32_t* sv_status,
                                                 const uint8_t* converged, uint8_t* sv_converged) {
-  const int env = blockIdx.x, l = threadIdx.x;
-  if (env >= N) return;
+  const int env = env0 + blockIdx.x, l = threadIdx.x;   // envs [env0, env0 + N)
+  if ((int)blockIdx.x >= N) return;
   if (l < NQP) sv_qpos[(size_t)env * NQP + l] = qpos[(size_t)env * NQP + l];
   if (l < NVP) {
     sv_qvel[(size_t)env * NVP + l] = qvel[(size_t)env * NVP + l];
@@ -1404,13 +1404,13 @@ __global__ __launch_bounds__(64) void k_prepare(const uint8_t* user_mask, const 
 }
 
 // put the selected envs back to their saved pre-launch state (one workgroup per env)
-__global__ __launch_bounds__(64) void k_restore_rows(const uint8_t* sel, int N, float* qpos, const float* sv_qpos,
+__global__ __launch_bounds__(64) void k_restore_rows(const uint8_t* sel, int env0, int N, float* qpos, const float* sv_qpos,
                                                      float* qvel, const float* sv_qvel, float* qacc_ws,
                                                      const float* sv_qacc_ws, float* ctrl, const float* sv_ctrl,
                                                      uint32_t* status, const uint32_t* sv_status, uint8_t* converged,
                                                      const uint8_t* sv_converged) {
-  const int env = blockIdx.x, l = threadIdx.x;
-  if (env >= N || sel[env] == 0) return;
+  const int env = env0 + blockIdx.x, l = threadIdx.x;
+  if ((int)blockIdx.x >= N || sel[env] == 0) return;
   if (l < NQP) qpos[(size_t)env * NQP + l] = sv_qpos[(size_t)env * NQP + l];
   if (l < NVP) {
     qvel[(size_t)env * NVP + l] = sv_qvel[(size_t)env * NVP + l];
@@ -1422,21 +1422,21 @@ __global__ __launch_bounds__(64) void k_restore_rows(const uint8_t* sel, int N, 
 
 }  // namespace mre
 
-extern "C" void mre_launch_prepare(const uint8_t* user_mask, const uint8_t* large, int N, uint8_t* mask_compact,
+extern "C" void mre_launch_prepare(const uint8_t* user_mask, const uint8_t* large, int env0, int N, uint8_t* mask_compact,
                                    uint8_t* mask_large, int* launch_info, const float* qpos, float* sv_qpos,
                                    const float* qvel, float* sv_qvel, const float* qacc_ws, float* sv_qacc_ws,
                                    const float* ctrl, float* sv_ctrl, const uint32_t* status, uint32_t* sv_status,
                                    const uint8_t* converged, uint8_t* sv_converged, hipStream_t stream) {
-  hipLaunchKernelGGL(mre::k_prepare, dim3(N), dim3(64), 0, stream, user_mask, large, N, mask_compact, mask_large,
+  hipLaunchKernelGGL(mre::k_prepare, dim3(N), dim3(64), 0, stream, user_mask, large, env0, N, mask_compact, mask_large,
                      launch_info, qpos, sv_qpos, qvel, sv_qvel, qacc_ws, sv_qacc_ws, ctrl, sv_ctrl, status, sv_status,
                      converged, sv_converged);
 }
 
-extern "C" void mre_launch_restore_rows(const uint8_t* sel, int N, float* qpos, const float* sv_qpos, float* qvel,
+extern "C" void mre_launch_restore_rows(const uint8_t* sel, int env0, int N, float* qpos, const float* sv_qpos, float* qvel,
                                         const float* sv_qvel, float* qacc_ws, const float* sv_qacc_ws, float* ctrl,
                                         const float* sv_ctrl, uint32_t* status, const uint32_t* sv_status,
                                         uint8_t* converged, const uint8_t* sv_converged, hipStream_t stream) {
-  hipLaunchKernelGGL(mre::k_restore_rows, dim3(N), dim3(64), 0, stream, sel, N, qpos, sv_qpos, qvel, sv_qvel,
+  hipLaunchKernelGGL(mre::k_restore_rows, dim3(N), dim3(64), 0, stream, sel, env0, N, qpos, sv_qpos, qvel, sv_qvel,
                      qacc_ws, sv_qacc_ws, ctrl, sv_ctrl, status, sv_status, converged, sv_converged);
 }
 

@@ -232,6 +232,49 @@ def test_fallback_reproduces_the_large_kernel_bit_for_bit(compiled_model, solver
     assert np.array_equal(out[1][2], out[2][2])
 
 
+@pytest.mark.parametrize("solver", ["PGS", "Newton"])
+def test_pipelined_env_groups_equal_the_synchronous_path(compiled_model, solver, monkeypatch):
+    """The stepping calls cut the batch into env groups on separate streams and return before the launches have
+    finished; a group's launch info is read -- and an overflowing env re-run from its saved rows -- only when the
+    group's next launch is issued or the state is touched.  Same grasp-on-the-table scenario as above (promotions
+    and re-runs mid-phase), then 30 ticks of per-tick control sequences, one call per tick without a sync in
+    between: state, status and fallback counters must equal the single-group (synchronous) handle bit for bit."""
+    import torch
+    import bench
+    from mujoco_robot_environments_amd import demo_logic, rng
+    A, _ = compiled_model
+    N = 64
+    out = {}
+    for groups in (1, 3):
+        monkeypatch.setenv("MRE_GROUPS", str(groups))
+        monkeypatch.setenv("MRE_GROUP_MIN", "1")
+        phys = _phys(N, A)
+        phys.set_solver(solver)
+        bench.setup_envs(phys, 7, np.arange(N))
+        cube = phys.qpos()[:, 15:22].astype(np.float64)
+        yaw = np.abs(demo_logic.quat_to_yaw_deg(cube[:, 3:7]))
+        quat = demo_logic.grasp_quat(np.minimum(yaw, yaw - 90.0))
+        pick = np.concatenate([cube[:, :2], np.full((N, 1), 0.565)], axis=1)
+        pre = pick.copy(); pre[:, 2] = 0.9
+        phys.osc_set_target(position=pre, quat=quat, velocity=np.zeros(3), angular_velocity=np.zeros(3))
+        phys.gripper_set(np.zeros(N, np.uint8))
+        phys.run_controller(400, 5)
+        phys.osc_set_target(position=pick)
+        phys.run_controller(400, 5)
+        phys.gripper_set(np.ones(N, np.uint8))
+        phys.run_controller(200, 5)
+        seq = torch.from_numpy(rng.random_actions(3, np.arange(N), np.arange(30), scale=0.3).astype(np.float32)).to(phys.device)
+        for t in range(30):
+            phys.rollout(seq[t:t + 1].contiguous(), control_steps=5)   # no sync between the calls
+        out[groups] = (phys.qpos().copy(), phys.qvel().copy(), phys.status().copy(), phys.get_warmstart().copy(),
+                       phys.fallback_stats(), phys.solver_stats().copy())
+        phys.close()
+    assert out[1][4]["promotions"] > 0 and out[1][4]["reruns"] > 0, out[1][4]
+    assert out[1][4] == out[3][4], (out[1][4], out[3][4])
+    for k in (0, 1, 2, 3, 5):
+        assert np.array_equal(out[1][k], out[3][k]), k
+
+
 def test_run_controller_in_chunks_equals_one_launch(compiled_model, monkeypatch):
     """mre_run_controller cuts a phase into launches of 50 ticks (so that a capacity re-run repeats at
     most one chunk).  State, converged flags and status must be bit-identical to a single launch,
