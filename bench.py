@@ -64,12 +64,15 @@ def pmc_summary(solver="PGS"):
         return json.load(f), os.path.basename(files[-1])
 
 
-def pmc_traffic(solver="PGS"):
+def pmc_traffic(solver="PGS", envs_per_launch=None):
     d, name = pmc_summary(solver)
-    return d.get("traffic_bytes_per_launch"), name
+    t = d.get("traffic_bytes_per_launch")
+    if t is not None and envs_per_launch:
+        t *= envs_per_launch / float(d.get("envs_per_launch", ENVS_PER_GPU))
+    return t, name
 
 
-def valu_issue(avg_launch_s, solver="PGS"):
+def valu_issue(avg_launch_s, solver="PGS", envs_per_launch=ENVS_PER_GPU):
     """What actually bounds the kernel: VALU issue slots.  A wave64 VALU instruction occupies its
     SIMD for 4 cycles (16 lanes per SIMD), so  util = SQ_INSTS_VALU * 4 / (SIMDs * clock * time).
     ``avg_launch_s``: wall time per launch (tick time / launches per tick): launches of different env groups
@@ -78,11 +81,14 @@ def valu_issue(avg_launch_s, solver="PGS"):
     n = d.get("SQ_INSTS_VALU_per_launch")
     if not n or avg_launch_s <= 0:
         return None
+    scale = envs_per_launch / float(d.get("envs_per_launch", ENVS_PER_GPU))   # counters were taken on launches of that many envs
+    n *= scale
     simds, clock = 256 * 4, 2.4e9  # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, 2.4 GHz peak engine clock
     out = {"valu_insts_per_launch": n, "cycles_per_wave64_inst": 4, "simds": simds, "clock_hz": clock,
            "util": n * 4.0 / (simds * clock * avg_launch_s), "source": name}
     fl = d.get("counted_flop_f32_per_launch")
     if fl:
+        fl *= scale
         # counted FLOPs (SQ_INSTS_VALU_{ADD,MUL,TRANS,FMA}_F32 x 64 lanes, FMA = 2) against the FP32 vector peak
         # of MI355X_MICROARCH.md (157.3 TFLOP/s); idle lanes of a wave count as work, so this is an upper bound
         out["counted_flop"] = {"f32_per_launch": fl, "f64_per_launch": d.get("counted_flop_f64_per_launch"),
@@ -336,19 +342,28 @@ def main():
         # the GPU, csrc/mre_api.cpp launch_step): one tick = `per_tick` launches of N / per_tick envs each
         per_tick = max(1, round(launches / max(K // F, 1)))
         bytes_per_launch = bytes_per_tick / per_tick
-        achieved = bytes_per_launch / avg_launch_s / 1e9
-        wall_per_launch_s = elapsed / max(K // F, 1) / per_tick   # overlapping launches: use wall time for utilisation
+        wall_per_launch_s = elapsed / max(K // F, 1) / per_tick
+        # the group launches of a tick (and of consecutive ticks) overlap on the GPU, so their individual durations
+        # are not additive: the bandwidth the path achieves is the tick's algorithmic bytes over the tick's wall time
+        # (= bytes per launch over wall time per launch); the per-launch form is kept beside it
+        achieved = bytes_per_launch / wall_per_launch_s / 1e9
+        achieved_per_launch = bytes_per_launch / avg_launch_s / 1e9
         kname = "mre::k_step" if solver == "PGS" else "mre::k_step_newton"
         return {
             "solver": solver, "value": total_env_steps / elapsed, "ms_per_step": elapsed / K * 1e3, "gather_ms": gather_ms,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic(solver)[0] if pmc else None, "traffic_source": pmc_traffic(solver)[1],
+                         "traffic": pmc_traffic(solver, n_local // per_tick)[0] if pmc else None, "traffic_source": pmc_traffic(solver)[1],
                          "kernel": kname, "avg_launch_ms": avg_launch_s * 1e3, "launches": launches,
                          "launches_per_tick": per_tick, "envs_per_launch": n_local // per_tick,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "achieved_over_wall_time": bytes_per_tick / (elapsed / max(K // F, 1)) / 1e9,
-                         "valu_issue": valu_issue(wall_per_launch_s, solver) if pmc else None,
+                         "wall_ms_per_launch": wall_per_launch_s * 1e3,
+                         "achieved_per_overlapping_launch": achieved_per_launch,
+                         "valu_issue": valu_issue(wall_per_launch_s, solver, n_local // per_tick) if pmc else None,
+                         "launch_note": "a tick is stepped as `launches_per_tick` env-group launches on prioritised streams that "
+                                        "overlap each other and the next tick's (csrc/mre_api.cpp launch_step): avg_launch_ms is one "
+                                        "group launch's own duration (HIP events; rocprofv3 --stats agrees), wall_ms_per_launch the "
+                                        "tick's wall time divided by the launches per tick; achieved / frac use the wall time",
                          "note": ("HBM is not the bound: per-env state stays in LDS across the 5 fused steps. PGS: VALU "
                                   "issue (see valu_issue; the 100 sweeps are 87 % of a tick, profiles/*_phase_stamps_pgs.log)" if solver == "PGS" else
                                   "HBM is not the bound: per-env state stays in LDS across the 5 fused steps. Newton: "

@@ -3,6 +3,7 @@
 // converts the model blob into the fp32 DevModel the kernels read, and
 // enqueues kernels.  No torch types; plain pointers and sizes only.
 #include <hip/hip_runtime.h>
+#include <chrono>
 
 #include <cmath>
 #include <cstdio>
@@ -130,6 +131,7 @@ struct mre_env {
   float* seq_copy[2] = {nullptr, nullptr};  // own copies of the last two ctrl_seq arguments (re-runs read them later)
   size_t seq_cap = 0;
   unsigned seq_calls = 0;
+  double dbg_wait_s = 0, dbg_call_s = 0; long dbg_calls = 0;   // MRE_DEBUG_TIMING
 };
 
 // solver-specific instantiations of the step kernel (opt_solver of the model, mre_set_solver)
@@ -172,7 +174,11 @@ static int profile_events(mre_env* e, hipEvent_t* e0, hipEvent_t* e1) {
 // dispatch order of the group's next launch, re-run of the envs that overflowed the compact kernel.
 static int finish_group(mre_env* e, mre_env::Group& G) {
   if (!G.pending) return MRE_OK;
-  HIPCHK(hipEventSynchronize(G.ev_info));
+  {
+    const auto w0 = std::chrono::steady_clock::now();
+    HIPCHK(hipEventSynchronize(G.ev_info));
+    e->dbg_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
+  }
   G.pending = false;
   int nrerun = 0;
   bool changed = false;
@@ -286,6 +292,8 @@ static int launch_step(mre_env* e, const StepArgs& a, bool settle = false) {
                            a.trace == nullptr && a.contacts == nullptr && a.settle_steps == nullptr && a.geoms == nullptr &&
                            (a.flags & (F_DETECT | F_SETTLE_EXIT | F_OSC_EVAL)) == 0;
     if (pipelined) {
+      struct Timer { mre_env* e; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+                     ~Timer() { e->dbg_call_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); e->dbg_calls++; } } timer_{e};
       HIPCHK(hipEventRecord(e->ev_main, e->stream));
       // serve the groups in the order their previous launches complete
       const size_t ng = e->groups.size();
@@ -748,6 +756,9 @@ extern "C" int mre_destroy(mre_env* e) {
   if (!e) return MRE_OK;
   (void)hipSetDevice(e->device);
   (void)drain(e);
+  if (getenv("MRE_DEBUG_TIMING") && e->dbg_calls > 0)
+    fprintf(stderr, "mre: %ld pipelined calls, %.1f us per call in the library, of which %.1f us waiting for launch info\n",
+            e->dbg_calls, 1e6 * e->dbg_call_s / e->dbg_calls, 1e6 * e->dbg_wait_s / e->dbg_calls);
   for (auto& G : e->groups) {
     if (G.st) { (void)hipStreamSynchronize(G.st); (void)hipStreamDestroy(G.st); }
     if (G.st2) { (void)hipStreamSynchronize(G.st2); (void)hipStreamDestroy(G.st2); }

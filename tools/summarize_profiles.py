@@ -19,7 +19,8 @@ from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNELS = {"PGS": "mre::k_step(", "Newton": "mre::k_step_newton("}
 KERNEL = KERNELS["PGS"]
-WARMUP = 20  # bench.py default --warmup
+GROUPS = int(os.environ.get("MRE_GROUPS", "4"))   # env groups per tick (csrc/mre_api.cpp: one launch per group)
+WARMUP = 20 * GROUPS  # bench.py default --warmup ticks
 
 
 def one(pattern):
@@ -49,9 +50,11 @@ def main():
     shutil.copy(one(os.path.join(stats_d, "**", "*kernel_stats.csv")), os.path.join(out, f"{tag}_kernel_stats{sfx}.csv"))
     summary = {
         "command": f"rocprofv3 --pmc <COUNTERS> --kernel-trace --output-format csv -- python bench.py --solver {solver} "
-                   "--no-cpu-baseline (20 warm-up launches dropped, 200 timed launches averaged; separate passes: FETCH_SIZE | WRITE_SIZE | SQ_* | "
+                   f"--no-cpu-baseline ({WARMUP} warm-up launches dropped, {200 * GROUPS} timed launches averaged; separate passes: FETCH_SIZE | WRITE_SIZE | SQ_* | "
                    "SQ_INSTS_VALU_*_F32/F64)",
-        "kernel": KERNEL.rstrip("("), "launch": "1 control tick = 5 physics steps x 4096 envs", "build": note}
+        "kernel": KERNEL.rstrip("("), "launch": f"1 env group of 1 control tick = 5 physics steps x {4096 // GROUPS} envs ({GROUPS} launches per tick; "
+                   "the counter passes serialise the dispatches, so launch durations in these passes are those of one group alone on the GPU)",
+        "envs_per_launch": 4096 // GROUPS, "build": note}
     passes = [("fetch", fetch_d), ("write", write_d), ("sq", sq_d)]
     if flop_d != "-":
         passes.append(("flop", flop_d))
