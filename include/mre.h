@@ -22,6 +22,11 @@
  *     row with a single coalesced access).  fp32 on device.
  *   - one handle <-> one host thread / HIP stream; calls are asynchronous on
  *     that stream, mre_sync() / mre_get_* synchronise.
+ *   - the stepping calls (mre_step, mre_rollout, mre_run_controller) cut the batch into env groups on
+ *     streams of their own and return before the launches have finished; every other entry point
+ *     first completes what is pending.  Results do not depend on the grouping (MRE_GROUPS=1 in the
+ *     environment: a stepping call completes before it returns).  ctrl_seq of mre_rollout is copied
+ *     at the call; it need not outlive it.
  */
 #ifndef MRE_H
 #define MRE_H
