@@ -132,6 +132,10 @@ struct mre_env {
   size_t seq_cap = 0;
   unsigned seq_calls = 0;
   double dbg_wait_s = 0, dbg_call_s = 0; long dbg_calls = 0;   // MRE_DEBUG_TIMING
+  // a caller that reads or writes the state after EVERY stepping call (a per-tick loop with host-side targets)
+  // gains nothing from the groups and pays their launches: after two such calls in a row the stepping calls
+  // go back to one launch of the whole batch, until two stepping calls arrive back to back again
+  int calls_since_drain = 0, sync_streak = 0;
 };
 
 // solver-specific instantiations of the step kernel (opt_solver of the model, mre_set_solver)
@@ -232,7 +236,12 @@ static int finish_group(mre_env* e, mre_env::Group& G) {
 }
 
 // Complete every pending group launch: every entry point that reads or writes device state starts here.
-static int drain(mre_env* e) {
+static int drain(mre_env* e, bool api_call = false) {
+  if (api_call) {
+    if (e->calls_since_drain == 1) e->sync_streak++;
+    else if (e->calls_since_drain > 1) e->sync_streak = 0;
+    e->calls_since_drain = 0;
+  }
   bool any = false;
   for (auto& G : e->groups) any = any || G.pending;
   if (!any) return MRE_OK;
@@ -244,7 +253,8 @@ static int drain(mre_env* e) {
   }
   return MRE_OK;
 }
-#define DRAIN(e) do { int rc_ = drain(e); if (rc_) return rc_; } while (0)
+#define DRAIN(e) do { int rc_ = drain(e, true); if (rc_) return rc_; } while (0)
+#define DRAIN_PENDING(e) do { int rc_ = drain(e, false); if (rc_) return rc_; } while (0)
 
 // One group's part of a stepping call: finish its previous launch, enqueue the new one, do not wait.
 static int launch_group(mre_env* e, mre_env::Group& G, const StepArgs& a_full) {
@@ -284,11 +294,12 @@ static int launch_group(mre_env* e, mre_env::Group& G, const StepArgs& a_full) {
   return MRE_OK;
 }
 
-static int launch_step(mre_env* e, const StepArgs& a, bool settle = false) {
+static int launch_step(mre_env* e, const StepArgs& a, bool settle = false, bool pipeline_ok = true) {
   HIPCHK(hipSetDevice(e->device));  // the HIP current device is per thread; callers may have moved it
   {
     const bool guarded_ = e->fallback && a.nsteps > 0 && (a.flags & F_NO_CONSTRAINTS) == 0;
-    const bool pipelined = e->groups.size() > 1 && guarded_ && !settle && a.env_mask == nullptr && !e->use_order &&
+    if (++e->calls_since_drain >= 2) e->sync_streak = 0;
+    const bool pipelined = pipeline_ok && e->sync_streak < 2 && e->groups.size() > 1 && guarded_ && !settle && a.env_mask == nullptr && !e->use_order &&
                            a.trace == nullptr && a.contacts == nullptr && a.settle_steps == nullptr && a.geoms == nullptr &&
                            (a.flags & (F_DETECT | F_SETTLE_EXIT | F_OSC_EVAL)) == 0;
     if (pipelined) {
@@ -312,7 +323,7 @@ static int launch_step(mre_env* e, const StepArgs& a, bool settle = false) {
       }
       return MRE_OK;
     }
-    DRAIN(e);
+    DRAIN_PENDING(e);
   }
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (e->profiling) {
@@ -1139,7 +1150,7 @@ extern "C" int mre_rollout(mre_env* e, const float* ctrl_seq, int nticks, int co
     // from the handle's own copy (two buffers: the copy of call k is needed until call k + 1 has been issued)
     const size_t n = (size_t)nticks * (size_t)e->N * NU;
     if (n > e->seq_cap) {
-      DRAIN(e);
+      DRAIN_PENDING(e);
       for (float*& p : e->seq_copy) { if (p) HIPCHK(hipFree(p)); p = nullptr; HIPCHK(hipMalloc(&p, n * 4)); }
       e->seq_cap = n;
     }
@@ -1317,7 +1328,9 @@ extern "C" int mre_run_controller(mre_env* e, int nticks, int control_steps, uin
     a.converged = e->converged;
     if (t0 > 0) a.flags |= F_CONV_CONTINUE;
     if (t0 + n < nticks) a.flags |= F_CONV_OPEN;
-    int rc = launch_step(e, a);
+    // (a call that is one launch and hands the converged flags back completes before it returns anyway: one
+    // launch of the whole batch then costs less than one per env group)
+    int rc = launch_step(e, a, false, /*pipeline_ok=*/!(converged_out != nullptr && chunk >= nticks));
     if (rc) return rc;
     if (e->trace) e->trace_pos += a.nsteps;
     t0 += n;
