@@ -826,8 +826,17 @@ MRE_PHASE_FN void solve_constraints(ModelP M, Sm& s, int l) {
     o.b1r = *reinterpret_cast<const float*>(jp + lstr + broff);
     o.b2r = *reinterpret_cast<const float*>(jp + 2u * lstr + broff);
     // the block's uniform operands: one 64-byte record, four 16-byte LDS reads
-    const float4* rec = reinterpret_cast<const float4*>(sb + (ent.x >> 16));
-    o.q0 = rec[0]; o.q1 = rec[1]; o.q2 = rec[2]; o.q3 = rec[3];
+    // (explicit LDS address space: the generic pointer hides the record's 16-byte alignment from the compiler,
+    //  which then splits each 16-byte read in two)
+    typedef float rec4 __attribute__((ext_vector_type(4)));
+#if defined(__HIP_DEVICE_COMPILE__)
+    const __attribute__((address_space(3))) rec4* rec = (const __attribute__((address_space(3))) rec4*)(sb + (ent.x >> 16));
+#else
+    const rec4* rec = reinterpret_cast<const rec4*>(sb + (ent.x >> 16));
+#endif
+    const rec4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
+    o.q0 = make_float4(r0.x, r0.y, r0.z, r0.w); o.q1 = make_float4(r1.x, r1.y, r1.z, r1.w);
+    o.q2 = make_float4(r2.x, r2.y, r2.z, r2.w); o.q3 = make_float4(r3.x, r3.y, r3.z, r3.w);
     return o;
   };
   int st = 0, iter = 0;
