@@ -670,7 +670,7 @@ static int create_buffers(mre_env* e, int num_envs, int device_id) {
   e->h_large.assign(N, 0); e->h_rerun.assign(N, 0);
   {
     // env groups of the pipelined stepping path (MRE_GROUPS = 1: every call completes before it returns)
-    int ng = 4, min_envs = 128;   // (measured on the bench: 2, 3 and 4 groups are within 1 % for Newton, 4 best for PGS)
+    int ng = 4, min_envs = 512;   // (measured on the bench: 2, 3 and 4 groups are within 1 % for Newton, 4 best for PGS)
     if (const char* g = getenv("MRE_GROUPS")) ng = atoi(g);
     if (const char* g = getenv("MRE_GROUP_MIN")) min_envs = atoi(g);   // test knob: smallest group worth a launch of its own
     if (ng < 1) ng = 1;
