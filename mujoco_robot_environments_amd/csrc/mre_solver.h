@@ -750,7 +750,8 @@ MRE_PHASE_FN void solve_constraints(ModelP M, Sm& s, int l) {
   for (int p = 0; p < s.nprops; p++)
     msum += 3.f * s.prop_mass[p] + s.prop_inertia[p][0] + s.prop_inertia[p][1] + s.prop_inertia[p][2];
   const float scale = 1.0f / ((msum / nva) * nva);
-  const int nsched = s.nsched, max_iter = M->iterations, nscalar = 7 + nl;
+  // (wave-uniform by construction; said so, the step counters of the sweep live in scalar registers)
+  const int nsched = __builtin_amdgcn_readfirstlane(s.nsched), max_iter = M->iterations, nscalar = 7 + nl;
   const float tol = M->tolerance;
   // Operand table: the schedule's descriptor words expanded once per solve into LDS byte offsets,
   // so that a sweep step costs one 8-byte read per lane instead of a decode.  It lives in the
