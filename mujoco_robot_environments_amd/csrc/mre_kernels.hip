@@ -182,33 +182,75 @@ MRE_DEV void hinge_body(const Frame& F, const float* bpos, const float* bquat, c
   q2mat(out.m, out.q);
 }
 
-// The tree is walked in registers, not level by level through LDS: the arm is a chain (body k hangs off body
-// k - 1, one hinge each: mre_create checks the dof tree against ROBOT_DOF_PARENT), so every lane computes links
-// 1..7 itself -- the same values in all lanes, model constants at compile-time indices -- and keeps the frame of
-// the link it owns; a finger body sits one or two hinges below link 7 and its lane adds those; a cube's frame is
-// its free joint's qpos.  Same operations per body as the level-by-level form it replaces (same bits), without
-// its nine LDS round trips and ordering points.
+// The arm is a chain (body k hangs off body k - 1, one hinge each: mre_create checks the dof tree against
+// ROBOT_DOF_PARENT).  Lane k computes link k's pose in its PARENT's frame (one hinge), and the world poses are the
+// inclusive prefix products of those rigid transforms, (q, p) o (q', p') = (q q', p + R(q) p'), taken over lanes
+// 1..7 in three DPP steps -- instead of seven dependent hinges evaluated by every lane.  A finger body sits one or
+// two hinges below link 7 (whose frame its lane reads from lane 7); a cube's frame is its free joint's qpos.
+// Rounding differs from the link-by-link product in the last bits (quaternions are normalised at the end, as
+// mj_kinematics normalises after every joint).
 // writeback: store the normalised free-joint quaternions in qpos (mj_kinematics does); the
 // query-only pass at the end of a launch must leave the state bits alone
+MRE_DEV float dpp_shr(float v, float fill, int sh) {
+  // value of lane l - sh within the row of 16 (fill where there is none)
+  int r;
+  const int vi = __builtin_bit_cast(int, v), fi = __builtin_bit_cast(int, fill);
+  if (sh == 1) r = __builtin_amdgcn_update_dpp(fi, vi, 0x111, 0xF, 0xF, false);
+  else if (sh == 2) r = __builtin_amdgcn_update_dpp(fi, vi, 0x112, 0xF, 0xF, false);
+  else r = __builtin_amdgcn_update_dpp(fi, vi, 0x114, 0xF, 0xF, false);
+  return __builtin_bit_cast(float, r);
+}
 template <bool WRITEBACK>
 MRE_DEV void kinematics(ModelP M, Sm& s, int l, BodyRegs& br) {
   constexpr int LINK7 = GRIP_BODY0 - 1;
-  Frame F;   // running parent frame, starts as the world
-  v3zero(F.p);
-  F.q[0] = 1.f; F.q[1] = F.q[2] = F.q[3] = 0.f;
-#pragma unroll
-  for (int k = 0; k < 9; k++) F.m[k] = (k % 4 == 0) ? 1.f : 0.f;
-  Frame mine = F;
-  v3zero(br.anchor); v3zero(br.axis);
-#pragma unroll
-  for (int k = 1; k <= LINK7; k++) {
-    Frame G;
-    float an[3], ax[3];
-    hinge_body(F, M->body_pos[k], M->body_quat[k], M->jnt_pos[k], M->jnt_axis[k], s.qpos[k - 1] - M->qpos0[k - 1],
-               G, an, ax);
-    if (l == k) { mine = G; v3copy(br.anchor, an); v3copy(br.axis, ax); }
-    F = G;
+  // ---- link k in its parent's frame (lanes 1..7; identity elsewhere)
+  float q[4] = {1.f, 0.f, 0.f, 0.f}, p[3] = {0.f, 0.f, 0.f};
+  const bool arm = l >= 1 && l <= LINK7;
+  if (arm) {
+    float ql[4], t0[3], t1[3];
+    const float* bq = M->body_quat[l];
+    const float bq4[4] = {bq[0], bq[1], bq[2], bq[3]};
+    const float ax[3] = {M->jnt_axis[l][0], M->jnt_axis[l][1], M->jnt_axis[l][2]};
+    const float jp[3] = {M->jnt_pos[l][0], M->jnt_pos[l][1], M->jnt_pos[l][2]};
+    axisangle2q(ql, ax, s.qpos[l - 1] - M->qpos0[l - 1]);
+    qmul(q, bq4, ql);
+    qrotv(t0, bq4, jp);
+    qrotv(t1, q, jp);
+    for (int c = 0; c < 3; c++) p[c] = M->body_pos[l][c] + t0[c] - t1[c];
   }
+  // ---- inclusive prefix product over lanes 1..7 (shifts 1, 2, 4 inside the DPP row; lane 0 is the identity)
+#pragma unroll
+  for (int sh = 1; sh <= 4; sh *= 2) {
+    float aq[4], ap[3], nq[4], t[3];
+    aq[0] = dpp_shr(q[0], 1.f, sh);
+    for (int c = 1; c < 4; c++) aq[c] = dpp_shr(q[c], 0.f, sh);
+    for (int c = 0; c < 3; c++) ap[c] = dpp_shr(p[c], 0.f, sh);
+    qmul(nq, aq, q);
+    qrotv(t, aq, p);
+    for (int c = 0; c < 4; c++) q[c] = nq[c];
+    for (int c = 0; c < 3; c++) p[c] = ap[c] + t[c];
+  }
+  Frame mine;
+  qnormalize(q);
+  for (int c = 0; c < 4; c++) mine.q[c] = q[c];
+  v3copy(mine.p, p);
+  q2mat(mine.m, mine.q);
+  v3zero(br.anchor); v3zero(br.axis);
+  if (arm) {
+    float t[3];
+    const float jp[3] = {M->jnt_pos[l][0], M->jnt_pos[l][1], M->jnt_pos[l][2]};
+    const float ax[3] = {M->jnt_axis[l][0], M->jnt_axis[l][1], M->jnt_axis[l][2]};
+    qrotv(t, mine.q, jp);
+    v3add(br.anchor, mine.p, t);      // the joint anchor is fixed in the body: x + R jnt_pos
+    qrotv(br.axis, mine.q, ax);       // a rotation about the axis leaves the axis where it was
+  }
+  // frame of the arm's last link, for the finger lanes
+  Frame F;
+  for (int c = 0; c < 3; c++)
+    F.p[c] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.p[c]), LINK7));
+  for (int c = 0; c < 4; c++)
+    F.q[c] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.q[c]), LINK7));
+  q2mat(F.m, F.q);
   const int b = l < NB ? l : 0;
   if (l >= GRIP_BODY0 && l < NRB) {
     const int par = M->body_parent[b];
