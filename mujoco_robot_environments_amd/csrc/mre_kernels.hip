@@ -724,91 +724,144 @@ MRE_DEV void solve_robot_one(const float* LD, const float* dinv, float* xv, int 
 namespace mre {
 
 // ------------------------------------------------ mj_comVel + mj_rne + mj_passive
-MRE_PHASE_FN void velocity_stage(ModelP M, Sm& s, int l) {
-  // cvel, cdof_dot (lane = body; each lane re-accumulates its chain prefix)
-  float cv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  if (l >= 1 && l < NB) {
-    const int b = l;
-    if (M->body_propid[b] < 0) {
-      const int n = M->chain_len[b];
-      for (int k = 0; k < n; k++) {
-        const int j = M->chain_dof[b][k];
-        if (k == n - 1) cross_motion(s.cdof_dot[j], cv, s.cdof[j]);
-        const float qv = s.qvel[j];
+// Sums along the robot's body tree with lane = body (lanes 0..15 of the first DPP row; lane 0 = the world, which
+// contributes nothing).  The tree is the one the kernels are unrolled for (ROBOT_DOF_PARENT, checked in mre_create):
+// the arm is the chain 1..7, and below link 7 hang four two-body fingers (8 -> 9, 10 -> 11, 12 -> 13, 14 -> 15).
+//   tree_prefix: x_b <- sum of x over b and its ancestors     (mj_comVel's accumulation down the tree)
+//   tree_suffix: x_b <- sum of x over b and its descendants   (mj_rne's / mj_crb's accumulation up the tree)
+// Row shifts instead of one loop per lane over its chain / its descendants; the order of the additions differs from
+// the loops' (last-bit rounding).
+template <int CTRL>
+MRE_DEV float dpp_row(float v) {  // lane's source by the row shift CTRL, 0 where the row has no such lane
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+template <int N>
+MRE_DEV void tree_prefix(float (&x)[N], int l) {
+  constexpr int LINK7 = GRIP_BODY0 - 1;
+  float own[N], par[N];
 #pragma unroll
-        for (int t = 0; t < 6; t++) cv[t] += s.cdof[j][t] * qv;
-      }
-    } else {
-      const int da = M->body_dofadr[b];
+  for (int c = 0; c < N; c++) { own[c] = x[c]; par[c] = dpp_row<0x111>(x[c]); }
 #pragma unroll
-      for (int j = 0; j < 3; j++) {
-        for (int t = 0; t < 6; t++) s.cdof_dot[da + j][t] = 0.f;
-        cv[3 + j] += s.qvel[da + j];
-      }
+  for (int c = 0; c < N; c++) x[c] += dpp_row<0x111>(x[c]);
 #pragma unroll
-      for (int j = 3; j < 6; j++) {
-        float cd[6];
-        prop_cdof(s, b, j, cd);
-        cross_motion(s.cdof_dot[da + j], cv, cd);
-      }
+  for (int c = 0; c < N; c++) x[c] += dpp_row<0x112>(x[c]);
 #pragma unroll
-      for (int j = 3; j < 6; j++) {
-        float cd[6];
-        prop_cdof(s, b, j, cd);
-        const float qv = s.qvel[da + j];
-        for (int t = 0; t < 3; t++) cv[t] += cd[t] * qv;
-      }
-    }
+  for (int c = 0; c < N; c++) x[c] += dpp_row<0x114>(x[c]);
+  const bool finger = l >= GRIP_BODY0 && l < NRB, leaf = (l & 1) != 0;   // (bodies 9, 11, 13, 15 hang off 8, 10, 12, 14)
 #pragma unroll
-    for (int t = 0; t < 6; t++) s.cvel[b][t] = cv[t];
+  for (int c = 0; c < N; c++) {
+    const float p7 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x[c]), LINK7));
+    x[c] = finger ? (p7 + (leaf ? par[c] : 0.f)) + own[c] : x[c];
   }
-  MRE_SYNC();
-  // cacc, cfrc_body (lane = body)
+}
+template <int N>
+MRE_DEV void tree_suffix(float (&x)[N], int l) {
+  float own[N], nxt[N];
+#pragma unroll
+  for (int c = 0; c < N; c++) { own[c] = x[c]; nxt[c] = dpp_row<0x101>(x[c]); }
+#pragma unroll
+  for (int c = 0; c < N; c++) x[c] += dpp_row<0x101>(x[c]);
+#pragma unroll
+  for (int c = 0; c < N; c++) x[c] += dpp_row<0x102>(x[c]);
+#pragma unroll
+  for (int c = 0; c < N; c++) x[c] += dpp_row<0x104>(x[c]);
+#pragma unroll
+  for (int c = 0; c < N; c++) x[c] += dpp_row<0x108>(x[c]);
+  const bool finger = l >= GRIP_BODY0 && l < NRB, leaf = (l & 1) != 0;
+#pragma unroll
+  for (int c = 0; c < N; c++) x[c] = finger ? (leaf ? own[c] : own[c] + nxt[c]) : x[c];
+}
+
+MRE_PHASE_FN void velocity_stage(ModelP M, Sm& s, int l) {
+  constexpr int LINK7 = GRIP_BODY0 - 1;
+  const bool rob = l >= 1 && l < NRB;   // lane = robot body l, whose hinge is dof l - 1
+  // ---- robot: cvel, cdof_dot, cacc in registers (mj_comVel, mj_rne forward pass)
+  float cd[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, qv = 0.f;
+  if (rob) {
+#pragma unroll
+    for (int t = 0; t < 6; t++) cd[t] = s.cdof[l - 1][t];
+    qv = s.qvel[l - 1];
+  }
+  float cv[6];
+#pragma unroll
+  for (int t = 0; t < 6; t++) cv[t] = cd[t] * qv;
+  tree_prefix(cv, l);
+  // the parent's velocity: the lane below, except for the bodies that hang off link 7
+  float pv[6];
+  {
+    const bool off7 = l >= GRIP_BODY0 && l < NRB && (l & 1) == 0;
+#pragma unroll
+    for (int t = 0; t < 6; t++) {
+      const float below = dpp_row<0x111>(cv[t]);
+      const float v7 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cv[t]), LINK7));
+      pv[t] = off7 ? v7 : below;
+    }
+  }
+  float cdd[6], ca[6];
+  cross_motion(cdd, pv, cd);
+#pragma unroll
+  for (int t = 0; t < 6; t++) ca[t] = cdd[t] * qv;
+  tree_prefix(ca, l);
+  // ---- cubes: free joints (lane = body)
+  if (l >= NRB && l < NB) {
+    const int b = l;
+#pragma unroll
+    for (int t = 0; t < 6; t++) { cv[t] = 0.f; ca[t] = 0.f; }
+    const int da = M->body_dofadr[b];
+#pragma unroll
+    for (int j = 0; j < 3; j++) cv[3 + j] += s.qvel[da + j];
+    float cdot[3][6];
+#pragma unroll
+    for (int j = 3; j < 6; j++) {
+      float c6[6];
+      prop_cdof(s, b, j, c6);
+      cross_motion(cdot[j - 3], cv, c6);
+    }
+#pragma unroll
+    for (int j = 3; j < 6; j++) {
+      float c6[6];
+      prop_cdof(s, b, j, c6);
+      const float q = s.qvel[da + j];
+      for (int t = 0; t < 3; t++) cv[t] += c6[t] * q;
+      for (int t = 0; t < 6; t++) ca[t] += cdot[j - 3][t] * q;
+    }
+  }
+  // ---- cacc, cfrc_body (lane = body)
+  float f[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (l >= 1 && l < NB) {
     const int b = l;
-    float ca[6] = {0.f, 0.f, 0.f, -M->gravity[0], -M->gravity[1], -M->gravity[2]};
-    if (M->body_propid[b] < 0) {
-      const int n = M->chain_len[b];
-      for (int k = 0; k < n; k++) {
-        const int j = M->chain_dof[b][k];
-        const float qv = s.qvel[j];
-#pragma unroll
-        for (int t = 0; t < 6; t++) ca[t] += s.cdof_dot[j][t] * qv;
-      }
-    } else {
-      const int da = M->body_dofadr[b];
-      for (int j = 3; j < 6; j++) {
-        const float qv = s.qvel[da + j];
-        for (int t = 0; t < 6; t++) ca[t] += s.cdof_dot[da + j][t] * qv;
-      }
-    }
-    float t0[6], t1[6], f[6];
+    ca[3] -= M->gravity[0]; ca[4] -= M->gravity[1]; ca[5] -= M->gravity[2];
+    float t0[6], t1[6], g[6];
     mul_inert_vec(t0, s.cinert[b], cv);
     cross_force(t1, cv, t0);
-    mul_inert_vec(f, s.cinert[b], ca);
+    mul_inert_vec(g, s.cinert[b], ca);
 #pragma unroll
-    for (int t = 0; t < 6; t++) s.cfrc[b][t] = f[t] + t1[t];
+    for (int t = 0; t < 6; t++) f[t] = g[t] + t1[t];
+    if (b >= NRB) {
+#pragma unroll
+      for (int t = 0; t < 6; t++) s.cfrc[b][t] = f[t];
+    }
   }
+  // robot: force on the subtree of every body, then lane = dof (dof l belongs to body l + 1: one row shift)
+  tree_suffix(f, l);
+  float tot[6];
+#pragma unroll
+  for (int t = 0; t < 6; t++) tot[t] = dpp_row<0x101>(f[t]);
   MRE_SYNC();
   // qfrc_bias (lane = dof): cdof . sum of cfrc over the subtree of the dof's body
   if (l < NV) {
     const int b = M->dof_body[l];
-    float tot[6];
-#pragma unroll
-    for (int t = 0; t < 6; t++) tot[t] = s.cfrc[b][t];
+    float c6[6];
     if (b < NRB) {
-      const unsigned mask = M->body_desc_mask[b];
-      for (int c = b + 1; c < NRB; c++)
-        if (mask & (1u << c)) {
 #pragma unroll
-          for (int t = 0; t < 6; t++) tot[t] += s.cfrc[c][t];
-        }
+      for (int t = 0; t < 6; t++) c6[t] = s.cdof[l][t];
+    } else {
+#pragma unroll
+      for (int t = 0; t < 6; t++) tot[t] = s.cfrc[b][t];
+      prop_cdof(s, b, l - M->body_dofadr[b], c6);
     }
     const bool act = body_is_active(M, s, b);
-    float cd[6];
-    if (b < NRB) { for (int t = 0; t < 6; t++) cd[t] = s.cdof[l][t]; }
-    else prop_cdof(s, b, l - M->body_dofadr[b], cd);
-    s.qfrc_bias[l] = act ? dot6(cd, tot) : 0.f;
+    s.qfrc_bias[l] = act ? dot6(c6, tot) : 0.f;
   }
 }
 
