@@ -558,20 +558,65 @@ MRE_PHASE_FN void connect_rows_local(ModelP M, Sm& s, int l) {
   MRE_SYNC();
 }
 
+// Sums along the robot's body tree with lane = body (lanes 0..15 of the first DPP row; lane 0 = the world, which
+// contributes nothing).  The tree is the one the kernels are unrolled for (ROBOT_DOF_PARENT, checked in mre_create):
+// the arm is the chain 1..7, and below link 7 hang four two-body fingers (8 -> 9, 10 -> 11, 12 -> 13, 14 -> 15).
+//   tree_prefix: x_b <- sum of x over b and its ancestors     (mj_comVel's accumulation down the tree)
+//   tree_suffix: x_b <- sum of x over b and its descendants   (mj_rne's / mj_crb's accumulation up the tree)
+// Row shifts instead of one loop per lane over its chain / its descendants; the order of the additions differs from
+// the loops' (last-bit rounding).
+template <int CTRL>
+MRE_DEV float dpp_row(float v) {  // lane's source by the row shift CTRL, 0 where the row has no such lane
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+template <int N>
+MRE_DEV void tree_prefix(float (&x)[N], int l) {
+  constexpr int LINK7 = GRIP_BODY0 - 1;
+  float own[N], par[N];
+#pragma unroll
+  for (int c = 0; c < N; c++) { own[c] = x[c]; par[c] = dpp_row<0x111>(x[c]); }
+#pragma unroll
+  for (int c = 0; c < N; c++) x[c] += dpp_row<0x111>(x[c]);
+#pragma unroll
+  for (int c = 0; c < N; c++) x[c] += dpp_row<0x112>(x[c]);
+#pragma unroll
+  for (int c = 0; c < N; c++) x[c] += dpp_row<0x114>(x[c]);
+  const bool finger = l >= GRIP_BODY0 && l < NRB, leaf = (l & 1) != 0;   // (bodies 9, 11, 13, 15 hang off 8, 10, 12, 14)
+#pragma unroll
+  for (int c = 0; c < N; c++) {
+    const float p7 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x[c]), LINK7));
+    x[c] = finger ? (p7 + (leaf ? par[c] : 0.f)) + own[c] : x[c];
+  }
+}
+template <int N>
+MRE_DEV void tree_suffix(float (&x)[N], int l) {
+  float own[N], nxt[N];
+#pragma unroll
+  for (int c = 0; c < N; c++) { own[c] = x[c]; nxt[c] = dpp_row<0x101>(x[c]); }
+#pragma unroll
+  for (int c = 0; c < N; c++) x[c] += dpp_row<0x101>(x[c]);
+#pragma unroll
+  for (int c = 0; c < N; c++) x[c] += dpp_row<0x102>(x[c]);
+#pragma unroll
+  for (int c = 0; c < N; c++) x[c] += dpp_row<0x104>(x[c]);
+#pragma unroll
+  for (int c = 0; c < N; c++) x[c] += dpp_row<0x108>(x[c]);
+  const bool finger = l >= GRIP_BODY0 && l < NRB, leaf = (l & 1) != 0;
+#pragma unroll
+  for (int c = 0; c < N; c++) x[c] = finger ? (leaf ? own[c] : own[c] + nxt[c]) : x[c];
+}
+
 // ------------------------------------------------------- mj_crb (robot block)
 MRE_DEV void crb_mass_matrix(ModelP M, Sm& s, int l) {
-  if (l >= 1 && l < NRB) {
-    const unsigned mask = M->body_desc_mask[l];
+  {  // composite inertia of every robot body = its own plus its descendants' (lane = body, tree_suffix)
     float acc[10];
 #pragma unroll
-    for (int k = 0; k < 10; k++) acc[k] = s.cinert[l][k];
-    for (int c = l + 1; c < NRB; c++)
-      if (mask & (1u << c)) {
+    for (int k = 0; k < 10; k++) acc[k] = (l >= 1 && l < NRB) ? s.cinert[l][k] : 0.f;
+    tree_suffix(acc, l);
+    if (l >= 1 && l < NRB) {
 #pragma unroll
-        for (int k = 0; k < 10; k++) acc[k] += s.cinert[c][k];
-      }
-#pragma unroll
-    for (int k = 0; k < 10; k++) s.crb[l][k] = acc[k];
+      for (int k = 0; k < 10; k++) s.crb[l][k] = acc[k];
+    }
   }
   MRE_SYNC();
   for (int e = l; e < NMR; e += 64) {
@@ -724,54 +769,6 @@ MRE_DEV void solve_robot_one(const float* LD, const float* dinv, float* xv, int 
 namespace mre {
 
 // ------------------------------------------------ mj_comVel + mj_rne + mj_passive
-// Sums along the robot's body tree with lane = body (lanes 0..15 of the first DPP row; lane 0 = the world, which
-// contributes nothing).  The tree is the one the kernels are unrolled for (ROBOT_DOF_PARENT, checked in mre_create):
-// the arm is the chain 1..7, and below link 7 hang four two-body fingers (8 -> 9, 10 -> 11, 12 -> 13, 14 -> 15).
-//   tree_prefix: x_b <- sum of x over b and its ancestors     (mj_comVel's accumulation down the tree)
-//   tree_suffix: x_b <- sum of x over b and its descendants   (mj_rne's / mj_crb's accumulation up the tree)
-// Row shifts instead of one loop per lane over its chain / its descendants; the order of the additions differs from
-// the loops' (last-bit rounding).
-template <int CTRL>
-MRE_DEV float dpp_row(float v) {  // lane's source by the row shift CTRL, 0 where the row has no such lane
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
-}
-template <int N>
-MRE_DEV void tree_prefix(float (&x)[N], int l) {
-  constexpr int LINK7 = GRIP_BODY0 - 1;
-  float own[N], par[N];
-#pragma unroll
-  for (int c = 0; c < N; c++) { own[c] = x[c]; par[c] = dpp_row<0x111>(x[c]); }
-#pragma unroll
-  for (int c = 0; c < N; c++) x[c] += dpp_row<0x111>(x[c]);
-#pragma unroll
-  for (int c = 0; c < N; c++) x[c] += dpp_row<0x112>(x[c]);
-#pragma unroll
-  for (int c = 0; c < N; c++) x[c] += dpp_row<0x114>(x[c]);
-  const bool finger = l >= GRIP_BODY0 && l < NRB, leaf = (l & 1) != 0;   // (bodies 9, 11, 13, 15 hang off 8, 10, 12, 14)
-#pragma unroll
-  for (int c = 0; c < N; c++) {
-    const float p7 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x[c]), LINK7));
-    x[c] = finger ? (p7 + (leaf ? par[c] : 0.f)) + own[c] : x[c];
-  }
-}
-template <int N>
-MRE_DEV void tree_suffix(float (&x)[N], int l) {
-  float own[N], nxt[N];
-#pragma unroll
-  for (int c = 0; c < N; c++) { own[c] = x[c]; nxt[c] = dpp_row<0x101>(x[c]); }
-#pragma unroll
-  for (int c = 0; c < N; c++) x[c] += dpp_row<0x101>(x[c]);
-#pragma unroll
-  for (int c = 0; c < N; c++) x[c] += dpp_row<0x102>(x[c]);
-#pragma unroll
-  for (int c = 0; c < N; c++) x[c] += dpp_row<0x104>(x[c]);
-#pragma unroll
-  for (int c = 0; c < N; c++) x[c] += dpp_row<0x108>(x[c]);
-  const bool finger = l >= GRIP_BODY0 && l < NRB, leaf = (l & 1) != 0;
-#pragma unroll
-  for (int c = 0; c < N; c++) x[c] = finger ? (leaf ? own[c] : own[c] + nxt[c]) : x[c];
-}
-
 MRE_PHASE_FN void velocity_stage(ModelP M, Sm& s, int l) {
   constexpr int LINK7 = GRIP_BODY0 - 1;
   const bool rob = l >= 1 && l < NRB;   // lane = robot body l, whose hinge is dof l - 1
