@@ -383,11 +383,26 @@ MRE_DEV void prop_cdof(const Sm& s, int b, int j, float* c) {
 // eight finger joint angles alone, so it is evaluated in THAT link's frame, about the pinch site, in
 // fp64 (sin / cos by Taylor polynomials, |half angle| < 1), and only the results are rounded.
 MRE_DEV void sincos_poly_d(double x, double& sn, double& cs) {
+  // Taylor polynomials to x^15 / x^16 in Horner form with the reciprocal factorials as constants (the nested
+  // z / 6 * (1 - z / 20 * ...) form costs a full fp64 division per term)
   const double z = x * x;
-  sn = x * (1.0 - z / 6.0 * (1.0 - z / 20.0 * (1.0 - z / 42.0 * (1.0 - z / 72.0 * (1.0 - z / 110.0 *
-       (1.0 - z / 156.0 * (1.0 - z / 210.0)))))));
-  cs = 1.0 - z / 2.0 * (1.0 - z / 12.0 * (1.0 - z / 30.0 * (1.0 - z / 56.0 * (1.0 - z / 90.0 *
-       (1.0 - z / 132.0 * (1.0 - z / 182.0 * (1.0 - z / 240.0)))))));
+  double ps = -1.0 / 1307674368000.0;
+  ps = ps * z + 1.0 / 6227020800.0;
+  ps = ps * z - 1.0 / 39916800.0;
+  ps = ps * z + 1.0 / 362880.0;
+  ps = ps * z - 1.0 / 5040.0;
+  ps = ps * z + 1.0 / 120.0;
+  ps = ps * z - 1.0 / 6.0;
+  sn = x + x * (z * ps);
+  double pc = 1.0 / 20922789888000.0;
+  pc = pc * z - 1.0 / 87178291200.0;
+  pc = pc * z + 1.0 / 479001600.0;
+  pc = pc * z - 1.0 / 3628800.0;
+  pc = pc * z + 1.0 / 40320.0;
+  pc = pc * z - 1.0 / 720.0;
+  pc = pc * z + 1.0 / 24.0;
+  pc = pc * z - 0.5;
+  cs = 1.0 + z * pc;
 }
 MRE_DEV void dq_mul(double* r, const double* a, const double* b) {
   const double w = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
@@ -453,15 +468,27 @@ MRE_DEV void inert_about_d(ModelP M, int c, const double* p, const double* q, co
 // of the arm's last link, and the momentum map P = crb * cdof that the finger rows of M are built
 // from (crb_mass_matrix).  Chains below the arm are at most two bodies deep (checked in mre_create).
 // lane = finger body: its pose in the arm link's frame (composition with its parent's joint included)
+MRE_DEV double dpp_shr1_d(double v) {   // the value of lane l - 1 (same DPP row)
+  const long long b = __builtin_bit_cast(long long, v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xFFFFFFFFll), 0x111, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x111, 0xF, 0xF, false);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned)lo);
+}
 MRE_PHASE_FN void gripper_pose(ModelP M, Sm& s, int l) {
-  if (l >= GRIP_BODY0 && l < NRB) {
+  const bool fin = l >= GRIP_BODY0 && l < NRB;
+  double p[3] = {0.0, 0.0, 0.0}, q[4] = {1.0, 0.0, 0.0, 0.0};
+  if (fin) hinge_local_d(M, s, l, p, q);
+  // a body that hangs off another finger body (9, 11, 13, 15 off 8, 10, 12, 14: the dof tree mre_create checks)
+  // takes its parent's pose from the lane below instead of evaluating that hinge a second time
+  double pp[3], pq[4];
+#pragma unroll
+  for (int k = 0; k < 3; k++) pp[k] = dpp_shr1_d(p[k]);
+#pragma unroll
+  for (int k = 0; k < 4; k++) pq[k] = dpp_shr1_d(q[k]);
+  if (fin) {
     const int b = l;
-    double p[3], q[4];
-    hinge_local_d(M, s, b, p, q);
-    const int par = M->body_parent[b];
-    if (par >= GRIP_BODY0) {
-      double pp[3], pq[4], t[3], q2[4];
-      hinge_local_d(M, s, par, pp, pq);
+    if (M->body_parent[b] >= GRIP_BODY0) {
+      double t[3], q2[4];
       dq_rot(t, pq, p);
       for (int k = 0; k < 3; k++) p[k] = pp[k] + t[k];
       dq_mul(q2, pq, q);
