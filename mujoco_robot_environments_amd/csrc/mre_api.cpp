@@ -694,6 +694,10 @@ static int create_buffers(mre_env* e, int num_envs, int device_id) {
         HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
         const char* gp = getenv("MRE_GROUP_PRIORITY");
         if (!(gp && atoi(gp) == 0)) { pr = greatest + g; if (pr > least) pr = least; }
+        // tuning knob: one digit per group, 0 = highest priority level
+        if (const char* map = getenv("MRE_GROUP_PRIO_MAP")) {
+          if ((int)strlen(map) > g && map[g] >= '0' && map[g] <= '9') { pr = greatest + (map[g] - '0'); if (pr > least) pr = least; }
+        }
       }
       HIPCHK(hipStreamCreateWithPriority(&G.st, hipStreamNonBlocking, pr));
       HIPCHK(hipStreamCreateWithPriority(&G.st2, hipStreamNonBlocking, pr));
