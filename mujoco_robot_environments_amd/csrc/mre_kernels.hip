@@ -679,37 +679,37 @@ MRE_DEV void crb_mass_matrix(ModelP M, Sm& s, int l) {
 // (ROBOT_DOF_PARENT), every lane solving its own right-hand side; the factor entries are LDS
 // reads at constant offsets.  Same operations in the same order as mj_solveLD.
 typedef const __attribute__((address_space(3))) float* lds_cfloat_p;
-template <int I, int K>
-MRE_DEV void solve_regs_back(float (&x)[NRV], lds_cfloat_p LD, float xi) {
+template <int I, int K, class F>
+MRE_DEV void solve_regs_back(float (&x)[NRV], const F& LD, float xi) {
   constexpr int j = robot_dof_anc(I, K);
   if constexpr (j >= 0) {
     constexpr int adr = robot_dof_madr(I) + 1 + K;
     x[j] -= LD[adr] * xi;
-    solve_regs_back<I, K + 1>(x, LD, xi);
+    solve_regs_back<I, K + 1, F>(x, LD, xi);
   }
 }
-template <int I>
-MRE_DEV void solve_regs_back_rows(float (&x)[NRV], lds_cfloat_p LD) {
-  solve_regs_back<I, 0>(x, LD, x[I]);
+template <int I, class F>
+MRE_DEV void solve_regs_back_rows(float (&x)[NRV], const F& LD) {
+  solve_regs_back<I, 0, F>(x, LD, x[I]);
   __builtin_amdgcn_sched_barrier(0);  // keep the factor reads of later rows out of the live set
-  if constexpr (I > 0) solve_regs_back_rows<I - 1>(x, LD);
+  if constexpr (I > 0) solve_regs_back_rows<I - 1, F>(x, LD);
 }
-template <int I, int K>
-MRE_DEV void solve_regs_fwd(float (&x)[NRV], lds_cfloat_p LD, float& xi) {
+template <int I, int K, class F>
+MRE_DEV void solve_regs_fwd(float (&x)[NRV], const F& LD, float& xi) {
   constexpr int j = robot_dof_anc(I, K);
   if constexpr (j >= 0) {
     constexpr int adr = robot_dof_madr(I) + 1 + K;
     xi -= LD[adr] * x[j];
-    solve_regs_fwd<I, K + 1>(x, LD, xi);
+    solve_regs_fwd<I, K + 1, F>(x, LD, xi);
   }
 }
-template <int I>
-MRE_DEV void solve_regs_fwd_rows(float (&x)[NRV], lds_cfloat_p LD) {
+template <int I, class F>
+MRE_DEV void solve_regs_fwd_rows(float (&x)[NRV], const F& LD) {
   float xi = x[I];
-  solve_regs_fwd<I, 0>(x, LD, xi);
+  solve_regs_fwd<I, 0, F>(x, LD, xi);
   x[I] = xi;
   __builtin_amdgcn_sched_barrier(0);
-  if constexpr (I + 1 < NRV) solve_regs_fwd_rows<I + 1>(x, LD);
+  if constexpr (I + 1 < NRV) solve_regs_fwd_rows<I + 1, F>(x, LD);
 }
 MRE_DEV void solve_robot_regs(const float* LD_, const float* dinv_, float (&x)[NRV]) {
   // explicit LDS pointers, opaque to loop strength reduction: every factor entry is then one
@@ -717,10 +717,10 @@ MRE_DEV void solve_robot_regs(const float* LD_, const float* dinv_, float (&x)[N
   lds_cfloat_p LD = (lds_cfloat_p)LD_;
   lds_cfloat_p dinv = (lds_cfloat_p)dinv_;
   asm volatile("" : "+v"(LD), "+v"(dinv));
-  solve_regs_back_rows<NRV - 1>(x, LD);
+  solve_regs_back_rows<NRV - 1, lds_cfloat_p>(x, LD);
 #pragma unroll
   for (int i = 0; i < NRV; i++) x[i] *= dinv[i];
-  solve_regs_fwd_rows<0>(x, LD);
+  solve_regs_fwd_rows<0, lds_cfloat_p>(x, LD);
 }
 
 // mj_factorM on the robot block with the matrix in registers: every lane runs the whole
@@ -748,13 +748,13 @@ MRE_DEV void factor_regs_anc(float (&A)[NMR], float inv) {
     factor_regs_anc<K, P + 1>(A, inv);
   }
 }
-template <int K>
-MRE_DEV void factor_regs_rows(float (&A)[NMR], lds_float_p dinv) {
+template <int K, class D>
+MRE_DEV void factor_regs_rows(float (&A)[NMR], D& dinv) {
   constexpr int kk = robot_dof_madr(K);
   const float inv = 1.0f / A[kk];
   dinv[K] = inv;
   factor_regs_anc<K, 1>(A, inv);
-  if constexpr (K > 0) factor_regs_rows<K - 1>(A, dinv);
+  if constexpr (K > 0) factor_regs_rows<K - 1, D>(A, dinv);
 }
 // src: the matrix (qM, or M - h dF/dv already formed in LD); LD / dinv: factor and 1/D (all LDS)
 MRE_DEV void factor_robot_regs(const float* src_, float* LD_, float* dinv_) {
@@ -764,7 +764,7 @@ MRE_DEV void factor_robot_regs(const float* src_, float* LD_, float* dinv_) {
   float A[NMR];
 #pragma unroll
   for (int e = 0; e < NMR; e++) A[e] = src[e];
-  factor_regs_rows<NRV - 1>(A, dinv);
+  factor_regs_rows<NRV - 1, lds_float_p>(A, dinv);
 #pragma unroll
   for (int e = 0; e < NMR; e++) LD[e] = A[e];
   MRE_SYNC();
@@ -779,6 +779,30 @@ MRE_DEV void solve_robot_one(const float* LD, const float* dinv, float* xv, int 
 #pragma unroll
   for (int i = 0; i < NRV; i++) x[i] = xv[i];
   solve_robot_regs(LD, dinv, x);
+  MRE_SYNC();
+  float mine = 0.f;
+#pragma unroll
+  for (int i = 0; i < NRV; i++) mine = (l == i) ? x[i] : mine;
+  if (l < NRV) xv[l] = mine;
+  MRE_SYNC();
+}
+
+// Factor and one solve in one go, nothing stored: the implicit integrator's M - h dF/dv is factored for the single
+// solve that follows it, so the factor never needs to leave the registers (saves the 111 LDS stores of the factor
+// and the 111 loads of the solve).  src: the matrix, xv: right-hand side in, solution out (lane i keeps component i).
+MRE_DEV void factor_solve_robot(const float* src_, float* xv, int l) {
+  lds_cfloat_p src = (lds_cfloat_p)src_;
+  asm volatile("" : "+v"(src));
+  float A[NMR], dv[NRV], x[NRV];
+#pragma unroll
+  for (int e = 0; e < NMR; e++) A[e] = src[e];
+#pragma unroll
+  for (int i = 0; i < NRV; i++) x[i] = xv[i];
+  factor_regs_rows<NRV - 1, float[NRV]>(A, dv);
+  solve_regs_back_rows<NRV - 1, float[NMR]>(x, A);
+#pragma unroll
+  for (int i = 0; i < NRV; i++) x[i] *= dv[i];
+  solve_regs_fwd_rows<0, float[NMR]>(x, A);
   MRE_SYNC();
   float mine = 0.f;
 #pragma unroll
@@ -1148,8 +1172,7 @@ MRE_DEV void step_body(const StepArgs& a, Sm& s) {
     }
 
     integrate_setup(M, s, l, clamped);
-    factor_robot_regs(s.qLD, s.qLD, s.qLDinv);
-    solve_robot_one(s.qLD, s.qLDinv, s.scratch, l);
+    factor_solve_robot(s.qLD, s.scratch, l);
     integrate(M, s, l, a.flags);
     steps_done = step + 1;
     if ((a.flags & F_SETTLE_EXIT) != 0) {
