@@ -1,0 +1,34 @@
+"""A larger sample of the two 1000-step Newton parity runs of tests/test_gpu_newton.py (same seeds, same report),
+for DESIGN section 7.  usage: python tests/diagnostics/parity_sample.py [nenvs=256]   (needs the GPU; not a test)"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+from mujoco_robot_environments_amd.model import compile as MC  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+from tests.test_gpu_newton import TOL, _divergence_report  # noqa: E402
+from tests.test_gpu_parity import _rollout_both  # noqa: E402
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+A = MC.compile_scene()
+cm = (A, MC.to_blob(A))
+om = O.Model(cm[1])
+for name, kw in (("gentle torques", dict(scale=0.1, seed=11, gravity_comp=True)), ("bench law", dict(scale=1.0, seed=5))):
+    gq, oq, nprops, phys, gcen, ocen, bq = _rollout_both(cm, om, N=N, T=200, flags=0, z_extra=0.0005, yaw=True,
+                                                         solver="Newton", census=True, fp32_state=True, **kw)
+    under, switched, unexplained, cmax = _divergence_report(f"newton {name} ({N} envs)", gq, oq, nprops, gcen, ocen, bq=bq)
+    err = np.abs(gq - oq)
+    for i in range(N):
+        err[:, i, 15 + 7 * int(nprops[i]):] = 0
+    first = np.array([np.argmax(err[:, i].max(axis=1) > TOL) if (err[:, i].max() > TOL) else err.shape[0] for i in range(N)])
+    clean = [i for i in range(N) if not np.any(gcen[:, i] != ocen[:, i])]
+    print(f"{name}: {N} envs x 1000 steps: under 1e-4 on all 43 coordinates at 250 / 500 / 750 / 1000 steps: "
+          f"{(first >= 250).mean():.3f} / {(first >= 500).mean():.3f} / {(first >= 750).mean():.3f} / {(first >= 1000).mean():.3f}; "
+          f"first exit at step {first.min()}; {len(clean)} envs never switched their constraint set: arm {err[:, clean, :7].max():.2e}, "
+          f"cubes {err[:, clean][:, :, 15:].max():.2e}, fingers {err[:, clean][:, :, 7:15].max():.2e}; "
+          f"{len(unexplained)} exits explained by neither reference", flush=True)
+    phys.close()
