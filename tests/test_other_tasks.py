@@ -150,6 +150,7 @@ def test_push_friction_quirk_and_the_forwarded_gradient():
             e.forward()
             e.step(300)
             e.arr("qvel")[16] = -0.5
+            e.forward()   # (velocity-dependent terms of the coming step2 at the new velocity)
             e.step(50)
             dec[(ff, xc)] = (e.arr("qvel")[16] + 0.5) / 0.05
     g = 9.8
