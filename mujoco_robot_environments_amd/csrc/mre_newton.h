@@ -419,16 +419,15 @@ MRE_PHASE_FN void nw_direction(ModelP M, Sm& s, int l) {
       w2 = nprops > 2 ? ldw(((d.y >> sh) & 0xFFFFu) + lo) : 0.f;
     };
     static_assert(sizeof(s.Jr[0]) == 60 && sizeof(s.JpA[0]) == 24 && sizeof(s.JpB[0]) == 24, "row strides of the gathers");
-    int iiN, stN, hN;
-    float RN;
-    uint2 dN;
-    meta(0, iiN, stN, hN, RN, dN);
-    for (int r0 = 0; r0 < nefc; r0 += 4) {
-      const int ii = iiN, h = hN, st = stN;
-      const uint2 d = dN;
+    // one chunk on the metadata `cur`; the metadata of the following chunk goes to `nxt`.  The loop calls it with
+    // two sets in turn, so no registers are shuffled between chunks.
+    struct Meta { int ii, st, h; float R; uint2 d; };
+    auto chunk = [&](const Meta& cur, Meta& nxt, int r0) {
+      const int ii = cur.ii, h = cur.h, st = cur.st;
+      const uint2 d = cur.d;
       const bool quad = st == NW_QUAD, cone = st == NW_CONE;
-      const float D = quad ? __builtin_amdgcn_rcpf(RN) : 0.f;   // (1 ulp; the IEEE division is 12 instructions)
-      if (r0 + 4 < nefc) meta(r0 + 4, iiN, stN, hN, RN, dN);
+      const float D = quad ? __builtin_amdgcn_rcpf(cur.R) : 0.f;   // (1 ulp; the IEEE division is 12 instructions)
+      if (r0 + 4 < nefc) meta(r0 + 4, nxt.ii, nxt.st, nxt.h, nxt.R, nxt.d);
       float v0, v1, v2, a0, a1, a2;
       if (__any(cone)) {
         // a contact in the middle zone enters with its 3 x 3 Hessian: row k of the contact contributes
@@ -463,6 +462,13 @@ MRE_PHASE_FN void nw_direction(ModelP M, Sm& s, int l) {
         c21 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, v1, c21, 0, 0, 0);
         c22 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, v2, c22, 0, 0, 0);
       }
+    };
+    Meta mA, mB;
+    meta(0, mA.ii, mA.st, mA.h, mA.R, mA.d);
+    mB = mA;
+    for (int r0 = 0; r0 < nefc; r0 += 8) {
+      chunk(mA, mB, r0);
+      if (r0 + 4 < nefc) chunk(mB, mA, r0 + 4);
     }
     MRE_DBG_STAMP(4, 1);
     // Tiles -> rows: lane j needs row j of H.  One tile at a time through LDS (the factor's home, unused until
