@@ -592,6 +592,16 @@ MRE_PHASE_FN void connect_rows_local(ModelP M, Sm& s, int l) {
 //   tree_suffix: x_b <- sum of x over b and its descendants   (mj_rne's / mj_crb's accumulation up the tree)
 // Row shifts instead of one loop per lane over its chain / its descendants; the order of the additions differs from
 // the loops' (last-bit rounding).
+constexpr bool robot_tree_is_chain_plus_two_body_fingers() {
+  for (int d = 0; d < NRV; d++) {
+    const int b = d + 1;   // body of dof d
+    const int want = b < GRIP_BODY0 ? d - 1 : ((b & 1) ? d - 1 : GRIP_BODY0 - 2);
+    if (ROBOT_DOF_PARENT[d] != want) return false;
+  }
+  return true;
+}
+static_assert(GRIP_BODY0 % 2 == 0 && NRB == 16 && robot_tree_is_chain_plus_two_body_fingers(),
+              "tree_prefix / tree_suffix / the prefix kinematics are written for this body tree");
 template <int CTRL>
 MRE_DEV float dpp_row(float v) {  // lane's source by the row shift CTRL, 0 where the row has no such lane
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
