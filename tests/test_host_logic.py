@@ -61,7 +61,7 @@ def test_config_compose_matches_reference_tree():
     t = config.colour_separator_task_config()
     assert t.name == "colour_splitter" and t.task.colour_target_map.green == "bottom_left"
     assert t.task.target_locations.top_left.size == [0.075, 0.15, 0.01]
-    with pytest.raises(ValueError):
+    with pytest.raises(config.MissingConfig):
         config.compose("rearrangement", [])  # props has no default in the reference tree
     with pytest.raises(KeyError):
         config.compose("rearrangement", ["arena/props=colour_splitter", "nonexistent=1"])

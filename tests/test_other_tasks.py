@@ -161,7 +161,8 @@ def test_push_friction_quirk_and_the_forwarded_gradient():
 def test_configs_of_the_other_tasks():
     l = cfgm.lasa_default_config()
     assert l.physics_dt == 0.01 and l.simulation_tuning_mode is True
-    assert [c.name for c in l.arena.cameras] == ["main_camera", "front_camera", "left_camera"]
+    assert [c.name for c in l.arena.cameras] == ["main_camera"]   # config/arena/cameras/lasa.yaml (one live entry)
+    assert "props" not in l.arena                                 # config/arena/lasa.yaml has no props group
     d = cfgm.lasa_deployment_config()
     assert d.robots.arm.actuator_config.type == "general"
     assert d.robots.arm.actuator_config.joint4.ctrlrange == "-3.0718 -0.0698"
