@@ -1,29 +1,36 @@
-"""RLDS-style episode shards from batched rollouts -- the on-disk side of the reference's data
+"""RLDS episode shards in TFDS's on-disk format from batched rollouts -- the on-disk side of the reference's data
 generation (transporter_network_data_generation.py:56-111: ``tfds.rlds.rlds_base.DatasetConfig`` +
 ``envlogger.EnvLogger`` with a ``TFDSBackendWriter``), without envlogger / TensorFlow.
 
-What is written: TFRecord files (``<name>-train.tfrecord-00000-of-NNNNN``) whose records are
-``tf.train.Example`` protos, one EPISODE per record, with the RLDS step fields flattened under
-``steps/`` exactly as the reference's ``ds_config`` names them:
+What ``TFDSBackendWriter(data_directory, split_name, max_episodes_per_file, ds_config)`` leaves in ``data_directory``,
+and what is written here (all restated from the public TFDS / RLDS / TFRecord / protobuf formats; TensorFlow is
+absent from this image, so ``tests/test_dataset_tfds.py`` -- ``tfds.builder_from_directory`` on a written
+directory -- skips here and runs wherever tensorflow_datasets is importable):
 
-    steps/observation/overhead_camera/rgb     bytes_list: one raw uint8 [H, W, 3] buffer per step
-    steps/observation/overhead_camera/depth   float_list: H * W floats per step, steps concatenated
-    steps/action/pose                         float_list: 7 per step (float64 in the reference; the
-                                              Example proto only has float32 lists -- TFDS stores
-                                              float64 tensors the same way)
-    steps/action/pixel_coords                 int64_list: 2 per step
-    steps/action/gripper_rot                  float_list: 1 per step
-    steps/reward, steps/discount              float_list: 1 per step
-    steps/is_first, steps/is_last, steps/is_terminal   int64_list: 1 per step
-    episode_metadata/intrinsics/{fx,fy,cx,cy}, episode_metadata/extrinsics/{x,y,z,qx,qy,qz,qw}
-                                              float_list: 1 each (calibration_metadata, :88-95)
+* ``<name>-<split>.tfrecord-XXXXX-of-NNNNN``: TFRecord files (length, masked CRC-32C of the length, payload, masked
+  CRC-32C of the payload), ``max_episodes_per_file`` episodes each (config/dataset/default.yaml:3), one
+  ``tf.train.Example`` per EPISODE.  Feature keys are the ``/``-joined paths of ``rlds_base.build_info``'s feature
+  tree -- ``steps`` is a ``tfds.features.Dataset`` of the step fields, the ``episode_metadata_info`` entries sit at
+  the TOP level beside it -- and every leaf is serialised the way TFDS's example serializer does it: a step field
+  is ONE flat list over all steps (leading step axis, then the tensor's own shape), integers AND uint8 AND bool go to
+  ``int64_list`` (the default ``Encoding.NONE`` of ``tfds.features.Tensor``: one varint per pixel byte), float32 AND
+  float64 go to ``float_list`` (the Example proto has no double list):
 
-plus ``features.json`` (the feature spec above with shapes / dtypes) and ``dataset_info.json`` (name,
-split, shard lengths).  ``max_episodes_per_file`` (config/dataset/default.yaml:3) cuts the shards.
-The TFRecord framing (length, masked CRC-32C of the length, payload, masked CRC-32C of the payload)
-and the proto wire format are restated from their public specifications; TensorFlow is not present
-here, so byte-compatibility with ``tfds.builder_from_directory`` is untested -- ``read_episodes`` in
-this module parses the files back and tests/test_dataset.py round-trips them.
+      steps/observation/overhead_camera/rgb     int64_list   T * H * W * 3
+      steps/observation/overhead_camera/depth   float_list   T * H * W
+      steps/action/pose                         float_list   T * 7
+      steps/action/pixel_coords                 int64_list   T * 2
+      steps/action/gripper_rot, steps/reward, steps/discount          float_list   T
+      steps/is_first, steps/is_last, steps/is_terminal                int64_list   T
+      intrinsics/{fx,fy,cx,cy}, extrinsics/{x,y,z,qx,qy,qz,qw}        float_list   1   (calibration_metadata, :88-95)
+
+* ``features.json``: the feature tree as TFDS serialises it (proto3 JSON of ``feature.proto``: ``pythonClassName`` +
+  one of ``featuresDict`` / ``sequence`` / ``tensor``; int64 fields as strings).
+* ``dataset_info.json``: proto3 JSON of ``DatasetInfo`` (name, version 0.0.1 -- TFDSBackendWriter's default --,
+  ``fileFormat``, one split with ``shardLengths`` / ``numBytes`` as strings and the standard ``filepathTemplate``).
+
+``read_episodes`` parses a directory back BY ITS features.json (it is a generic reader of this format, not a mirror
+of the writer), and tests/test_dataset.py round-trips through it.
 """
 from __future__ import annotations
 
@@ -140,13 +147,27 @@ def _ld(field: int, payload: bytes) -> bytes:   # length-delimited field
     return _varint((field << 3) | 2) + _varint(len(payload)) + payload
 
 
+def _pack_varints(a: np.ndarray) -> bytes:
+    """Packed varints of non-negative integers < 2^14 (pixel bytes, flags, pixel coordinates): vectorised."""
+    a = a.reshape(-1).astype(np.uint16)
+    two = a >= 128
+    out = np.empty(a.size + int(two.sum()), np.uint8)
+    pos = np.arange(a.size) + np.concatenate([[0], np.cumsum(two)[:-1]]) if a.size else np.zeros(0, np.int64)
+    out[pos] = np.where(two, (a & 0x7F) | 0x80, a).astype(np.uint8)
+    out[pos[two] + 1] = (a[two] >> 7).astype(np.uint8)
+    return out.tobytes()
+
+
 def _feature(value) -> bytes:
+    """One tf.train.Feature: bytes_list for a list of bytes, float_list for floating arrays, int64_list otherwise."""
     if isinstance(value, (list, tuple)) and value and isinstance(value[0], (bytes, bytearray)):
         body = b"".join(_ld(1, bytes(v)) for v in value)
         return _ld(1, body)                                   # bytes_list
     a = np.asarray(value)
     if a.dtype.kind == "f":
         return _ld(2, _ld(1, a.astype("<f4").tobytes()))      # float_list, packed
+    if a.size and a.dtype.kind in "ub" or (a.size and a.min() >= 0 and a.max() < (1 << 14)):
+        return _ld(3, _ld(1, _pack_varints(a)))               # int64_list, packed
     packed = b"".join(_varint(int(v) & 0xFFFFFFFFFFFFFFFF) for v in a.reshape(-1))
     return _ld(3, _ld(1, packed))                             # int64_list, packed
 
@@ -189,6 +210,26 @@ def _fields(b: bytes):
             raise ValueError("unsupported wire type")
 
 
+def _unpack_varints(v: bytes) -> np.ndarray:
+    b = np.frombuffer(v, np.uint8)
+    if b.size == 0:
+        return np.zeros(0, np.int64)
+    last = (b & 0x80) == 0                       # final byte of every varint
+    if last.all():
+        return b.astype(np.int64)
+    start = np.concatenate([[0], np.nonzero(last)[0][:-1] + 1])
+    length = np.nonzero(last)[0] + 1 - start
+    if length.max() <= 2:                        # (values < 2^14: pixel bytes and coordinates)
+        lo = (b[start] & 0x7F).astype(np.int64)
+        hi = np.where(length == 2, b[np.minimum(start + 1, b.size - 1)].astype(np.int64) << 7, 0)
+        return lo + hi
+    vals, i = [], 0
+    while i < len(v):
+        n, i = _read_varint(v, i)
+        vals.append(n - (1 << 64) if n >= (1 << 63) else n)
+    return np.asarray(vals, np.int64)
+
+
 def decode_example(payload: bytes) -> Dict[str, object]:
     out = {}
     for f, feats in _fields(payload):
@@ -206,21 +247,67 @@ def decode_example(payload: bytes) -> Dict[str, object]:
                         elif f4 == 2:
                             val = np.concatenate([np.frombuffer(v, "<f4") for _, v in _fields(lst)] or [np.zeros(0, "<f4")])
                         elif f4 == 3:
-                            vals = []
-                            for _, v in _fields(lst):
-                                i = 0
-                                while i < len(v):
-                                    n, i = _read_varint(v, i)
-                                    vals.append(n - (1 << 64) if n >= (1 << 63) else n)
-                            val = np.asarray(vals, np.int64)
+                            val = np.concatenate([_unpack_varints(v) for _, v in _fields(lst)] or [np.zeros(0, np.int64)])
             out[key] = val
     return out
+
+
+# ------------------------------------------------------------------ TFDS metadata
+_FEATURES_PKG = "tensorflow_datasets.core.features."
+
+
+def _tensor_feature(shape, dtype: str) -> dict:
+    """features.json node of tfds.features.Tensor(shape, dtype) / tfds.features.Scalar(dtype) (shape ())."""
+    cls = "scalar.Scalar" if len(shape) == 0 else "tensor_feature.Tensor"
+    sh = {"dimensions": [str(int(d)) for d in shape]} if len(shape) else {}
+    return {"pythonClassName": _FEATURES_PKG + cls, "tensor": {"shape": sh, "dtype": dtype, "encoding": "none"}}
+
+
+def _dict_feature(children: dict) -> dict:
+    return {"pythonClassName": _FEATURES_PKG + "features_dict.FeaturesDict", "featuresDict": {"features": children}}
+
+
+def rlds_features(height: int, width: int) -> dict:
+    """features.json of ``rlds_base.build_info(ds_config)`` for the reference's ds_config
+    (transporter_network_data_generation.py:56-86): FeaturesDict{steps: Dataset(FeaturesDict{observation, action,
+    reward, discount, is_first, is_last, is_terminal}), **episode_metadata_info}."""
+    h, w = int(height), int(width)
+    step = _dict_feature({
+        "observation": _dict_feature({"overhead_camera/rgb": _tensor_feature((h, w, 3), "uint8"),
+                                      "overhead_camera/depth": _tensor_feature((h, w), "float32")}),
+        "action": _dict_feature({"pose": _tensor_feature((7,), "float64"),
+                                 "pixel_coords": _tensor_feature((2,), "int32"),
+                                 "gripper_rot": _tensor_feature((), "float64")}),
+        "reward": _tensor_feature((), "float64"), "discount": _tensor_feature((), "float64"),
+        "is_first": _tensor_feature((), "bool"), "is_last": _tensor_feature((), "bool"),
+        "is_terminal": _tensor_feature((), "bool")})
+    return _dict_feature({
+        "steps": {"pythonClassName": _FEATURES_PKG + "dataset_feature.Dataset",
+                  "sequence": {"feature": step, "length": "-1"}},
+        "intrinsics": _dict_feature({k: _tensor_feature((), "float64") for k in ("fx", "fy", "cx", "cy")}),
+        "extrinsics": _dict_feature({k: _tensor_feature((), "float64") for k in ("x", "y", "z", "qx", "qy", "qz", "qw")})})
+
+
+def feature_leaves(node: dict, prefix: str = "", in_sequence: bool = False):
+    """(example key, shape tuple, dtype, inside a Dataset / Sequence) of every tensor leaf of a features.json tree."""
+    if "featuresDict" in node:
+        for k, v in node["featuresDict"]["features"].items():
+            yield from feature_leaves(v, f"{prefix}/{k}" if prefix else k, in_sequence)
+    elif "sequence" in node:
+        yield from feature_leaves(node["sequence"]["feature"], prefix, True)
+    elif "tensor" in node:
+        dims = node["tensor"].get("shape", {}).get("dimensions", [])
+        yield prefix, tuple(int(d) for d in dims), node["tensor"]["dtype"], in_sequence
+    else:
+        raise ValueError(f"features.json: unsupported feature at '{prefix}': {sorted(node)}")
 
 
 # ------------------------------------------------------------------ the writer
 class EpisodeWriter:
     """Shard writer mirroring ``TFDSBackendWriter(data_directory, split_name, max_episodes_per_file,
     ds_config)`` (transporter_network_data_generation.py:103-111)."""
+
+    VERSION = "0.0.1"   # TFDSBackendWriter's default `version`
 
     def __init__(self, data_directory: str, name: str, height: int, width: int, split_name: str = "train",
                  max_episodes_per_file: int = 10):
@@ -232,22 +319,10 @@ class EpisodeWriter:
         self._file = None
         self._in_file = 0
         self._episodes = 0
+        self._bytes = 0
 
     def features(self) -> dict:
-        h, w = self.h, self.w
-        return {
-            "steps": {
-                "observation": {"overhead_camera/rgb": {"shape": [h, w, 3], "dtype": "uint8"},
-                                "overhead_camera/depth": {"shape": [h, w], "dtype": "float32"}},
-                "action": {"pose": {"shape": [7], "dtype": "float64"},
-                           "pixel_coords": {"shape": [2], "dtype": "int32"},
-                           "gripper_rot": {"shape": [], "dtype": "float64"}},
-                "reward": {"shape": [], "dtype": "float64"}, "discount": {"shape": [], "dtype": "float64"},
-                "is_first": {"shape": [], "dtype": "bool"}, "is_last": {"shape": [], "dtype": "bool"},
-                "is_terminal": {"shape": [], "dtype": "bool"}},
-            "episode_metadata": {"intrinsics": {k: {"shape": [], "dtype": "float64"} for k in ("fx", "fy", "cx", "cy")},
-                                 "extrinsics": {k: {"shape": [], "dtype": "float64"}
-                                                for k in ("x", "y", "z", "qx", "qy", "qz", "qw")}}}
+        return rlds_features(self.h, self.w)
 
     def _tmp_path(self, k: int) -> str:
         return os.path.join(self.dir, f"{self.name}-{self.split}.tfrecord-{k:05d}.tmp")
@@ -273,10 +348,10 @@ class EpisodeWriter:
             r = np.asarray(o["overhead_camera/rgb"], np.uint8)
             d = np.asarray(o["overhead_camera/depth"], np.float32)
             assert r.shape == (self.h, self.w, 3) and d.shape == (self.h, self.w), (r.shape, d.shape)
-            rgb.append(r.tobytes())
+            rgb.append(r.reshape(-1))
             depth.append(d.reshape(-1))
         feats = {
-            "steps/observation/overhead_camera/rgb": rgb,
+            "steps/observation/overhead_camera/rgb": np.concatenate(rgb) if rgb else np.zeros(0, np.uint8),
             "steps/observation/overhead_camera/depth": np.concatenate(depth) if depth else np.zeros(0, np.float32),
             "steps/action/pose": np.concatenate([np.asarray(a["pose"], np.float64).reshape(7) for a in acts]),
             "steps/action/pixel_coords": np.concatenate([np.asarray(a["pixel_coords"], np.int64).reshape(2) for a in acts]),
@@ -287,12 +362,22 @@ class EpisodeWriter:
             "steps/is_last": np.asarray([int(bool(s.get("is_last", k == T - 1))) for k, s in enumerate(steps)], np.int64),
             "steps/is_terminal": np.asarray([int(bool(s.get("is_terminal", False))) for s in steps], np.int64),
         }
-        for grp in ("intrinsics", "extrinsics"):
+        for grp in ("intrinsics", "extrinsics"):       # episode_metadata_info entries: top-level features
             for k, v in metadata[grp].items():
-                feats[f"episode_metadata/{grp}/{k}"] = np.asarray([float(v)])
-        write_record(self._file, encode_example(feats))
+                feats[f"{grp}/{k}"] = np.asarray([float(v)])
+        payload = encode_example(feats)
+        write_record(self._file, payload)
+        self._bytes += len(payload)
         self._in_file += 1
         self._episodes += 1
+
+    def dataset_info(self) -> dict:
+        """dataset_info.json: proto3 JSON of tfds' DatasetInfo message (int64 fields are strings)."""
+        return {"name": self.name, "version": self.VERSION, "fileFormat": "tfrecord", "moduleName": "",
+                "description": "RLDS episodes of RearrangementEnv (overhead camera, scripted pick / place actions)",
+                "splits": [{"name": self.split, "shardLengths": [str(n) for n in self._shards],
+                            "numBytes": str(self._bytes),
+                            "filepathTemplate": "{DATASET}-{SPLIT}.{FILEFORMAT}-{SHARD_X_OF_Y}"}]}
 
     def close(self) -> dict:
         if self._file is not None:
@@ -302,38 +387,64 @@ class EpisodeWriter:
         n = len(self._shards)
         for k in range(n):
             os.replace(self._tmp_path(k), os.path.join(self.dir, f"{self.name}-{self.split}.tfrecord-{k:05d}-of-{n:05d}"))
-        info = {"name": self.name, "splits": [{"name": self.split, "shard_lengths": self._shards,
-                                               "num_examples": self._episodes}],
-                "file_format": "tfrecord", "record": "tf.train.Example, one episode per record, RLDS step fields under steps/"}
+        info = self.dataset_info()
         with open(os.path.join(self.dir, "dataset_info.json"), "w") as f:
-            json.dump(info, f, indent=1)
+            json.dump(info, f, indent=2)
         with open(os.path.join(self.dir, "features.json"), "w") as f:
-            json.dump(self.features(), f, indent=1)
+            json.dump(self.features(), f, indent=4)
         return info
 
 
-def read_episodes(data_directory: str, name: str, split_name: str = "train") -> Iterator[dict]:
-    """Parses the shards back into {"steps": {...arrays with a leading step axis...}, "episode_metadata": {...}}."""
+_NP_DTYPE = {"uint8": np.uint8, "int32": np.int32, "int64": np.int64, "bool": np.bool_, "float32": np.float32,
+             "float64": np.float64}
+
+
+def _nest(tree: dict, key: str, leaf_names, value):
+    """Put `value` at the path of `key` in a nested dict; `leaf_names` are the feature names on the way (a name may
+    contain '/' itself, e.g. overhead_camera/rgb)."""
+    node = tree
+    for name in leaf_names[:-1]:
+        node = node.setdefault(name, {})
+    node[leaf_names[-1]] = value
+
+
+def _leaf_paths(node: dict, path=()):
+    if "featuresDict" in node:
+        for k, v in node["featuresDict"]["features"].items():
+            yield from _leaf_paths(v, path + (k,))
+    elif "sequence" in node:
+        yield from _leaf_paths(node["sequence"]["feature"], path)
+    else:
+        yield path
+
+
+def read_episodes(data_directory: str, name: Optional[str] = None, split_name: str = "train") -> Iterator[dict]:
+    """Generic reader of a TFDS directory of this kind: dataset_info.json names the dataset, its split and shard
+    count, features.json says how every Example key is typed and shaped.  Yields nested dicts shaped like the
+    feature tree ({"steps": {...arrays with a leading step axis...}, "intrinsics": {...}, "extrinsics": {...}})."""
     with open(os.path.join(data_directory, "features.json")) as f:
         feat = json.load(f)
-    h, w, _ = feat["steps"]["observation"]["overhead_camera/rgb"]["shape"]
-    files = sorted(p for p in os.listdir(data_directory) if p.startswith(f"{name}-{split_name}.tfrecord-"))
-    for p in files:
-        for rec in read_records(os.path.join(data_directory, p)):
+    with open(os.path.join(data_directory, "dataset_info.json")) as f:
+        info = json.load(f)
+    name = name or info["name"]
+    split = next(sp for sp in info["splits"] if sp["name"] == split_name)
+    n = len(split["shardLengths"])
+    leaves = list(feature_leaves(feat))
+    paths = list(_leaf_paths(feat))
+    for k in range(n):
+        p = os.path.join(data_directory, f"{name}-{split_name}.{info['fileFormat']}-{k:05d}-of-{n:05d}")
+        count = 0
+        for rec in read_records(p):
             e = decode_example(rec)
-            T = len(e["steps/reward"])
-            rgb = np.stack([np.frombuffer(b, np.uint8).reshape(h, w, 3) for b in e["steps/observation/overhead_camera/rgb"]])
-            steps = {"observation": {"overhead_camera/rgb": rgb,
-                                     "overhead_camera/depth": e["steps/observation/overhead_camera/depth"].reshape(T, h, w)},
-                     "action": {"pose": e["steps/action/pose"].reshape(T, 7),
-                                "pixel_coords": e["steps/action/pixel_coords"].reshape(T, 2),
-                                "gripper_rot": e["steps/action/gripper_rot"]},
-                     "reward": e["steps/reward"], "discount": e["steps/discount"],
-                     "is_first": e["steps/is_first"].astype(bool), "is_last": e["steps/is_last"].astype(bool),
-                     "is_terminal": e["steps/is_terminal"].astype(bool)}
-            meta = {g: {k.split("/")[-1]: float(v[0]) for k, v in e.items() if k.startswith(f"episode_metadata/{g}/")}
-                    for g in ("intrinsics", "extrinsics")}
-            yield {"steps": steps, "episode_metadata": meta}
+            out: dict = {}
+            for (key, shape, dtype, seq), path in zip(leaves, paths):
+                v = np.asarray(e[key])
+                v = v.reshape((-1,) + shape) if seq else v.reshape(shape)
+                _nest(out, key, path, v.astype(_NP_DTYPE[dtype]))
+            count += 1
+            yield out
+        if count != int(split["shardLengths"][k]):
+            raise ValueError(f"{p}: {count} records, dataset_info.json says {split['shardLengths'][k]}")
 
 
 class BatchedEpisodeLogger:

@@ -62,7 +62,9 @@ def test_batched_logger_round_trip(tmp_path):
             log.step(act, t, active)
             seen.append((act, t, active))
     info = w.close()
-    assert info["splits"][0]["shard_lengths"] == [2, 2, 1] and info["splits"][0]["num_examples"] == N
+    assert info["splits"][0]["shardLengths"] == ["2", "2", "1"] and info["version"] == "0.0.1"
+    sizes = [os.path.getsize(os.path.join(tmp_path, p)) for p in os.listdir(tmp_path) if "tfrecord" in p]
+    assert int(info["splits"][0]["numBytes"]) == sum(sizes) - 16 * N   # payloads without the 16 framing bytes per record
     files = sorted(p for p in os.listdir(tmp_path) if "tfrecord" in p)
     assert files == [f"colour_splitter_test-train.tfrecord-{k:05d}-of-00003" for k in range(3)]
     eps = list(D.read_episodes(str(tmp_path), "colour_splitter_test"))
@@ -77,8 +79,63 @@ def test_batched_logger_round_trip(tmp_path):
         assert np.allclose(s["action"]["pose"][0], act["pose"][i], atol=1e-6)
         assert s["action"]["pixel_coords"][0].tolist() == act["pixel_coords"][i].tolist()
         assert np.array_equal(s["observation"]["overhead_camera/depth"][1], t.observation["overhead_camera/depth"][i])
-        assert abs(e["episode_metadata"]["intrinsics"]["fx"] + 405.0) < 1e-6
-        assert abs(e["episode_metadata"]["extrinsics"]["qw"] - 0.9) < 1e-6
+        assert s["observation"]["overhead_camera/rgb"].dtype == np.uint8 and s["action"]["pixel_coords"].dtype == np.int32
+        assert s["is_first"].dtype == np.bool_ and s["reward"].dtype == np.float64
+        assert abs(e["intrinsics"]["fx"] + 405.0) < 1e-6      # episode_metadata_info entries are top-level features
+        assert abs(e["extrinsics"]["qw"] - 0.9) < 1e-6
+
+
+def test_metadata_files_follow_the_tfds_schema(tmp_path):
+    """features.json / dataset_info.json as tfds writes them (proto3 JSON of feature.proto / dataset_info.proto):
+    spelled out by hand for the reference's ds_config (transporter_network_data_generation.py:56-86)."""
+    import json
+    w = D.EpisodeWriter(str(tmp_path), "colour_splitter_x", 480, 640, max_episodes_per_file=10)
+    w.close()
+    f = json.load(open(tmp_path / "features.json"))
+    pkg = "tensorflow_datasets.core.features."
+    assert f["pythonClassName"] == pkg + "features_dict.FeaturesDict"
+    top = f["featuresDict"]["features"]
+    assert sorted(top) == ["extrinsics", "intrinsics", "steps"]       # rlds_base.build_info: {steps, **episode_metadata}
+    assert top["steps"]["pythonClassName"] == pkg + "dataset_feature.Dataset" and top["steps"]["sequence"]["length"] == "-1"
+    step = top["steps"]["sequence"]["feature"]["featuresDict"]["features"]
+    assert sorted(step) == ["action", "discount", "is_first", "is_last", "is_terminal", "observation", "reward"]
+    assert step["observation"]["featuresDict"]["features"]["overhead_camera/rgb"] == {
+        "pythonClassName": pkg + "tensor_feature.Tensor",
+        "tensor": {"shape": {"dimensions": ["480", "640", "3"]}, "dtype": "uint8", "encoding": "none"}}
+    assert step["observation"]["featuresDict"]["features"]["overhead_camera/depth"]["tensor"] == {
+        "shape": {"dimensions": ["480", "640"]}, "dtype": "float32", "encoding": "none"}
+    act = step["action"]["featuresDict"]["features"]
+    assert act["pose"]["tensor"] == {"shape": {"dimensions": ["7"]}, "dtype": "float64", "encoding": "none"}
+    assert act["pixel_coords"]["tensor"]["dtype"] == "int32"
+    assert act["gripper_rot"] == {"pythonClassName": pkg + "scalar.Scalar",
+                                  "tensor": {"shape": {}, "dtype": "float64", "encoding": "none"}}
+    assert step["is_terminal"]["tensor"]["dtype"] == "bool" and step["reward"]["tensor"]["dtype"] == "float64"
+    assert sorted(top["extrinsics"]["featuresDict"]["features"]) == ["qw", "qx", "qy", "qz", "x", "y", "z"]
+    keys = {k: (shape, dtype, seq) for k, shape, dtype, seq in D.feature_leaves(f)}
+    assert keys["steps/observation/overhead_camera/rgb"] == ((480, 640, 3), "uint8", True)
+    assert keys["intrinsics/fx"] == ((), "float64", False) and len(keys) == 21
+    info = json.load(open(tmp_path / "dataset_info.json"))
+    assert info["name"] == "colour_splitter_x" and info["fileFormat"] == "tfrecord"
+    assert info["splits"] == [{"name": "train", "shardLengths": [], "numBytes": "0",
+                               "filepathTemplate": "{DATASET}-{SPLIT}.{FILEFORMAT}-{SHARD_X_OF_Y}"}]
+
+
+def test_uint8_tensor_goes_to_an_int64_list_like_tfds():
+    """tfds.features.Tensor(dtype=uint8) with the default Encoding.NONE: one varint per byte in an int64_list
+    (values >= 128 take two bytes).  Key order inside the map is sorted, as TFDS's serializer emits it."""
+    img = np.array([0, 127, 128, 255], np.uint8)
+    got = D.encode_example({"x": img})
+    packed = bytes([0x00, 0x7F, 0x80, 0x01, 0xFF, 0x01])
+    int64_list = bytes([0x0A, len(packed)]) + packed
+    feature = bytes([0x1A, len(int64_list)]) + int64_list
+    entry = bytes([0x0A, 1]) + b"x" + bytes([0x12, len(feature)]) + feature
+    features = bytes([0x0A, len(entry)]) + entry
+    assert got == bytes([0x0A, len(features)]) + features
+    assert D.decode_example(got)["x"].tolist() == [0, 127, 128, 255]
+    big = np.random.RandomState(1).randint(0, 256, 100000).astype(np.uint8)
+    assert np.array_equal(D.decode_example(D.encode_example({"i": big}))["i"], big)
+    neg = np.array([-1, 5, 1 << 40])
+    assert D.decode_example(D.encode_example({"n": neg}))["n"].tolist() == neg.tolist()
 
 
 def test_tfrecord_detects_corruption(tmp_path):

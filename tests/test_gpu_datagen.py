@@ -161,3 +161,67 @@ def test_datagen_loop_8192_envs_properties():
     done = ~env.sort_colours()[0]
     print(f"{int(done.sum())} of {N} envs have every cube in its colour's zone after one pair")
     env.close()
+
+
+def test_env_to_tfds_shards_8_envs(tmp_path):
+    """SURVEY 8(f).3 end to end: BatchedRearrangementEnv(render=True) -> BatchedEpisodeLogger -> TFDS-format shards
+    (transporter_network_data_generation.py:97-143 with envlogger's TFDSBackendWriter) -> read back by the
+    features.json-driven reader.  The first stored image is the camera's image of the post-reset state
+    (`mre_render`), step fields follow the RLDS convention, metadata = get_camera_metadata()."""
+    import json
+    import os
+    from mujoco_robot_environments_amd import dataset as D
+    from mujoco_robot_environments_amd.tasks.rearrangement import BatchedRearrangementEnv, colour_separator_task_config
+    N = 8
+    cfg = colour_separator_task_config()
+    env = BatchedRearrangementEnv(cfg=cfg, num_envs=N, seed=5, solver="Newton", render=True)
+    ts0 = env.reset()
+    rgb0 = ts0.observation["overhead_camera/rgb"].cpu().numpy().copy()
+    depth0 = ts0.observation["overhead_camera/depth"].cpu().numpy().copy()
+    again = env.render(rgb=True, depth=True)            # a second mre_render of the same state: same bytes
+    assert np.array_equal(again["overhead_camera/rgb"].cpu().numpy(), rgb0)
+    cam = "overhead_camera/overhead_camera"
+    name = f"{cfg.name}_test"
+    w = D.EpisodeWriter(str(tmp_path), name, env.overhead_camera_height, env.overhead_camera_width,
+                        max_episodes_per_file=cfg.dataset.max_episodes_per_file)
+    in_progress, pick, place = env.sort_colours()
+    assert in_progress.any()
+    acts = []
+    with D.BatchedEpisodeLogger(env, w) as log:
+        log.reset(ts0)
+        for pose in (pick, place):
+            a = {"pose": pose.copy(), "pixel_coords": env.world_2_pixel(cam, pose[:, :3]), "gripper_rot": 0.0}
+            acts.append({k: np.array(v).copy() if not np.isscalar(v) else v for k, v in a.items()})
+            ts = env.step(a)
+            log.step(a, ts, in_progress)
+    info = w.close()
+    assert info["splits"][0]["shardLengths"] == [str(N)]                       # 8 episodes, 10 per file
+    assert os.path.exists(os.path.join(tmp_path, f"{name}-train.tfrecord-00000-of-00001"))
+    feats = json.load(open(os.path.join(tmp_path, "features.json")))
+    dims = feats["featuresDict"]["features"]["steps"]["sequence"]["feature"]["featuresDict"]["features"]["observation"][
+        "featuresDict"]["features"]["overhead_camera/rgb"]["tensor"]["shape"]["dimensions"]
+    assert dims == ["480", "640", "3"]                                         # transporter_data_collection.yaml:4-5
+    meta = env.get_camera_metadata()
+    eps = list(D.read_episodes(str(tmp_path)))
+    assert len(eps) == N
+    for i, e in enumerate(eps):
+        s = e["steps"]
+        T = 3 if in_progress[i] else 1       # reset step + one step per env.step() of an env still in progress
+        assert s["reward"].shape == (T,)
+        assert s["is_first"].tolist() == [True] + [False] * (T - 1)
+        assert s["is_last"].tolist() == [False] * (T - 1) + [True] and not s["is_terminal"].any()
+        assert np.array_equal(s["observation"]["overhead_camera/rgb"][0], rgb0[i])          # = mre_render's image
+        assert np.array_equal(s["observation"]["overhead_camera/depth"][0], depth0[i])
+        if T == 3:
+            # RLDS: the action is stored with the step it was taken from; float64 poses pass through a float_list
+            assert np.allclose(s["action"]["pose"][0], acts[0]["pose"][i], atol=1e-6)
+            assert np.allclose(s["action"]["pose"][1], acts[1]["pose"][i], atol=1e-6)
+            assert s["action"]["pixel_coords"][0].tolist() == np.asarray(acts[0]["pixel_coords"][i]).tolist()
+            assert (s["action"]["pose"][2] == 0).all()                                       # last step: no action
+            # the observation of step k + 1 is what env.step returned: rendered BEFORE the action ran (App. D.1),
+            # so the image stored after the pick still shows the post-reset scene
+            assert np.array_equal(s["observation"]["overhead_camera/rgb"][1], rgb0[i])
+        for grp in ("intrinsics", "extrinsics"):
+            for k, v in meta[grp].items():
+                assert abs(float(e[grp][k]) - float(v)) <= 1e-6 * max(1.0, abs(float(v)))
+    env.close()
