@@ -76,6 +76,11 @@ typedef struct {
 struct mro_data {
   /* per-env model parameters */
   int nprops, freeze_robot, no_constraints, ncon_cap, nefc_cap, nrrow_cap, npp_cap, overflow;
+  int round32;   /* diagnostic (mro_set_round32): intermediate arrays rounded to float32, see mre_oracle.h */
+  /* diagnostic (mro_set_emulation): a device-like error on the solver's output and the device's cure for it */
+  double emu_rel_arm, emu_abs_finger;
+  int emu_polish;
+  unsigned long long emu_rng;
   int body_active[MRO_MAXB], dof_active[MRO_MAXV];
   double body_mass[MRO_MAXB], body_inertia[MRO_MAXB][3], body_invweight0[MRO_MAXB][2],
       dof_invweight0[MRO_MAXV], geom_size[MRO_MAXG][3], geom_rbound[MRO_MAXG];
@@ -383,6 +388,12 @@ void mro_data_free(mro_data* d) {
   if (d) { free(d->efc_AR); free(d->efc_B); free(d); }
 }
 void mro_set_freeze_robot(mro_data* d, int f) { d->freeze_robot = f; }
+void mro_set_round32(mro_data* d, int mask) { d->round32 = mask; }
+void mro_set_emulation(mro_data* d, double rel_arm, double abs_finger, int polish, unsigned long long seed) {
+  d->emu_rel_arm = rel_arm; d->emu_abs_finger = abs_finger; d->emu_polish = polish;
+  d->emu_rng = seed * 0x9E3779B97F4A7C15ull + 0x1234567ull;
+}
+static void round32(double* v, int n) { for (int i = 0; i < n; i++) v[i] = (double)(float)v[i]; }
 void mro_set_no_constraints(mro_data* d, int f) { d->no_constraints = f; }
 void mro_set_caps(mro_data* d, int ncon_cap, int nefc_cap, int nrrow_cap, int npp_cap) {
   d->ncon_cap = ncon_cap; d->nefc_cap = nefc_cap; d->nrrow_cap = nrrow_cap; d->npp_cap = npp_cap;
@@ -1047,10 +1058,14 @@ static void fwd_position(const mro_model* m, mro_data* d) {
   com_pos(m, d);
   tendon(m, d);
   crb(m, d);
+  if (d->round32 & 4) round32(d->qM, m->nM);
   factor_m(m, d);
   collision(m, d);
   make_constraint(m, d);
+  if (d->round32 & 1) for (int i = 0; i < d->nefc; i++) round32(d->efc_J[i], m->nv);
+  if (d->round32 & 64) round32(d->efc_pos, d->nefc);
   make_impedance(m, d);
+  if (d->round32 & 128) { round32(d->efc_R, d->nefc); for (int i = 0; i < d->nefc; i++) d->efc_D[i] = 1.0 / d->efc_R[i]; }
   project_constraint(m, d);
 }
 
@@ -1123,7 +1138,9 @@ static void fwd_velocity(const mro_model* m, mro_data* d) {
   com_vel(m, d);
   passive(m, d);
   reference_constraint(m, d);
+  if (d->round32 & 2) round32(d->efc_aref, d->nefc);
   rne(m, d);
+  if (d->round32 & 256) round32(d->qfrc_bias, m->nv);
 }
 
 /* ------------------------------------------------------- mj_fwdActuation */
@@ -1164,7 +1181,9 @@ static void fwd_acceleration(const mro_model* m, mro_data* d) {
                             : 0.0;
     d->qacc_smooth[i] = d->qfrc_smooth[i];
   }
+  if (d->round32 & 8) round32(d->qfrc_smooth, m->nv);
   solve_ld(m, d->qLD, d->qLDiagInv, d->qacc_smooth);
+  if (d->round32 & 8) round32(d->qacc_smooth, m->nv);
 }
 
 /* -------------------------------------------- mj_constraintUpdate (force) */
@@ -1715,6 +1734,7 @@ static void integrate(const mro_model* m, mro_data* d) {
   for (int i = 0; i < nv; i++) qfrc[i] = d->qfrc_smooth[i] + d->qfrc_constraint[i];
   memcpy(qa, qfrc, sizeof(double) * nv);
   solve_ld(m, MH, diaginv, qa);
+  if (d->round32 & 32) round32(qa, nv);
   double rq[MRO_MAXQ], rv[MRO_MAXV];
   if (d->freeze_robot) { memcpy(rq, d->qpos, sizeof(rq)); memcpy(rv, d->qvel, sizeof(rv)); }
   for (int i = 0; i < nv; i++)
@@ -1751,10 +1771,84 @@ static void step1(const mro_model* m, mro_data* d) {
   fwd_position(m, d);
   fwd_velocity(m, d);
 }
+/* Diagnostic (tests/diagnostics/finger_precision_study.py): what a float32 solver leaves behind, and the cure.
+ * The converged qacc gets a relative error on the arm dofs and an absolute error on the finger dofs (Gaussian,
+ * fresh every step); then, optionally, the dofs [lo, 15) are polished: Newton steps on THAT block of the primal
+ * problem with the exact gradient and the exact block of the Hessian, every other dof held where it is (polish 1:
+ * the eight finger dofs, 2: the robot's fifteen).  The integrator then sees forces consistent with the result
+ * (qfrc_constraint = M qacc - qfrc_smooth), which is how the device integrates. */
+static double emu_gauss(mro_data* d) {
+  double u[2];
+  for (int k = 0; k < 2; k++) {
+    d->emu_rng ^= d->emu_rng << 13; d->emu_rng ^= d->emu_rng >> 7; d->emu_rng ^= d->emu_rng << 17;
+    u[k] = ((d->emu_rng >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+  }
+  return sqrt(-2.0 * log(u[0])) * cos(6.283185307179586 * u[1]);
+}
+static void emulate_device_solver(const mro_model* m, mro_data* d) {
+  int nv = m->nv, n = d->nefc;
+  if (d->no_constraints || n == 0) return;
+  double a[MRO_MAXV], Ma[MRO_MAXV], jar[MRO_MAXEFC], g[MRO_MAXV];
+  memcpy(a, d->qacc, sizeof(double) * nv);
+  for (int k = 0; k < 7; k++) a[k] *= 1.0 + d->emu_rel_arm * emu_gauss(d);
+  for (int k = 7; k < 15; k++) a[k] += d->emu_abs_finger * emu_gauss(d);
+  int lo = d->emu_polish == 2 ? 0 : 7, nb = 15 - lo;
+  for (int it = 0; d->emu_polish && it < 3; it++) {
+    mul_jac(d, nv, jar, a);
+    for (int i = 0; i < n; i++) jar[i] -= d->efc_aref[i];
+    constraint_update_full(m, d, jar, d->efc_force, d->efc_state, 1);
+    mul_m(m, d, Ma, a);
+    for (int k = 0; k < nv; k++) g[k] = Ma[k] - d->qfrc_smooth[k];
+    for (int i = 0; i < n; i++)
+      for (int k = 0; k < nv; k++) g[k] -= d->efc_J[i][k] * d->efc_force[i];
+    double H[15 * 15] = {0}, e[MRO_MAXV], col[MRO_MAXV];
+    for (int p = 0; p < nb; p++) {     /* block of M by columns */
+      memset(e, 0, sizeof(e)); e[lo + p] = 1.0;
+      mul_m(m, d, col, e);
+      for (int q = 0; q < nb; q++) H[q * nb + p] = col[lo + q];
+    }
+    for (int i = 0; i < n;) {
+      int st = d->efc_state[i];
+      if (st == ST_CONE) {
+        const double* Hc = d->contact[d->efc_id[i]].H;
+        for (int p = 0; p < 3; p++) for (int q = 0; q < 3; q++)
+          for (int x = 0; x < nb; x++) for (int y = 0; y < nb; y++)
+            H[x * nb + y] += Hc[3 * p + q] * d->efc_J[i + p][lo + x] * d->efc_J[i + q][lo + y];
+        i += 3; continue;
+      }
+      if (st == ST_QUADRATIC)
+        for (int x = 0; x < nb; x++) for (int y = 0; y < nb; y++)
+          H[x * nb + y] += d->efc_D[i] * d->efc_J[i][lo + x] * d->efc_J[i][lo + y];
+      i++;
+    }
+    /* Cholesky solve H delta = -g on the block */
+    for (int j = 0; j < nb; j++) {
+      double t = H[j * nb + j];
+      for (int k = 0; k < j; k++) t -= H[j * nb + k] * H[j * nb + k];
+      t = sqrt(t > MINVAL ? t : MINVAL);
+      H[j * nb + j] = t;
+      for (int i = j + 1; i < nb; i++) {
+        double u = H[i * nb + j];
+        for (int k = 0; k < j; k++) u -= H[i * nb + k] * H[j * nb + k];
+        H[i * nb + j] = u / t;
+      }
+    }
+    double x[15];
+    for (int i = 0; i < nb; i++) { double t = -g[lo + i]; for (int k = 0; k < i; k++) t -= H[i * nb + k] * x[k]; x[i] = t / H[i * nb + i]; }
+    for (int i = nb - 1; i >= 0; i--) { double t = x[i]; for (int k = i + 1; k < nb; k++) t -= H[k * nb + i] * x[k]; x[i] = t / H[i * nb + i]; }
+    for (int i = 0; i < nb; i++) a[lo + i] += x[i];
+  }
+  memcpy(d->qacc, a, sizeof(double) * nv);
+  mul_m(m, d, Ma, a);
+  for (int k = 0; k < nv; k++) d->qfrc_constraint[k] = Ma[k] - d->qfrc_smooth[k];
+}
+
 static void step2(const mro_model* m, mro_data* d) {
   fwd_actuation(m, d);
   fwd_acceleration(m, d);
   fwd_constraint(m, d);
+  if (d->emu_rel_arm > 0 || d->emu_abs_finger > 0 || d->emu_polish) emulate_device_solver(m, d);
+  if (d->round32 & 16) { round32(d->qacc, m->nv); round32(d->qfrc_constraint, m->nv); }
   integrate(m, d);
 }
 void mro_forward(const mro_model* m, mro_data* d) {

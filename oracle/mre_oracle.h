@@ -53,6 +53,15 @@ void mro_forward(const mro_model*, mro_data*);
 void mro_step(const mro_model*, mro_data*, int nstep);
 /* freeze_robot != 0 reproduces JointStaticIsolator (prop_initializer.py:246) */
 void mro_set_freeze_robot(mro_data*, int freeze);
+/* Diagnostic (tests/diagnostics/finger_precision_study.py): round intermediate arrays to float32 where they are
+ * produced -- 1 efc_J, 2 efc_aref, 4 qM, 8 qfrc_smooth + qacc_smooth, 16 qacc + qfrc_constraint (solver output),
+ * 32 the implicit integrator's acceleration, 64 efc_pos, 128 efc_R / efc_D, 256 qfrc_bias.  0 = the plain fp64 oracle. */
+void mro_set_round32(mro_data*, int mask);
+/* Diagnostic: after every solve the converged qacc gets a Gaussian error (relative `rel_arm` on the 7 arm dofs,
+ * absolute `abs_finger` rad/s^2 on the 8 finger dofs) and is then, optionally, polished by exact Newton steps on a
+ * block of dofs with the others held (polish 1: finger dofs, 2: all robot dofs) -- mre_oracle.c:
+ * emulate_device_solver.  All zeros = the plain oracle. */
+void mro_set_emulation(mro_data*, double rel_arm, double abs_finger, int polish, unsigned long long seed);
 /* test switches: drop all constraints (smooth-dynamics parity slice); emulate the
  * device capacity limits (active contacts / rows beyond the caps are dropped) */
 void mro_set_no_constraints(mro_data*, int flag);

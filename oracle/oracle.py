@@ -50,6 +50,8 @@ def lib() -> C.CDLL:
         L.mro_set_freeze_robot.argtypes = [C.c_void_p, C.c_int]
         L.mro_solver_iters.argtypes = [C.c_void_p]
         L.mro_set_no_constraints.argtypes = [C.c_void_p, C.c_int]
+        L.mro_set_round32.argtypes = [C.c_void_p, C.c_int]
+        L.mro_set_emulation.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_ulonglong]
         L.mro_set_caps.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
         L.mro_overflow.argtypes = [C.c_void_p]
         L.mro_set_solver.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double]
@@ -129,6 +131,14 @@ class Env:
 
     def freeze_robot(self, flag: bool):
         lib().mro_set_freeze_robot(self.ptr, int(flag))
+
+    def round32(self, mask: int):
+        """Diagnostic: round intermediate arrays to float32 (bit mask, oracle/mre_oracle.h)."""
+        lib().mro_set_round32(self.ptr, int(mask))
+
+    def emulate(self, rel_arm: float = 0.0, abs_finger: float = 0.0, polish: int = 0, seed: int = 1):
+        """Diagnostic: device-like solver error + block polish (oracle/mre_oracle.h: mro_set_emulation)."""
+        lib().mro_set_emulation(self.ptr, float(rel_arm), float(abs_finger), int(polish), int(seed))
 
     def no_constraints(self, flag: bool):
         lib().mro_set_no_constraints(self.ptr, int(flag))

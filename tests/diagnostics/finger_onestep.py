@@ -1,0 +1,89 @@
+"""One-step error of the device on the robot's accelerations (GPU diagnostic, not a test).
+
+64 envs of the bench's action law are rolled out on the fp64 oracle; at every probed step the device is put on the
+oracle's state (mre_set_state_f64: the robot's joints keep their fp64 values, the cubes' coordinates are rounded to
+float32 on BOTH sides), both take ONE step with the same control, and the velocity changes are compared:
+(dv_device - dv_oracle) / h is the error of the acceleration the device integrated, free of any drift.
+
+    python tests/diagnostics/finger_onestep.py [solver=Newton] [probes=40]
+"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+from mujoco_robot_environments_amd import rng  # noqa: E402
+from mujoco_robot_environments_amd.model import compile as MC  # noqa: E402
+from mujoco_robot_environments_amd.physics import BatchedPhysics  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+from tests.common import init_oracle_env  # noqa: E402
+
+
+def main():
+    solver = sys.argv[1] if len(sys.argv) > 1 else "Newton"
+    probes = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+    N, seed, scale, cs, T0 = 64, 5, 1.0, 5, 300
+    A = MC.compile_scene()
+    om = O.Model(MC.to_blob(A))
+    ids = np.arange(N)
+    nprops, sizes = rng.prop_params(seed, ids)
+    acts = rng.random_actions(seed, ids, np.arange(T0 // cs + probes + 2), scale=scale).astype(np.float32).astype(np.float64)
+    yaws = rng.uniform(seed + 7, ids, [0], 4)[0] * np.pi
+    phys = BatchedPhysics(N, model=A, solver=solver)
+    phys.set_props(nprops, sizes)
+    phys.reset()
+    parked = phys.qpos().astype(np.float64)
+    envs = []
+    for i in range(N):
+        e = O.Env(om, int(nprops[i]), sizes[i])
+        e.set_solver(solver)
+        q0 = init_oracle_env(e, int(nprops[i]), sizes[i], z_extra=0.0005, yaw=yaws[i])
+        e.arr("qpos")[:43] = parked[i]
+        e.arr("qpos")[:15 + 7 * int(nprops[i])] = q0[:15 + 7 * int(nprops[i])].astype(np.float32)
+        e.forward()
+        envs.append(e)
+    for i, e in enumerate(envs):          # warm-up on the oracle alone
+        for t in range(T0 // cs):
+            e.arr("ctrl")[:] = acts[t, i]
+            e.step(cs)
+    h = 0.001
+    errs, accs = [], []
+    for k in range(probes):
+        t = T0 // cs + k
+        q = np.zeros((N, 43)); v = np.zeros((N, 39)); ws = np.zeros((N, 39), np.float32)
+        for i, e in enumerate(envs):
+            for nm in ("qpos", "qvel"):
+                a = e.arr(nm)
+                a[15:] = a[15:].astype(np.float32)       # the cubes' state is float32 on the device
+            e.forward()
+            q[i], v[i], ws[i] = e.arr("qpos")[:43], e.arr("qvel")[:39], e.arr("qacc_warmstart")[:39]
+        phys.set_state_f64(q, v)
+        phys.set_warmstart(ws)
+        phys.set_control(acts[t].astype(np.float32))
+        phys.step(1)
+        phys.sync()
+        _, v1 = phys.get_state_f64()
+        dvo = np.zeros((N, 39))
+        for i, e in enumerate(envs):
+            e.arr("ctrl")[:] = acts[t, i]
+            e.step(1)
+            dvo[i] = e.arr("qvel")[:39] - v[i]
+            e.step(cs - 1)                               # move on (a fresh state for the next probe)
+        errs.append(((v1 - v) - dvo)[:, :15] / h)
+        accs.append(dvo[:, :15] / h)
+    err = np.abs(np.stack(errs))          # [probes, N, 15]
+    acc = np.abs(np.stack(accs))
+    names = ["arm%d" % j for j in range(7)] + ["f%d" % j for j in range(8)]
+    print(f"{solver}: one-step error of the integrated acceleration [rad/s^2], {probes} probes x {N} envs")
+    for d in range(15):
+        e = err[:, :, d].reshape(-1)
+        print(f"  {names[d]:5s} |acc| median {np.median(acc[:, :, d]):9.3g}   err median {np.median(e):.2e}  90% {np.quantile(e, 0.9):.2e}  "
+              f"99% {np.quantile(e, 0.99):.2e}  max {e.max():.2e}")
+    f = err[:, :, 7:15]
+    print(f"fingers: rms {np.sqrt((f ** 2).mean()):.2e}  median {np.median(f):.2e}  max {f.max():.2e};  arm: rms "
+          f"{np.sqrt((err[:, :, :7] ** 2).mean()):.2e} max {err[:, :, :7].max():.2e}")
+
+
+if __name__ == "__main__":
+    main()

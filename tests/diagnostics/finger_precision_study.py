@@ -1,0 +1,146 @@
+"""CPU-only experiment behind the fp64 finger state: which part of a float32 state is it that
+takes the 2F-85 finger coordinates past the 1e-4 bar within 1000 steps?
+
+The fp64 oracle is stepped on the two 64-env workloads of tests/test_gpu_newton.py (gentle law, bench law) and,
+beside the plain run, with its state rounded after every step:
+  all         qpos / qvel / warm start of every dof -> float32   (what the device did in round 2)
+  not_finger  everything but the 8 finger dofs -> float32        (what a device with an fp64 finger state keeps)
+  finger      only the 8 finger dofs -> float32
+  not_finger+noise  as not_finger, plus a random error of `sigma` rad/s^2 on the finger accelerations of every
+              step (the device's one-step finger qacc error against the oracle, DESIGN section 4: 2e-5)
+Printed: envs under the bar on all 43 coordinates after 1000 steps.
+
+    python tests/diagnostics/finger_precision_study.py [N=64]
+"""
+import concurrent.futures as cf
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+from mujoco_robot_environments_amd import rng  # noqa: E402
+from mujoco_robot_environments_amd.model import compile as MC  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+from tests.common import init_oracle_env  # noqa: E402
+
+TOL = 1e-4
+FING = slice(7, 15)
+
+
+def run(om, law, N, mode, sigma=0.0, T=200, cs=5, rmask=0, emu=None):
+    scale, seed, gcomp = law
+    ids = np.arange(N)
+    nprops, sizes = rng.prop_params(seed, ids)
+    acts = rng.random_actions(seed, ids, np.arange(T), scale=scale)
+    yaws = rng.uniform(seed + 7, ids, [0], 4)[0] * np.pi
+    q0 = np.zeros((N, 43))
+    bias = None
+    for i in range(N):
+        e = O.Env(om, int(nprops[i]), sizes[i])
+        e.set_solver("Newton")
+        q0[i] = init_oracle_env(e, int(nprops[i]), sizes[i], z_extra=0.0005, yaw=yaws[i]).astype(np.float32)
+        if i == 0:
+            e.arr("qpos")[:43] = q0[i]
+            e.forward()
+            bias = e.arr("qfrc_bias")[:7].copy()
+    if gcomp:
+        acts[:, :, :7] += bias
+    a32 = acts.astype(np.float32).astype(np.float64)
+
+    def one(i):
+        e = O.Env(om, int(nprops[i]), sizes[i])
+        e.set_solver("Newton")
+        # parked slots as the device's reset leaves them are irrelevant to the active coordinates
+        e.arr("qpos")[:43] = q0[i]
+        e.round32(rmask)
+        if emu is not None:
+            e.emulate(emu[0], emu[1], emu[2], seed=1000 + i)
+        e.forward()
+        r = np.random.default_rng(1000 + i)
+        out = np.zeros((T * cs, 44))
+        h = 0.001
+        for t in range(T):
+            e.arr("ctrl")[:] = a32[t, i]
+            for k in range(cs):
+                out[t * cs + k, 43] = e.census    # the constraint set the coming solve sees
+                e.step(1)
+                qp, qv, ws = e.arr("qpos"), e.arr("qvel"), e.arr("qacc_warmstart")
+                if sigma > 0.0:
+                    da = sigma * r.standard_normal(8)
+                    qv[FING] += h * da
+                    qp[FING] += h * h * da
+                if mode != "plain":
+                    for v in (qp, qv, ws):
+                        keep = v[FING].copy()
+                        if mode in ("all", "not_finger"):
+                            v[:] = v.astype(np.float32)
+                        if mode == "not_finger":
+                            v[FING] = keep
+                        if mode == "finger":
+                            v[FING] = keep.astype(np.float32)
+                    if mode == "robot64":          # the robot's 15 dofs keep their fp64 state, the cubes are rounded
+                        for v in (qp, qv, ws):
+                            keep = v[:15].copy()
+                            v[:] = v.astype(np.float32)
+                            v[:15] = keep
+                    if mode == "qpos_only":
+                        keep = qp[FING].copy()
+                        for v in (qp, qv, ws):
+                            v[:] = v.astype(np.float32)
+                        qp[FING] = keep
+                out[t * cs + k, :43] = qp[:43]
+        return out
+    with cf.ThreadPoolExecutor(8) as ex:
+        tr = np.stack(list(ex.map(one, range(N))), axis=1)
+    for i in range(N):
+        tr[:, i, 15 + 7 * int(nprops[i]):43] = 0
+    return tr
+
+
+def main():
+    N = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+    O.build()
+    om = O.Model(MC.to_blob(MC.compile_scene()))
+    for name, law in (("gentle", (0.1, 11, True)), ("bench", (1.0, 5, False))):
+        ref = run(om, law, N, "plain")
+        modes = (("all", 0.0), ("finger", 0.0), ("not_finger", 0.0), ("qpos_only", 0.0), ("not_finger", 2e-5),
+                 ("not_finger", 2e-4), ("plain", 2e-5), ("plain", 1e-6))
+        if len(sys.argv) > 2:
+            # "r<mask>": the fp64 finger state kept, every other coordinate float32, and the oracle's intermediate
+            # arrays of bit mask <mask> rounded to float32 where they are produced (mro_set_round32)
+            base = "robot64" if "robot64" in sys.argv[2:] else "not_finger"
+            modes = tuple(m for m in modes if m[0] in sys.argv[2:]) + tuple((base, -int(a[1:])) for a in sys.argv[2:] if a[0] == "r" and a[1:].isdigit())
+        # "e<rel_arm>,<abs_finger>,<polish>": robot state fp64, cubes float32, all arrays rounded (r511), plus the
+        # solver-error emulation of mro_set_emulation (polish 0 / 1 = finger block / 2 = robot block)
+        emus = [tuple(float(x) for x in a[1:].split(",")) for a in sys.argv[2:] if a[0] == "e" and "," in a]
+        for em in emus:
+            tr = run(om, law, N, "robot64", 0.0, rmask=511, emu=(em[0], em[1], int(em[2])))
+            err = np.abs(tr - ref)[:, :, :43]
+            switched = [(tr[:, i, 43] != ref[:, i, 43]).any() for i in range(N)]
+            w = err.max(axis=2)
+            first = np.array([np.argmax(w[:, i] > TOL) if w[:, i].max() > TOL else w.shape[0] for i in range(N)])
+            print(f"{name:6s} robot64+r511 emu rel_arm {em[0]:.0e} abs_finger {em[1]:.0e} polish {int(em[2])}: under the bar "
+                  f"{int((first >= w.shape[0]).sum())}/{N}, {sum(switched)} census switches; max err arm {err[:, :, :7].max():.1e} "
+                  f"fingers {err[:, :, 7:15].max():.1e}; worst finger envs without a switch "
+                  f"{sorted([(round(float(err[:, i, 7:15].max()), 7), i) for i in range(N) if not switched[i]])[-3:]}", flush=True)
+        for mode, sigma in modes:
+            rmask = 0
+            if sigma < 0:
+                rmask, sigma = int(-sigma), 0.0
+            tr = run(om, law, N, mode, sigma, rmask=rmask)
+            mode = mode + (f"+r{rmask}" if rmask else "")
+            err = np.abs(tr - ref)[:, :, :43]
+            switched = [(tr[:, i, 43] != ref[:, i, 43]).any() for i in range(N)]
+            sw_at = [int(np.argmax(tr[:, i, 43] != ref[:, i, 43])) if switched[i] else -1 for i in range(N)]
+            w = err.max(axis=2)
+            first = np.array([np.argmax(w[:, i] > TOL) if w[:, i].max() > TOL else w.shape[0] for i in range(N)])
+            print(f"{name:6s} {mode:14s} sigma {sigma:.0e}: under the bar {int((first >= w.shape[0]).sum())}/{N}; "
+                  f"max err arm {err[:, :, :7].max():.1e} fingers {err[:, :, 7:15].max():.1e} cubes {err[:, :, 15:].max():.1e}; "
+                  f"exits (env, step, census switch at) {sorted([(i, int(f), sw_at[i]) for i, f in enumerate(first) if f < w.shape[0]], key=lambda x: x[1])[:8]}; "
+                  f"worst finger envs without a switch {sorted([(round(float(err[:, i, 7:15].max()), 7), i) for i in range(N) if not switched[i]])[-4:]}",
+                  flush=True)
+
+
+if __name__ == "__main__":
+    main()
