@@ -1,8 +1,8 @@
 """Newton iterations per step, device vs oracle, on the bench's action law (last step of every tick).
-usage: python tools/dbg_newton_iters.py [nenvs] [nticks]"""
+usage: python tests/diagnostics/dbg_newton_iters.py [nenvs] [nticks]"""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from mujoco_robot_environments_amd import rng
 from mujoco_robot_environments_amd.model import compile as MC

@@ -1,8 +1,8 @@
 """Per-phase time of the slowest envs of a late bench tick (diagnostic stamp builds 0, 1, 2; the run is
-deterministic, so the three builds see the same envs).  usage: python tools/dbg_straggler_phases.py [tick]"""
+deterministic, so the three builds see the same envs).  usage: python tests/diagnostics/dbg_straggler_phases.py [tick]"""
 import os, subprocess, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 DIAG = os.path.join(ROOT, "tools", "_diag")
 NAMES = ["position+crb+factor", "velocity", "collide", "assemble", "control", "smooth", "solve", "integrate+io",
          "newton: setup", "newton: direction", "newton: direction (re-used)", "newton: search",

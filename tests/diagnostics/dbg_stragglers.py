@@ -1,8 +1,8 @@
 """Which envs end a launch?  Per-env durations of late bench ticks (mre_get_launch_info) next to their
-constraint counts and solver iterations.  usage: python tools/dbg_stragglers.py [PGS|Newton] [nticks]"""
+constraint counts and solver iterations.  usage: python tests/diagnostics/dbg_stragglers.py [PGS|Newton] [nticks]"""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import bench
 from mujoco_robot_environments_amd import rng

@@ -1,7 +1,7 @@
 """Which envs are slow late in the random-action run?  Run twice (deterministic): once with the
 stamps build (per-env solve cycles), once with the product build (per-env ncon/nefc)."""
 import os, sys, subprocess, numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 T = int(os.environ.get("T", "200"))
 if len(sys.argv) > 1 and sys.argv[1] == "child":

@@ -56,6 +56,8 @@ def run(om, law, N, mode, sigma=0.0, T=200, cs=5, rmask=0, emu=None):
         e.round32(rmask)
         if emu is not None:
             e.emulate(emu[0], emu[1], emu[2], seed=1000 + i)
+            if len(emu) > 3:
+                e.bias_noise(emu[3])
         e.forward()
         r = np.random.default_rng(1000 + i)
         out = np.zeros((T * cs, 44))
@@ -115,12 +117,12 @@ def main():
         # solver-error emulation of mro_set_emulation (polish 0 / 1 = finger block / 2 = robot block)
         emus = [tuple(float(x) for x in a[1:].split(",")) for a in sys.argv[2:] if a[0] == "e" and "," in a]
         for em in emus:
-            tr = run(om, law, N, "robot64", 0.0, rmask=511, emu=(em[0], em[1], int(em[2])))
+            tr = run(om, law, N, "robot64", 0.0, rmask=511, emu=(em[0], em[1], int(em[2])) + tuple(em[3:]))
             err = np.abs(tr - ref)[:, :, :43]
             switched = [(tr[:, i, 43] != ref[:, i, 43]).any() for i in range(N)]
             w = err.max(axis=2)
             first = np.array([np.argmax(w[:, i] > TOL) if w[:, i].max() > TOL else w.shape[0] for i in range(N)])
-            print(f"{name:6s} robot64+r511 emu rel_arm {em[0]:.0e} abs_finger {em[1]:.0e} polish {int(em[2])}: under the bar "
+            print(f"{name:6s} robot64+r511 emu rel_arm {em[0]:.0e} abs_finger {em[1]:.0e} polish {int(em[2])} bias noise {em[3] if len(em) > 3 else 0:.0e}: under the bar "
                   f"{int((first >= w.shape[0]).sum())}/{N}, {sum(switched)} census switches; max err arm {err[:, :, :7].max():.1e} "
                   f"fingers {err[:, :, 7:15].max():.1e}; worst finger envs without a switch "
                   f"{sorted([(round(float(err[:, i, 7:15].max()), 7), i) for i in range(N) if not switched[i]])[-3:]}", flush=True)

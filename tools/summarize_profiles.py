@@ -1,10 +1,15 @@
 """Copy one round's rocprofv3 outputs from gpurun_out/ (scratch) into profiles/ (tracked).
 
-usage: python tools/summarize_profiles.py TAG SOLVER STATS_DIR FETCH_DIR WRITE_DIR SQ_DIR FLOP_DIR [BUILD NOTE]
+usage: [BENCH_STEPS=200 BENCH_WARMUP=20] python tools/summarize_profiles.py TAG SOLVER STATS_DIR FETCH_DIR WRITE_DIR SQ_DIR FLOP_DIR [BUILD NOTE]
+  BENCH_STEPS / BENCH_WARMUP: the --steps / --warmup the profiled bench.py command ran with (default: bench.py's own
+  200 / 20; the driver's end-of-round run uses 20 / 5).  They are recorded in the summary, and files of a
+  non-default pair carry the suffix _s<steps>w<warmup>: bench.py only quotes counters taken at ITS arguments, on
+  ITS sources (the summary records lib.source_hash()).
   SOLVER    : PGS (kernel mre::k_step, files TAG_*) or Newton (mre::k_step_newton, files TAG_*_newton)
   STATS_DIR : rocprofv3 --kernel-trace --stats --output-format csv -d STATS_DIR -- python bench.py ...
   FETCH_DIR / WRITE_DIR / SQ_DIR / FLOP_DIR : the separate --pmc passes (never combined with traces
-  other than --kernel-trace); FLOP_DIR (SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F32/F64) may be "-".
+  other than --kernel-trace); FLOP_DIR (SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F32/F64) may be "-"; MFMA_DIR (environment:
+  the SQ_INSTS_VALU_MFMA_MOPS_F32 pass) is optional.
 Writes profiles/TAG_kernel_stats.csv, TAG_pmc_{fetch,write,sq}.csv (k_step rows only) and
 TAG_pmc_summary.json (per-launch means; FETCH_SIZE / WRITE_SIZE are KiB on gfx950).
 """
@@ -20,7 +25,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNELS = {"PGS": "mre::k_step(", "Newton": "mre::k_step_newton("}
 KERNEL = KERNELS["PGS"]
 GROUPS = int(os.environ.get("MRE_GROUPS", "4"))   # env groups per tick (csrc/mre_api.cpp: one launch per group)
-WARMUP = 20 * GROUPS  # bench.py default --warmup ticks
+STEPS = int(os.environ.get("BENCH_STEPS", "200"))
+WARMUP_TICKS = int(os.environ.get("BENCH_WARMUP", "20"))
+WARMUP = WARMUP_TICKS * GROUPS  # the kernel's dispatches that belong to the untimed warm-up ticks
 
 
 def one(pattern):
@@ -46,18 +53,25 @@ def main():
     note = sys.argv[8] if len(sys.argv) > 8 else ""
     KERNEL = KERNELS[solver]
     sfx = "" if solver == "PGS" else "_newton"
+    if (STEPS, WARMUP_TICKS) != (200, 20):
+        sfx += f"_s{STEPS}w{WARMUP_TICKS}"
+    sys.path.insert(0, ROOT)
+    from mujoco_robot_environments_amd import lib as _lib
     out = os.path.join(ROOT, "profiles")
     shutil.copy(one(os.path.join(stats_d, "**", "*kernel_stats.csv")), os.path.join(out, f"{tag}_kernel_stats{sfx}.csv"))
     summary = {
         "command": f"rocprofv3 --pmc <COUNTERS> --kernel-trace --output-format csv -- python bench.py --solver {solver} "
-                   f"--no-cpu-baseline ({WARMUP} warm-up launches dropped, {200 * GROUPS} timed launches averaged; separate passes: FETCH_SIZE | WRITE_SIZE | SQ_* | "
-                   "SQ_INSTS_VALU_*_F32/F64)",
+                   f"--steps {STEPS} --warmup {WARMUP_TICKS} --no-cpu-baseline ({WARMUP} warm-up launches dropped, {STEPS * GROUPS} timed launches averaged; separate passes: FETCH_SIZE | WRITE_SIZE | SQ_* | "
+                   "SQ_INSTS_VALU_*_F32/F64 + MFMA)",
+        "bench_steps": STEPS, "bench_warmup": WARMUP_TICKS, "source_hash": _lib.source_hash(),
         "kernel": KERNEL.rstrip("("), "launch": f"1 env group of 1 control tick = 5 physics steps x {4096 // GROUPS} envs ({GROUPS} launches per tick; "
                    "the counter passes serialise the dispatches, so launch durations in these passes are those of one group alone on the GPU)",
         "envs_per_launch": 4096 // GROUPS, "build": note}
     passes = [("fetch", fetch_d), ("write", write_d), ("sq", sq_d)]
     if flop_d != "-":
         passes.append(("flop", flop_d))
+    if os.environ.get("MFMA_DIR"):
+        passes.append(("mfma", os.environ["MFMA_DIR"]))
     for name, d in passes:
         path, rows = counter_rows(d)
         if not rows:
@@ -93,6 +107,10 @@ def main():
         # visible to the counter), FMA = 2
         summary["counted_flop_f32_per_launch"] = 64.0 * (g("ADD_F32") + g("MUL_F32") + g("TRANS_F32") + 2.0 * g("FMA_F32"))
         summary["counted_flop_f64_per_launch"] = 64.0 * (g("ADD_F64") + g("MUL_F64") + 2.0 * g("FMA_F64"))
+    if "SQ_INSTS_VALU_MFMA_MOPS_F32_per_launch" in summary:
+        # matrix-core work of the Newton Hessian (v_mfma_f32_16x16x4_f32).  MI355X_MICROARCH.md: the MOPS counters
+        # count in units of 512 flops per wave instruction
+        summary["mfma_flop_f32_per_launch"] = 512.0 * summary["SQ_INSTS_VALU_MFMA_MOPS_F32_per_launch"]
     summary["note"] = ("FETCH_SIZE/WRITE_SIZE are in KiB. The gfx950 x2 FETCH_SIZE correction applies to 16-B-per-lane "
                        "streaming reads; this kernel reads dword rows, so the read figure is reported uncorrected "
                        "(upper bound with the correction: 2x).")
