@@ -48,36 +48,34 @@ def baseline_metric():
         return "env steps/sec (whole node), RearrangementEnv batch=4096 at 1/2/4/8 MI355X"
 
 
-def pmc_summary(solver="PGS"):
-    """Latest committed PMC pass of the solver's kernel (profiles/*_pmc_summary[_newton].json: separate
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* runs of this same bench command); the counters cannot
-    be read from inside the process, so the per-launch figures are carried over."""
+def pmc_summary(solver, steps, warmup):
+    """The committed counter passes that describe THIS run: profiles/rNNx_pmc_summary[_newton][_s<K>w<W>].json taken by
+    tools/measure_round.sh with the same --steps / --warmup (the constraint mix, hence every counter, depends on which
+    ticks are timed) on the same sources (lib.source_hash()).  The counters cannot be read from inside the process, so
+    per-launch figures are carried over -- but only from a pass that matches; otherwise (None, reason)."""
     import glob
     import re
-    sfx = "_pmc_summary.json" if solver == "PGS" else "_pmc_summary_newton.json"
-    # rNNx_pmc_summary[_newton].json only (other summaries in profiles/ describe other kernels)
+    from mujoco_robot_environments_amd import lib as _lib
+    sfx = "_pmc_summary" + ("" if solver == "PGS" else "_newton") + ("" if (steps, warmup) == (200, 20) else f"_s{steps}w{warmup}") + ".json"
     files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*" + sfx))
                    if re.fullmatch(r"r\d\d[a-z]" + re.escape(sfx), os.path.basename(f)))
     if not files:
-        return {}, None
+        return None, f"no counter passes at --steps {steps} --warmup {warmup} under profiles/"
     with open(files[-1]) as f:
-        return json.load(f), os.path.basename(files[-1])
+        d = json.load(f)
+    name = os.path.basename(files[-1])
+    if (d.get("bench_steps"), d.get("bench_warmup")) != (steps, warmup):
+        return None, f"{name} was taken at --steps {d.get('bench_steps')} --warmup {d.get('bench_warmup')}"
+    if d.get("source_hash") != _lib.source_hash():
+        return None, f"{name} was taken on other kernel sources ({d.get('source_hash')}, now {_lib.source_hash()})"
+    return d, name
 
 
-def pmc_traffic(solver="PGS", envs_per_launch=None):
-    d, name = pmc_summary(solver)
-    t = d.get("traffic_bytes_per_launch")
-    if t is not None and envs_per_launch:
-        t *= envs_per_launch / float(d.get("envs_per_launch", ENVS_PER_GPU))
-    return t, name
-
-
-def valu_issue(avg_launch_s, solver="PGS", envs_per_launch=ENVS_PER_GPU):
+def valu_issue(d, name, avg_launch_s, envs_per_launch=ENVS_PER_GPU):
     """What actually bounds the kernel: VALU issue slots.  A wave64 VALU instruction occupies its
     SIMD for 4 cycles (16 lanes per SIMD), so  util = SQ_INSTS_VALU * 4 / (SIMDs * clock * time).
     ``avg_launch_s``: wall time per launch (tick time / launches per tick): launches of different env groups
     overlap on the GPU, so their individual durations do not add up to the time the SIMDs were available."""
-    d, name = pmc_summary(solver)
     n = d.get("SQ_INSTS_VALU_per_launch")
     if not n or avg_launch_s <= 0:
         return None
@@ -91,7 +89,9 @@ def valu_issue(avg_launch_s, solver="PGS", envs_per_launch=ENVS_PER_GPU):
         fl *= scale
         # counted FLOPs (SQ_INSTS_VALU_{ADD,MUL,TRANS,FMA}_F32 x 64 lanes, FMA = 2) against the FP32 vector peak
         # of MI355X_MICROARCH.md (157.3 TFLOP/s); idle lanes of a wave count as work, so this is an upper bound
+        mf = d.get("mfma_flop_f32_per_launch")
         out["counted_flop"] = {"f32_per_launch": fl, "f64_per_launch": d.get("counted_flop_f64_per_launch"),
+                               "mfma_f32_per_launch": mf * scale if mf is not None else None,   # SQ_INSTS_VALU_MFMA_MOPS_F32 x 512
                                "tflops": fl / avg_launch_s / 1e12, "peak_tflops": 157.3,
                                "frac": fl / avg_launch_s / 1e12 / 157.3}
     return out
@@ -235,10 +235,12 @@ def spawn_ranks(args) -> int:
     return subprocess.call(cmd)
 
 
-def timed_run(phys, seq, K, W, F, world, backend, dist, torch, n_local):
+def timed_run(phys, seq, K, W, F, world, backend, dist, torch, n_local, dist_on=None):
     """W untimed warm-up ticks, then exactly K timed ticks between barrier + synchronize pairs."""
+    dist_on = world > 1 if dist_on is None else dist_on
+
     def barrier():
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
         phys.sync()
@@ -251,7 +253,7 @@ def timed_run(phys, seq, K, W, F, world, backend, dist, torch, n_local):
     for k in range(W, W + K, F):
         phys.rollout(seq[k:k + F], control_steps=CONTROL_STEPS)
     gather_ms = 0.0
-    if world > 1:
+    if dist_on:
         # end-of-rollout gather (the only collective of the job): final qpos/qvel/status
         phys.sync()
         tg = time.perf_counter()
@@ -268,7 +270,7 @@ def timed_run(phys, seq, K, W, F, world, backend, dist, torch, n_local):
     elapsed = time.perf_counter() - t0
     kern_ms, launches = phys.profile_read()
     phys.profile_enable(False)
-    if world > 1:
+    if dist_on:
         t = torch.tensor([elapsed], dtype=torch.float64, device=phys.device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -306,7 +308,11 @@ def main():
     if "MRE_BENCH_DEVICE" in os.environ:
         local_rank = int(os.environ["MRE_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # MRE_BENCH_FORCE_DIST=1 (under torch.distributed.run --nproc-per-node 1): the multi-rank code path -- RCCL init
+    # bound to the device, barriers, the device-tensor all_gather_into_tensor, the MAX all_reduce of the time -- with a
+    # world of one, so that those lines have run on a GPU before the first 8-GPU job (tests/test_gpu_api.py)
+    dist_on = world > 1 or os.environ.get("MRE_BENCH_FORCE_DIST") == "1"
+    if dist_on:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -335,7 +341,7 @@ def main():
         phys.set_state(qp0, qv0)
         phys.set_warmstart(ws0)
         phys.sync()
-        elapsed, kern_ms, launches, gather_ms = timed_run(phys, seq, K, W, F, world, backend, dist, torch, n_local)
+        elapsed, kern_ms, launches, gather_ms = timed_run(phys, seq, K, W, F, world, backend, dist, torch, n_local, dist_on)
         status, stats = phys.status(), phys.solver_stats()
         avg_launch_s = (kern_ms / max(launches, 1)) * 1e-3
         # the library steps the batch as env groups on separate streams (launches of different groups overlap on
@@ -349,17 +355,32 @@ def main():
         achieved = bytes_per_launch / wall_per_launch_s / 1e9
         achieved_per_launch = bytes_per_launch / avg_launch_s / 1e9
         kname = "mre::k_step" if solver == "PGS" else "mre::k_step_newton"
+        # counter-derived figures only from passes taken at these arguments on these sources (else null + the reason)
+        summ, summ_name = pmc_summary(solver, K, W) if pmc else (None, "counters describe --fused 1 at 4096 envs per GPU")
+        traffic = vi = None
+        if summ is not None:
+            traffic = summ.get("traffic_bytes_per_launch")
+            if traffic is not None:
+                traffic *= (n_local // per_tick) / float(summ.get("envs_per_launch", ENVS_PER_GPU))
+            vi = valu_issue(summ, summ_name, wall_per_launch_s, n_local // per_tick)
+        hbm = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS}
+        if vi is not None:
+            # the limiter of this path is VALU issue (PGS) / issue + dependent LDS latency (Newton), not HBM: the
+            # roofline object prices the kernel against the issue slots, the HBM figures stay beside it
+            head_roof = {"bound": "valu_issue", "achieved": vi["valu_insts_per_launch"] * 4.0 / wall_per_launch_s,
+                         "peak": vi["simds"] * vi["clock_hz"], "unit": "SIMD-cycles/s", "frac": vi["util"], "hbm": hbm}
+        else:
+            head_roof = dict(hbm, valu_issue_unavailable=summ_name)
         return {
             "solver": solver, "value": total_env_steps / elapsed, "ms_per_step": elapsed / K * 1e3, "gather_ms": gather_ms,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic(solver, n_local // per_tick)[0] if pmc else None, "traffic_source": pmc_traffic(solver)[1],
+            "roofline": {**head_roof,
+                         "traffic": traffic, "traffic_source": summ_name if summ is not None else None,
                          "kernel": kname, "avg_launch_ms": avg_launch_s * 1e3, "launches": launches,
                          "launches_per_tick": per_tick, "envs_per_launch": n_local // per_tick,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "wall_ms_per_launch": wall_per_launch_s * 1e3,
                          "achieved_per_overlapping_launch": achieved_per_launch,
-                         "valu_issue": valu_issue(wall_per_launch_s, solver, n_local // per_tick) if pmc else None,
+                         "valu_issue": vi,
                          "launch_note": "a tick is stepped as `launches_per_tick` env-group launches on prioritised streams that "
                                         "overlap each other and the next tick's (csrc/mre_api.cpp launch_step): avg_launch_ms is one "
                                         "group launch's own duration (HIP events; rocprofv3 --stats agrees), wall_ms_per_launch the "
@@ -405,9 +426,11 @@ def main():
     elif rank == 0:
         res["cpu_baseline"] = None
         res["mujoco"] = None
+    if dist_on:
+        res["distributed"] = {"backend": backend, "world": world, "gathered_rows": world * n_local}
     if rank == 0:
         print(json.dumps(res))
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

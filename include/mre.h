@@ -56,7 +56,10 @@ typedef enum {
 #define MRE_ST_NOT_CONVERGED 1u   /* arm outside OSC thresholds after run_controller */
 #define MRE_ST_NAN 2u             /* non-finite state detected */
 #define MRE_ST_CONTACT_OVERFLOW 4u /* contact / constraint-row capacity exceeded */
-#define MRE_ST_NOT_SETTLED 8u     /* PropPlacer: cubes still moving after max_settle_physics_time (2 s) */
+#define MRE_ST_NOT_SETTLED 8u     /* PropPlacer: cubes still moving after max_settle_physics_time (2 s) in each of the
+                                   * max_settle_physics_attempts (10) placements (prop_initializer.py:240-283) */
+#define MRE_ST_PLACEMENT_FAILED 16u /* PropPlacer: no collision-free pose for one of the env's cubes within
+                                   * max_attempts_per_prop (_REJECTION_SAMPLING_FAILED, prop_initializer.py:230-233) */
 
 typedef struct mre_env mre_env;
 
@@ -82,11 +85,12 @@ int mre_reset(mre_env*, const uint8_t* mask);
 /* PropPlacer.__call__ (environment/prop_initializer.py:164-283).  Props are placed one index at a
  * time over the batch: pose ~ U(workspace), yaw = pi U(0,1), rejected while the prop has ANY detected
  * contact (physics.data.contact: dist < margin) with a geom other than the table -- placed props
- * and robot geoms alike (:121-140), at most max_attempts draws per prop (error beyond, like the
- * reference's RuntimeError).  Then the physics settles with the robot frozen; every env stops by
- * itself once max|qvel| < 1e-3 and max|qacc| < 1e-2 after at least settle_steps steps (:240-258:
- * 0.3 s), at most 2 s (then MRE_ST_NOT_SETTLED).  mre_get_settle_steps: steps each env took
- * (negative: not settled). */
+ * and robot geoms alike (:121-140), at most max_attempts draws per prop (beyond: the reference raises
+ * for its one env; here THAT env gets MRE_ST_PLACEMENT_FAILED and the others carry on).  Then the
+ * physics settles with the robot frozen; every env stops by itself once max|qvel| < 1e-3 and
+ * max|qacc| < 1e-2 after at least settle_steps steps (:240-258: 0.3 s), at most 2 s; an env still moving
+ * then is placed again from fresh draws, up to 10 times (max_settle_physics_attempts), then flagged
+ * MRE_ST_NOT_SETTLED.  mre_get_settle_steps: steps each env took in its last settle (negative: not settled). */
 int mre_place_props(mre_env*, const uint8_t* mask, uint64_t seed, const float* ws_min,
                     const float* ws_max, int max_attempts, int settle_steps);
 int mre_get_settle_steps(mre_env*, int32_t* steps);
@@ -129,6 +133,15 @@ int mre_set_env_ids(mre_env*, const long long* ids);
 /* physics.bind(joints).qpos / .qvel access: rows [N][MRE_NQ_PAD] / [N][MRE_NV_PAD] */
 int mre_set_state(mre_env*, const float* qpos, const float* qvel);
 int mre_get_state(mre_env*, float* qpos, float* qvel);
+/* the same state as the reference holds it (physics.data.qpos / .qvel are float64): rows [N][MRE_NQ] /
+ * [N][MRE_NV] of doubles, HOST pointers.  On the device the robot's 15 joints are double-float pairs (the float32
+ * row entry + a low-order word: the soft closures of the 2F-85 four-bars amplify a float32 rounding of the state
+ * past the 1e-4 parity bar within 1000 steps), the cubes' coordinates are float32.  mre_set_state (float rows)
+ * clears the low-order words. */
+int mre_get_state_f64(mre_env*, double* qpos, double* qvel);
+int mre_set_state_f64(mre_env*, const double* qpos, const double* qvel);
+/* physics.data.time (models/robot_arm.py:68-69): seconds of physics since the last mre_reset, per env, host [N] */
+int mre_get_time(mre_env*, double* time);
 int mre_set_warmstart(mre_env*, const float* qacc_warmstart);
 int mre_get_warmstart(mre_env*, float* qacc_warmstart);
 /* Physics.set_control(u) (models/robot_arm.py:78): rows [N][MRE_NU] */

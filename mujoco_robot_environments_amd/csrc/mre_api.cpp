@@ -24,19 +24,15 @@ extern "C" void mre_launch_step_newton(const StepArgs* args, hipStream_t stream)
 extern "C" void mre_launch_settle_newton(const StepArgs* args, hipStream_t stream);
 extern "C" void mre_launch_step_large_newton(const StepArgs* args, hipStream_t stream);
 extern "C" void mre_launch_render(const RenderArgs* args, int row_groups, hipStream_t stream);
-extern "C" void mre_launch_prepare(const uint8_t* user_mask, const uint8_t* large, int env0, int N, uint8_t* mask_compact,
-                                   uint8_t* mask_large, int* launch_info, const float* qpos, float* sv_qpos,
-                                   const float* qvel, float* sv_qvel, const float* qacc_ws, float* sv_qacc_ws,
-                                   const float* ctrl, float* sv_ctrl, const uint32_t* status, uint32_t* sv_status,
-                                   const uint8_t* converged, uint8_t* sv_converged, hipStream_t stream);
 extern "C" void mre_launch_restore_rows(const uint8_t* sel, int env0, int N, float* qpos, const float* sv_qpos, float* qvel,
-                                        const float* sv_qvel, float* qacc_ws, const float* sv_qacc_ws, float* ctrl,
-                                        const float* sv_ctrl, uint32_t* status, const uint32_t* sv_status,
+                                        const float* sv_qvel, float* qacc_ws, const float* sv_qacc_ws, float* qfine,
+                                        const float* sv_qfine, float* ctrl, const float* sv_ctrl, int* nstep,
+                                        const int* sv_nstep, uint32_t* status, const uint32_t* sv_status,
                                         uint8_t* converged, const uint8_t* sv_converged, hipStream_t stream);
 extern "C" void mre_launch_pose_search(const SearchArgs* args, hipStream_t stream);
 extern "C" void mre_launch_sort_select(const SortArgs* args, hipStream_t stream);
-extern "C" void mre_launch_reset(const DevModel* M, int N, float* qpos, float* qvel, float* qacc_ws,
-                                 float* ctrl, uint32_t* status, const uint8_t* mask,
+extern "C" void mre_launch_reset(const DevModel* M, int N, float* qpos, float* qvel, float* qacc_ws, float* qfine,
+                                 float* ctrl, uint32_t* status, int* nstep, const uint8_t* mask,
                                  hipStream_t stream);
 
 
@@ -58,6 +54,8 @@ struct mre_env {
   DevModel* dM = nullptr;
   DevModel hM;
   float *qpos = nullptr, *qvel = nullptr, *qacc_ws = nullptr, *ctrl = nullptr;
+  float* qfine = nullptr;   // [N][QFINE] low-order words of the robot's joint angles / velocities (StepArgs::qfine)
+  int *nstep = nullptr, *sv_nstep = nullptr;   // [N] physics steps since the last reset (physics.data.time)
   int* nprops = nullptr;
   float* prop_size = nullptr;
   float* osc_target = nullptr;
@@ -94,8 +92,8 @@ struct mre_env {
   bool compact_only = false;  // mre_set_fallback(0)  // mre_set_fallback(2): every env on the large kernel (reference run for the fallback)
   hipStream_t stream2 = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_order = nullptr;
-  uint8_t *d_large = nullptr, *mask_c = nullptr, *mask_l = nullptr, *mask_r = nullptr;
-  float *sv_qpos = nullptr, *sv_qvel = nullptr, *sv_qacc_ws = nullptr, *sv_ctrl = nullptr;
+  uint8_t *d_large = nullptr, *mask_r = nullptr;
+  float *sv_qpos = nullptr, *sv_qvel = nullptr, *sv_qacc_ws = nullptr, *sv_ctrl = nullptr, *sv_qfine = nullptr;
   uint32_t* sv_status = nullptr;
   uint8_t* sv_converged = nullptr;
   float* contacts = nullptr;     // device [N][1 + 3 * CONTACT_EXPORT] (detect launches), allocated on first use
@@ -152,9 +150,11 @@ static void launch_large(const mre_env* e, const StepArgs& a, hipStream_t st) {
 //
 // Capacity fallback.  The compact kernel (8 workgroups/CU) holds at most NCON_MAX / NEFC_MAX /
 // NRROW_MAX / NPP_MAX constraints per env; a grasp or a pile needs more.  Every launch therefore
-//   1. copies the state rows (qpos, qvel, warm start, ctrl, status) aside (one small kernel),
-//   2. runs the envs currently marked "large" on the large-capacity kernel (second stream, own
-//      mask) next to the compact kernel for all others,
+//   1. has every env copy its state rows (qpos, qvel, warm start, finger low words, ctrl, status) aside as
+//      the step kernel loads them (StepArgs::sv_*),
+//   2. runs the envs currently marked "large" on the large-capacity kernel (second stream; an env takes
+//      part in the kernel that matches its flag, StepArgs::large / want_large) next to the compact kernel
+//      for all others,
 //   3. reads back per-env launch info (overflow flag + high-water marks of the launch),
 //   4. restores the envs that overflowed on the compact kernel to their saved rows, marks them
 //      large and runs them again on the large kernel -- so no result ever depends on the compact
@@ -219,9 +219,10 @@ static int finish_group(mre_env* e, mre_env::Group& G) {
   if (nrerun > 0) {
     HIPCHK(hipMemcpyAsync(e->mask_r + G.lo, e->h_rerun.data() + G.lo, (size_t)G.n, hipMemcpyHostToDevice, G.st));
     mre_launch_restore_rows(e->mask_r, G.lo, G.n, e->qpos, e->sv_qpos, e->qvel, e->sv_qvel, e->qacc_ws, e->sv_qacc_ws,
-                            e->ctrl, e->sv_ctrl, e->status, e->sv_status, e->converged, e->sv_converged, G.st);
+                            e->qfine, e->sv_qfine, e->ctrl, e->sv_ctrl, e->nstep, e->sv_nstep, e->status, e->sv_status,
+                            e->converged, e->sv_converged, G.st);
     StepArgs ar = G.args;
-    ar.env_mask = e->mask_r; ar.launch_info = nullptr;
+    ar.env_mask = e->mask_r; ar.launch_info = nullptr; ar.large = nullptr; ar.sv_qpos = nullptr;
     launch_large(e, ar, G.st);
     HIPCHK(hipGetLastError());
     e->n_reruns += nrerun;
@@ -256,6 +257,13 @@ static int drain(mre_env* e, bool api_call = false) {
 #define DRAIN(e) do { int rc_ = drain(e, true); if (rc_) return rc_; } while (0)
 #define DRAIN_PENDING(e) do { int rc_ = drain(e, false); if (rc_) return rc_; } while (0)
 
+// a launch under the capacity fallback: split by the envs' flags, state rows copied aside, launch info reported
+static void guard_args(mre_env* e, StepArgs& a) {
+  a.large = e->d_large; a.launch_info = e->launch_info;
+  a.sv_qpos = e->sv_qpos; a.sv_qvel = e->sv_qvel; a.sv_qacc_ws = e->sv_qacc_ws; a.sv_qfine = e->sv_qfine;
+  a.sv_ctrl = e->sv_ctrl; a.sv_status = e->sv_status; a.sv_converged = e->sv_converged; a.sv_nstep = e->sv_nstep;
+}
+
 // One group's part of a stepping call: finish its previous launch, enqueue the new one, do not wait.
 static int launch_group(mre_env* e, mre_env::Group& G, const StepArgs& a_full) {
   int rc = finish_group(e, G);
@@ -266,18 +274,16 @@ static int launch_group(mre_env* e, mre_env::Group& G, const StepArgs& a_full) {
   if (rc) return rc;
   HIPCHK(hipStreamWaitEvent(G.st, e->ev_main, 0));
   if (G.p0) HIPCHK(hipEventRecord(G.p0, G.st));
-  mre_launch_prepare(nullptr, e->d_large, G.lo, G.n, e->mask_c, e->mask_l, e->launch_info, e->qpos, e->sv_qpos,
-                     e->qvel, e->sv_qvel, e->qacc_ws, e->sv_qacc_ws, e->ctrl, e->sv_ctrl, e->status, e->sv_status,
-                     e->converged, e->sv_converged, G.st);
+  guard_args(e, a);
   StepArgs ac = a;
-  ac.env_mask = e->mask_c; ac.launch_info = e->launch_info;
+  ac.want_large = 0;
   bool run_large = false;
   for (int i = G.lo; i < G.lo + G.n && !run_large; i++) run_large = e->h_large[i] != 0;
   if (run_large) {
     HIPCHK(hipEventRecord(G.ev_fork, G.st));
     HIPCHK(hipStreamWaitEvent(G.st2, G.ev_fork, 0));
     StepArgs al = a;
-    al.env_mask = e->mask_l; al.launch_info = e->launch_info;
+    al.want_large = 1;
     launch_large(e, al, G.st2);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(G.ev_join, G.st2));
@@ -342,11 +348,9 @@ static int launch_step(mre_env* e, const StepArgs& a, bool settle = false, bool 
     HIPCHK(hipGetLastError());
   } else {
     const size_t N = (size_t)e->N;
-    mre_launch_prepare(a.env_mask, e->d_large, 0, e->N, e->mask_c, e->mask_l, e->launch_info, e->qpos, e->sv_qpos,
-                       e->qvel, e->sv_qvel, e->qacc_ws, e->sv_qacc_ws, e->ctrl, e->sv_ctrl, e->status, e->sv_status,
-                       e->converged, e->sv_converged, e->stream);
     StepArgs ac = a;
-    ac.env_mask = e->mask_c; ac.launch_info = e->launch_info;
+    guard_args(e, ac);
+    ac.want_large = 0;
     // (recounted from the flags every launch: an env flagged large is masked out of the compact
     // kernel, so the large kernel MUST run whenever a flag is set)
     e->n_large = 0;
@@ -355,8 +359,8 @@ static int launch_step(mre_env* e, const StepArgs& a, bool settle = false, bool 
     if (run_large) {
       HIPCHK(hipEventRecord(e->ev_fork, e->stream));
       HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_fork, 0));
-      StepArgs al = a;
-      al.env_mask = e->mask_l; al.launch_info = e->launch_info;
+      StepArgs al = ac;
+      al.want_large = 1;
       launch_large(e, al, e->stream2);
       HIPCHK(hipGetLastError());
       HIPCHK(hipEventRecord(e->ev_join, e->stream2));
@@ -415,7 +419,8 @@ static int launch_step(mre_env* e, const StepArgs& a, bool settle = false, bool 
     if (nrerun > 0) {
       HIPCHK(hipMemcpyAsync(e->mask_r, e->h_rerun.data(), N, hipMemcpyHostToDevice, e->stream));
       mre_launch_restore_rows(e->mask_r, 0, e->N, e->qpos, e->sv_qpos, e->qvel, e->sv_qvel, e->qacc_ws, e->sv_qacc_ws,
-                              e->ctrl, e->sv_ctrl, e->status, e->sv_status, e->converged, e->sv_converged, e->stream);
+                              e->qfine, e->sv_qfine, e->ctrl, e->sv_ctrl, e->nstep, e->sv_nstep, e->status,
+                              e->sv_status, e->converged, e->sv_converged, e->stream);
       StepArgs ar = a;
       ar.env_mask = e->mask_r; ar.launch_info = nullptr;
       launch_large(e, ar, e->stream);
@@ -649,6 +654,10 @@ static int create_buffers(mre_env* e, int num_envs, int device_id) {
   HIPCHK(hipMemcpy(e->dM, &e->hM, sizeof(DevModel), hipMemcpyHostToDevice));
   HIPCHK(hipMalloc(&e->qpos, N * NQP * 4)); HIPCHK(hipMalloc(&e->qvel, N * NVP * 4));
   HIPCHK(hipMalloc(&e->qacc_ws, N * NVP * 4)); HIPCHK(hipMalloc(&e->ctrl, N * NU * 4));
+  HIPCHK(hipMalloc(&e->qfine, N * QFINE * 4)); HIPCHK(hipMalloc(&e->sv_qfine, N * QFINE * 4));
+  HIPCHK(hipMemsetAsync(e->qfine, 0, N * QFINE * 4, e->stream));
+  HIPCHK(hipMalloc(&e->nstep, N * 4)); HIPCHK(hipMalloc(&e->sv_nstep, N * 4));
+  HIPCHK(hipMemsetAsync(e->nstep, 0, N * 4, e->stream));
   HIPCHK(hipMalloc(&e->nprops, N * 4)); HIPCHK(hipMalloc(&e->prop_size, N * NPROP * 3 * 4));
   HIPCHK(hipMalloc(&e->osc_target, N * 16 * 4)); HIPCHK(hipMalloc(&e->grip_closed, N));
   HIPCHK(hipMalloc(&e->converged, N)); HIPCHK(hipMalloc(&e->mask, N));
@@ -659,8 +668,7 @@ static int create_buffers(mre_env* e, int num_envs, int device_id) {
   HIPCHK(hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking));
   HIPCHK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
-  HIPCHK(hipMalloc(&e->d_large, N)); HIPCHK(hipMalloc(&e->mask_c, N)); HIPCHK(hipMalloc(&e->mask_l, N));
-  HIPCHK(hipMalloc(&e->mask_r, N));
+  HIPCHK(hipMalloc(&e->d_large, N)); HIPCHK(hipMalloc(&e->mask_r, N));
   HIPCHK(hipMalloc(&e->sv_qpos, N * NQP * 4)); HIPCHK(hipMalloc(&e->sv_qvel, N * NVP * 4));
   HIPCHK(hipMalloc(&e->sv_qacc_ws, N * NVP * 4)); HIPCHK(hipMalloc(&e->sv_ctrl, N * NU * 4));
   HIPCHK(hipMalloc(&e->sv_status, N * 4)); HIPCHK(hipMalloc(&e->launch_info, N * 16));
@@ -790,7 +798,7 @@ extern "C" int mre_destroy(mre_env* e) {
   void* ptrs[] = {e->dM, e->qpos, e->qvel, e->qacc_ws, e->ctrl, e->nprops, e->prop_size, e->osc_target,
                   e->grip_closed, e->converged, e->mask, e->sites, e->status, e->stats, e->d_osc, e->d_osc_env, e->order,
                   e->geoms, e->prop_rgb, e->bg_depth, e->bg_rgb, e->bg_seg,
-                  e->d_large, e->mask_c, e->mask_l, e->mask_r, e->sv_qpos, e->sv_qvel, e->sv_qacc_ws, e->sv_ctrl,
+                  e->d_large, e->mask_r, e->qfine, e->sv_qfine, e->nstep, e->sv_nstep, e->sv_qpos, e->sv_qvel, e->sv_qacc_ws, e->sv_ctrl,
                   e->sv_status, e->launch_info, e->auto_order, e->sv_converged, e->contacts, e->settle_steps,
                   e->d_env_ids, e->ps_attempts, e->ps_prop, e->ps_tick, e->ps_which, e->ps_bounds, e->ps_pose, e->ps_zones,
                   e->ps_pick};
@@ -852,7 +860,7 @@ extern "C" int mre_reset(mre_env* e, const uint8_t* mask) {
   const uint8_t* dmask;
   int rc = stage_mask(e, mask, &dmask);
   if (rc) return rc;
-  mre_launch_reset(e->dM, e->N, e->qpos, e->qvel, e->qacc_ws, e->ctrl, e->status, dmask, e->stream);
+  mre_launch_reset(e->dM, e->N, e->qpos, e->qvel, e->qacc_ws, e->qfine, e->ctrl, e->status, e->nstep, dmask, e->stream);
   HIPCHK(hipGetLastError());
   // a reset env starts on the compact kernel again (the mask may be a device pointer: read a host copy)
   bool changed = false;
@@ -1080,7 +1088,68 @@ extern "C" int mre_set_state(mre_env* e, const float* qpos, const float* qvel) {
   int rc = MRE_OK;
   if (qpos) rc = copy_in(e, e->qpos, qpos, (size_t)e->N * NQP * 4);
   if (!rc && qvel) rc = copy_in(e, e->qvel, qvel, (size_t)e->N * NVP * 4);
+  // a float32 row IS the value: the low-order words of the robot's angles / velocities start from zero
+  if (!rc && qpos) HIPCHK(hipMemset2DAsync(e->qfine, QFINE * 4, 0, QFINE * 2, (size_t)e->N, e->stream));
+  if (!rc && qvel) HIPCHK(hipMemset2DAsync(e->qfine + QFINE / 2, QFINE * 4, 0, QFINE * 2, (size_t)e->N, e->stream));
   return rc;
+}
+
+// physics.data.qpos / .qvel as the reference holds them (float64): the robot's 15 joints are carried as
+// double-float pairs on the device (StepArgs::qfine), the cubes' coordinates as float32.  Host pointers.
+extern "C" int mre_get_state_f64(mre_env* e, double* qpos, double* qvel) {
+  if (!e) return fail(MRE_ERR_ARG, "null handle");
+  DRAIN(e);
+  const size_t N = (size_t)e->N;
+  std::vector<float> hq(N * NQP), hv(N * NVP), hf(N * QFINE);
+  int rc = copy_out(e, hq.data(), e->qpos, N * NQP * 4);
+  if (!rc) rc = copy_out(e, hv.data(), e->qvel, N * NVP * 4);
+  if (!rc) rc = copy_out(e, hf.data(), e->qfine, N * QFINE * 4);
+  if (rc) return rc;
+  for (size_t i = 0; i < N; i++) {
+    if (qpos) for (int k = 0; k < NQ; k++)
+      qpos[i * NQ + k] = (double)hq[i * NQP + k] + (k < NRV ? (double)hf[i * QFINE + k] : 0.0);
+    if (qvel) for (int k = 0; k < NV; k++)
+      qvel[i * NV + k] = (double)hv[i * NVP + k] + (k < NRV ? (double)hf[i * QFINE + QFINE / 2 + k] : 0.0);
+  }
+  return MRE_OK;
+}
+extern "C" int mre_set_state_f64(mre_env* e, const double* qpos, const double* qvel) {
+  if (!e) return fail(MRE_ERR_ARG, "null handle");
+  DRAIN(e);
+  const size_t N = (size_t)e->N;
+  std::vector<float> hq(N * NQP), hv(N * NVP), hf(N * QFINE);
+  int rc = copy_out(e, hq.data(), e->qpos, N * NQP * 4);
+  if (!rc) rc = copy_out(e, hv.data(), e->qvel, N * NVP * 4);
+  if (!rc) rc = copy_out(e, hf.data(), e->qfine, N * QFINE * 4);
+  if (rc) return rc;
+  for (size_t i = 0; i < N; i++) {
+    if (qpos) for (int k = 0; k < NQ; k++) {
+      const float hi = (float)qpos[i * NQ + k];
+      hq[i * NQP + k] = hi;
+      if (k < NRV) hf[i * QFINE + k] = (float)(qpos[i * NQ + k] - (double)hi);
+    }
+    if (qvel) for (int k = 0; k < NV; k++) {
+      const float hi = (float)qvel[i * NV + k];
+      hv[i * NVP + k] = hi;
+      if (k < NRV) hf[i * QFINE + QFINE / 2 + k] = (float)(qvel[i * NV + k] - (double)hi);
+    }
+  }
+  rc = copy_in(e, e->qpos, hq.data(), N * NQP * 4);
+  if (!rc) rc = copy_in(e, e->qvel, hv.data(), N * NVP * 4);
+  if (!rc) rc = copy_in(e, e->qfine, hf.data(), N * QFINE * 4);
+  if (!rc) HIPCHK(hipStreamSynchronize(e->stream));   // (the staged rows must outlive the uploads)
+  return rc;
+}
+// physics.data.time (models/robot_arm.py:68-69): physics steps since the last mre_reset times the timestep, per env
+// (envs differ after PropPlacer's settle, whose exit is per env).  Host pointer [N].
+extern "C" int mre_get_time(mre_env* e, double* time) {
+  if (!e || !time) return fail(MRE_ERR_ARG, "mre_get_time: null");
+  DRAIN(e);
+  std::vector<int> hn((size_t)e->N);
+  int rc = copy_out(e, hn.data(), e->nstep, (size_t)e->N * 4);
+  if (rc) return rc;
+  for (int i = 0; i < e->N; i++) time[i] = (double)hn[i] * (double)e->hM.timestep;
+  return MRE_OK;
 }
 extern "C" int mre_get_ctrl(mre_env* e, float* ctrl) {
   if (!e || !ctrl) return fail(MRE_ERR_ARG, "mre_get_ctrl: null");
@@ -1115,12 +1184,12 @@ extern "C" int mre_set_ctrl(mre_env* e, const float* ctrl) {
 static void fill_args(mre_env* e, StepArgs& a) {
   memset(&a, 0, sizeof(a));
   a.M = e->dM; a.N = e->N; a.seq_stride = e->N;
-  a.qpos = e->qpos; a.qvel = e->qvel; a.qacc_ws = e->qacc_ws; a.ctrl = e->ctrl;
+  a.qpos = e->qpos; a.qvel = e->qvel; a.qacc_ws = e->qacc_ws; a.ctrl = e->ctrl; a.qfine = e->qfine;
   a.nprops = e->nprops; a.prop_size = e->prop_size;
   a.control_steps = 1; a.mode = CTRL_HELD;
   a.osc = e->d_osc_env ? e->d_osc_env : e->d_osc; a.osc_stride = e->d_osc_env ? 1 : 0;
   a.osc_target = e->osc_target; a.grip_closed = e->grip_closed;
-  a.sites = e->sites; a.status = e->status; a.stats = e->stats;
+  a.sites = e->sites; a.status = e->status; a.stats = e->stats; a.nstep = e->nstep;
   a.env_order = e->use_order ? e->order : (e->have_auto_order ? e->auto_order : nullptr);
   a.trace = e->trace; a.trace_nenv = e->trace_nenv; a.trace_max = e->trace_max; a.trace_base = e->trace_pos;
 }
@@ -1441,70 +1510,106 @@ extern "C" int mre_place_props(mre_env* e, const uint8_t* mask, uint64_t seed, c
   int rc;
   if (mask) { rc = copy_out(e, hm.data(), mask, N); if (rc) return rc; }
   std::vector<int> np(N);
-  std::vector<float> qp(N * NQP);
-  if ((rc = copy_out(e, np.data(), e->nprops, N * 4)) || (rc = copy_out(e, qp.data(), e->qpos, qp.size() * 4)))
-    return rc;
+  if ((rc = copy_out(e, np.data(), e->nprops, N * 4))) return rc;
   double lo[3], hi[3];
   for (int k = 0; k < 3; k++) { lo[k] = ws_min[k]; hi[k] = ws_max[k]; }
-  // props that are about to be placed start from their parking pose
-  for (size_t i = 0; i < N; i++)
-    if (hm[i])
-      for (int p = 0; p < NPROP; p++) {
-        float* q = &qp[i * NQP + NRV + 7 * p];
-        for (int k = 0; k < 3; k++) q[k] = e->hM.park_pos[p][k];
-        q[3] = 1.f; q[4] = q[5] = q[6] = 0.f;
-      }
-  if ((rc = copy_in(e, e->qpos, qp.data(), qp.size() * 4)) || (rc = copy_in(e, e->mask, hm.data(), N))) return rc;
   if ((rc = search_buffers(e))) return rc;
-  // one search launch per prop index: every env that still needs prop p runs its own attempt loop on
-  // the device (k_pose_search) and writes the accepted pose into its qpos row
-  std::vector<int> att(N);
-  for (int p = 0; p < NPROP; p++) {
-    SearchArgs sa;
-    fill_search(e, sa);
-    sa.env_mask = e->mask; sa.seed = seed; sa.fixed_prop = p;
-    for (int k = 0; k < 3; k++) { sa.shared_bounds[k] = lo[k]; sa.shared_bounds[3 + k] = hi[k]; }
-    sa.tick0 = (long long)p * (long long)max_attempts;
-    sa.max_attempts = max_attempts; sa.yaw_mode = 1; sa.max_dist = INFINITY; sa.commit = 1;
-    mre_launch_pose_search(&sa, e->stream);
-    HIPCHK(hipGetLastError());
-    if ((rc = copy_out(e, att.data(), e->ps_attempts, N * 4))) return rc;
+  if (settle_steps > 0 && !e->settle_steps) HIPCHK(hipMalloc(&e->settle_steps, N * 4));
+  if (settle_steps > 0) HIPCHK(hipMemsetAsync(e->settle_steps, 0, N * 4, e->stream));
+  std::vector<int> att(N), hs(N), nst(N);
+  std::vector<uint32_t> st(N);
+  std::vector<float> qp(N * NQP);
+  std::vector<uint8_t> todo = hm;      // envs whose cubes are (still) to be placed
+  std::vector<uint8_t> failed(N, 0);   // no pose within max_attempts for one of the env's cubes
+  e->last_settle_max = 0;
+  // PropPlacer.place_and_settle (environment/prop_initializer.py:240-258): place, settle with the robot frozen,
+  // and place AGAIN the envs whose cubes are still moving after max_settle_physics_time -- up to
+  // max_settle_physics_attempts (10) times, per env (the other envs keep what they have)
+  const int max_settle_attempts = settle_steps > 0 ? 10 : 1;
+  for (int round = 0; round < max_settle_attempts; round++) {
+    bool any = false;
+    for (size_t i = 0; i < N; i++) any = any || todo[i];
+    if (!any) break;
+    if ((rc = copy_out(e, qp.data(), e->qpos, qp.size() * 4)) || (rc = copy_out(e, nst.data(), e->nstep, N * 4))) return rc;
+    // props that are about to be placed start from their parking pose
     for (size_t i = 0; i < N; i++)
-      if (hm[i] && p < np[i] && att[i] <= 0)
-        return fail(MRE_ERR_ARG, "mre_place_props: failed to find a non-colliding pose within max_attempts (_REJECTION_SAMPLING_FAILED)");
-  }
-  HIPCHK(hipStreamSynchronize(e->stream));
-  if (settle_steps > 0) {
-    const uint8_t* dmask = nullptr;
-    if (mask) { rc = copy_in(e, e->mask, hm.data(), N); if (rc) return rc; dmask = e->mask; }
-    if (!e->settle_steps) HIPCHK(hipMalloc(&e->settle_steps, N * 4));
-    HIPCHK(hipMemsetAsync(e->settle_steps, 0, N * 4, e->stream));
+      if (todo[i])
+        for (int p = 0; p < NPROP; p++) {
+          float* q = &qp[i * NQP + NRV + 7 * p];
+          for (int k = 0; k < 3; k++) q[k] = e->hM.park_pos[p][k];
+          q[3] = 1.f; q[4] = q[5] = q[6] = 0.f;
+        }
+    if ((rc = copy_in(e, e->qpos, qp.data(), qp.size() * 4)) || (rc = copy_in(e, e->mask, todo.data(), N))) return rc;
+    if (round > 0) {   // a second try starts from rest
+      std::vector<float> z(N * NVP, 0.f), qv(N * NVP);
+      if ((rc = copy_out(e, qv.data(), e->qvel, qv.size() * 4))) return rc;
+      for (size_t i = 0; i < N; i++)
+        if (todo[i]) for (int k = NRV; k < NVP; k++) qv[i * NVP + k] = 0.f;
+      if ((rc = copy_in(e, e->qvel, qv.data(), qv.size() * 4))) return rc;
+      HIPCHK(hipStreamSynchronize(e->stream));
+    }
+    // one search launch per prop index: every env that still needs prop p runs its own attempt loop on
+    // the device (k_pose_search) and writes the accepted pose into its qpos row
+    for (int p = 0; p < NPROP; p++) {
+      SearchArgs sa;
+      fill_search(e, sa);
+      sa.env_mask = e->mask; sa.seed = seed; sa.fixed_prop = p;
+      for (int k = 0; k < 3; k++) { sa.shared_bounds[k] = lo[k]; sa.shared_bounds[3 + k] = hi[k]; }
+      sa.tick0 = ((long long)round * NPROP + p) * (long long)max_attempts;
+      sa.max_attempts = max_attempts; sa.yaw_mode = 1; sa.max_dist = INFINITY; sa.commit = 1;
+      mre_launch_pose_search(&sa, e->stream);
+      HIPCHK(hipGetLastError());
+      if ((rc = copy_out(e, att.data(), e->ps_attempts, N * 4))) return rc;
+      bool dropped = false;
+      for (size_t i = 0; i < N; i++)
+        if (todo[i] && p < np[i] && att[i] <= 0) { failed[i] = 1; todo[i] = 0; dropped = true; }
+      // (_REJECTION_SAMPLING_FAILED is an exception of ONE env in the reference: here that env is flagged
+      //  MRE_ST_PLACEMENT_FAILED, its remaining cubes stay parked, and the other envs carry on)
+      if (dropped && (rc = copy_in(e, e->mask, todo.data(), N))) return rc;
+    }
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (settle_steps <= 0) break;
     StepArgs a;
     fill_args(e, a);
     a.trace = nullptr;
     // _max_settle_physics_time = 2 s; min time = settle_steps * dt (0.3 s in the reference)
     a.nsteps = (int)std::lround(2.0 / e->hM.timestep);
     if (a.nsteps < settle_steps) a.nsteps = settle_steps;
-    a.flags = F_FREEZE_ROBOT | F_SETTLE_EXIT; a.env_mask = dmask;
+    a.flags = F_FREEZE_ROBOT | F_SETTLE_EXIT; a.env_mask = e->mask;
     a.settle_steps = e->settle_steps; a.min_settle_steps = settle_steps;
     const bool prof = e->profiling;
     e->profiling = false;  // setup, not a control tick
     rc = launch_step(e, a, /*settle=*/true);
     e->profiling = prof;
     if (rc) return rc;
-    std::vector<int> hs(N);
     if ((rc = copy_out(e, hs.data(), e->settle_steps, N * 4))) return rc;
-    std::vector<uint32_t> st(N);
-    if ((rc = copy_out(e, st.data(), e->status, N * 4))) return rc;
-    bool any = false;
-    e->last_settle_max = 0;
+    bool again = false;
     for (size_t i = 0; i < N; i++) {
-      if (!hm[i]) continue;
-      if (hs[i] < 0) { st[i] |= MRE_ST_NOT_SETTLED; any = true; }
+      if (!todo[i]) continue;
       const int n = hs[i] < 0 ? -hs[i] : hs[i];
       if (n > e->last_settle_max) e->last_settle_max = n;
+      if (hs[i] >= 0) todo[i] = 0;                                  // settled
+      else if (round + 1 < max_settle_attempts) again = true;       // placed again in the next round
     }
-    if (any && (rc = copy_in(e, e->status, st.data(), N * 4))) return rc;
+    if (again) {
+      // `physics.data.time = original_time` of a failed attempt (:258): the clock goes back for the envs placed again
+      std::vector<int> now(N);
+      if ((rc = copy_out(e, now.data(), e->nstep, N * 4))) return rc;
+      for (size_t i = 0; i < N; i++) if (todo[i]) now[i] = nst[i];
+      if ((rc = copy_in(e, e->nstep, now.data(), N * 4))) return rc;
+      HIPCHK(hipStreamSynchronize(e->stream));
+    }
+  }
+  // status: envs that never settled (the reference logs _SETTLING_PHYSICS_FAILED and goes on), envs without a pose
+  bool flag = false;
+  for (size_t i = 0; i < N; i++) flag = flag || failed[i] || (settle_steps > 0 && todo[i]);
+  if (flag) {
+    if ((rc = copy_out(e, st.data(), e->status, N * 4))) return rc;
+    for (size_t i = 0; i < N; i++) {
+      if (failed[i]) st[i] |= MRE_ST_PLACEMENT_FAILED;
+      else if (settle_steps > 0 && todo[i]) st[i] |= MRE_ST_NOT_SETTLED;
+    }
+    if ((rc = copy_in(e, e->status, st.data(), N * 4))) return rc;
     HIPCHK(hipStreamSynchronize(e->stream));
   }
   return MRE_OK;

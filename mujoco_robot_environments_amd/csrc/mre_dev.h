@@ -17,6 +17,7 @@ constexpr int NQ = 43;
 constexpr int NQP = 44;    // padded qpos row
 constexpr int NVP = 40;    // padded qvel row
 constexpr int NU = 8;
+constexpr int QFINE = 32;  // row of low-order state words: robot joint angles [0:15], velocities [16:31] (StepArgs::qfine)
 constexpr int NPROP = 4;
 constexpr int NG = 20;     // geoms: ground, table, robot hulls + pads, 4 cubes, then the hulls of arm links 1..4
 constexpr int PROP_GEOM0 = 12;  // geom id of cube 0 (cubes 12..15; checked against the blob in mre_create)
@@ -149,6 +150,9 @@ struct StepArgs {
   float* qpos;            // [N][NQP]
   float* qvel;            // [N][NVP]
   float* qacc_ws;         // [N][NVP]
+  float* qfine;           // [N][QFINE] or null: low-order words of the robot's state -- its 15 joint angles
+                          //  [0:15] and their velocities [16:31] are carried as unevaluated sums hi + lo of two
+                          //  floats (hi = the qpos / qvel row entry, i.e. the value rounded to float32)
   float* ctrl;            // [N][NU]  (held control / last applied control)
   const float* ctrl_seq;  // [T][seq_stride][NU] or null
   int seq_stride;         // envs per tick of ctrl_seq (the handle's env count; N may be a group of them)
@@ -165,6 +169,7 @@ struct StepArgs {
   // outputs
   float* sites;              // [N][16]: tcp_pos3, eef_pos3, eef_quat4, pad
   uint32_t* status;          // [N]
+  int* nstep;                // [N] or null: physics steps taken since the last reset (physics.data.time / timestep)
   int* stats;                // [N][4]
   float* trace;              // [max_steps][trace_nenv][NQP] or null
   int trace_nenv, trace_max, trace_base;
@@ -175,6 +180,16 @@ struct StepArgs {
   float* contacts;           // [N][1 + 3 * CONTACT_EXPORT] or null (F_DETECT): count, then (geom1, geom2, dist) each
   int* settle_steps;         // [N] or null (F_SETTLE_EXIT): physics steps the env took in this launch
   int min_settle_steps;
+  // capacity fallback (mre_api.cpp: launch_step): the launch is split between the compact and the large kernel by
+  // the per-env flag `large` (an env takes part in the kernel whose `want_large` equals its flag; null: every
+  // unmasked env takes part), and an env copies its state rows aside before it steps (sv_qpos != null), so that
+  // an env that overflows the compact capacities can be put back and re-run on the large kernel
+  const uint8_t* large;      // [N] or null
+  int want_large;
+  float *sv_qpos, *sv_qvel, *sv_qacc_ws, *sv_qfine, *sv_ctrl;
+  int* sv_nstep;
+  uint32_t* sv_status;
+  uint8_t* sv_converged;
   int* launch_info;          // [N][4] or null: {overflowed in this launch, max ncon | the env's own duration
                              //  in this launch (s_memtime ticks >> 10) << 16, max nefc, max robot rows | max cube-cube
                              //  contacts << 16} over the launch's steps

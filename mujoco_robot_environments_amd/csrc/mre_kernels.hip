@@ -53,8 +53,11 @@ constexpr int R1_MIN = TAB_BYTES - FRAME_BYTES > 0 ? TAB_BYTES - FRAME_BYTES : 4
 constexpr int MD_LD = 17;  // row stride of the dense robot mass matrix (Newton): odd, conflict-free columns
 
 struct Sm {
-  // state
-  float qpos[NQP], qvel[NVP], qacc_ws[NVP], ctrl[NU];
+  // state.  The robot's 15 joints are carried in double-float form: qpos / qvel hold the value rounded to
+  // float32 and qlo the remainder (angles [0:15], velocities [16:31]) -- see robot_q().  The warm start
+  // needs no array of its own: between the integration of one step and the solve of the next, qacc IS
+  // qacc_warmstart (mj_advance copies it), so the launch loads the warm-start row into qacc and stores qacc back.
+  float qpos[NQP], qvel[NVP], qlo[QFINE], ctrl[NU];
   // generalized vectors
   // (qfrc_con is dead between integrate and the next solve: its head carries the fp64-evaluated
   //  residuals of the two connect rows from connect_residuals to assemble_constraints)
@@ -93,6 +96,7 @@ struct Sm {
   int nprops;
   // active contacts (pair order)
   int ncon, nefc, nl, nrrow, npp, overflow, solver_iters;
+  int finger_contact;   // an active contact touches a finger body
   uint8_t con_pair[NCON_MAX], con_rslot[NCON_MAX], con_bslot[NCON_MAX], con_b1[NCON_MAX], con_b2[NCON_MAX];
   uint16_t lim_info[NRV + 1];
   // ---- contiguous block [JpA .. hdr]: written only after collision; hosts the per-lane
@@ -109,7 +113,12 @@ struct Sm {
   float JpB[3 * NPP_MAX][6];             // prop part B (cube-cube contacts only)
   union {
     float Jr[NRROW_MAX][NRV];
-    struct { float cdof_dot[NV][6], cvel[NB][6], cfrc[NB][6]; };  // velocity-stage temporaries (S1b)
+    struct {  // velocity-stage temporaries (S1b); gI / gS: every finger body's OWN spatial inertia and its cdof about
+              // the pinch site in the arm link's frame, fp64 (gripper_local -> finger_bias)
+      float cdof_dot[NV][6], cvel[NB][6], cfrc[NB][6];
+      alignas(8) double gI[NRB - GRIP_BODY0][10];
+      double gS[NRB - GRIP_BODY0][6];
+    };
   };
 #ifdef MRE_NEWTON
   // ---- Newton solver (mre_newton.h)
@@ -118,7 +127,7 @@ struct Sm {
   float con_fric[NCON_MAX];                    // friction coefficient of every contact
   float hc[NCON_MAX][6];                       // cone Hessian of contacts in the middle zone (00,01,02,11,12,22)
   float Md[NRV][MD_LD];                        // dense robot block of the mass matrix
-  float W[NV * (NV + 1) / 2];                  // Cholesky factor, packed by columns (transposed solve)
+  alignas(8) float W[NV * (NV + 1) / 2];       // Cholesky factor, packed by columns (transposed solve); after the solve: fp64 scratch of nw_robot_polish
   uint8_t rstate[NEFC_MAX];                    // row state after the last constraint update
   uint8_t clist[NPROP][NCON_MAX];              // contacts touching cube p (bit 7: the cube is part B)
   uint8_t ccount[NPROP], cpl_robot, cpl_cubes; // coupling of the Hessian blocks (robot-cube p, cube p-q)
@@ -152,6 +161,19 @@ static_assert(sizeof(Sm) <= 20480, "compact Sm must fit 8 workgroups per CU");
 struct BodyRegs {
   float anchor[3], axis[3], xipos[3], ximat[9];
 };
+
+// Angle / velocity of robot dof d (< NRV) with its low-order word added (fp64).
+// Why: a float32 joint angle is off by up to 3e-8 rad (fingers) .. 1.2e-7 rad (arm) after every step.  The soft
+// rows that close the 2F-85 four-bars turn a position error into K = 4e4 1/s^2 times as much acceleration, and links
+// of a few grams integrate that into 1e-4 .. 5e-3 rad within 600 .. 1000 steps; the arm's own rounding is a random
+// walk that reaches 4e-6 rad and shakes the fingers it carries by another 6 .. 9e-5 rad
+// (tests/diagnostics/finger_precision_study.py: the fp64 oracle with its whole state rounded to float32 after every
+// step leaves the 1e-4 bar in 7 .. 11 of 64 envs; with the 15 robot joints kept in fp64 and EVERY intermediate array
+// rounded to float32 it stays within 1.6e-5 in 64 of 64).  The quantities that see an angle through a stiff row read
+// the sum: the finger frame (hinge_local_d), the joint-equality and limit residuals, the tendon length and the
+// position actuators, and the integrator.  Everything else reads the float32 word.
+MRE_DEV double robot_q(const Sm& s, int d) { return (double)s.qpos[d] + (double)s.qlo[d]; }
+MRE_DEV double robot_v(const Sm& s, int d) { return (double)s.qvel[d] + (double)s.qlo[QFINE / 2 + d]; }
 
 MRE_DEV bool body_is_active(ModelP M, const Sm& s, int b) {
   int p = M->body_propid[b];
@@ -425,7 +447,7 @@ MRE_DEV void hinge_local_d(ModelP M, const Sm& s, int b, double* p, double* q) {
   for (int k = 0; k < 3; k++) { ax[k] = (double)M->jnt_axis[b][k]; jp[k] = (double)M->jnt_pos[b][k]; }
   const int qa = M->body_qposadr[b];
   double sn, cs;
-  sincos_poly_d(0.5 * ((double)s.qpos[qa] - (double)M->qpos0[qa]), sn, cs);
+  sincos_poly_d(0.5 * (robot_q(s, qa) - (double)M->qpos0[qa]), sn, cs);
   ql[0] = cs; ql[1] = ax[0] * sn; ql[2] = ax[1] * sn; ql[3] = ax[2] * sn;
   dq_mul(q, q0, ql);
   const double n = 1.0 / sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
@@ -508,6 +530,7 @@ MRE_PHASE_FN void gripper_local(ModelP M, Sm& s, int l) {
     const double O[3] = {(double)M->site_pos[ts][0], (double)M->site_pos[ts][1], (double)M->site_pos[ts][2]};
     double ci[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     inert_about_d(M, b, p, q, O, ci);
+    for (int k = 0; k < 10; k++) s.gI[b - GRIP_BODY0][k] = ci[k];
     for (int c = b + 1; c < NRB; c++) {
       if (M->body_parent[c] != b) continue;
       const double* cp = s.gpose[c - GRIP_BODY0];
@@ -527,7 +550,7 @@ MRE_PHASE_FN void gripper_local(ModelP M, Sm& s, int l) {
     P[3] = ci[8] * cd[1] - ci[7] * cd[2] + ci[9] * cd[3];
     P[4] = ci[6] * cd[2] - ci[8] * cd[0] + ci[9] * cd[4];
     P[5] = ci[7] * cd[0] - ci[6] * cd[1] + ci[9] * cd[5];
-    for (int k = 0; k < 6; k++) { s.gC[b - GRIP_BODY0][k] = (float)cd[k]; s.gP[b - GRIP_BODY0][k] = (float)P[k]; }
+    for (int k = 0; k < 6; k++) { s.gC[b - GRIP_BODY0][k] = (float)cd[k]; s.gP[b - GRIP_BODY0][k] = (float)P[k]; s.gS[b - GRIP_BODY0][k] = cd[k]; }
   }
   MRE_SYNC();
 }
@@ -889,6 +912,10 @@ MRE_PHASE_FN void velocity_stage(ModelP M, Sm& s, int l) {
   if (l >= 1 && l < NB) {
     const int b = l;
     ca[3] -= M->gravity[0]; ca[4] -= M->gravity[1]; ca[5] -= M->gravity[2];
+    if (l == LINK7) {   // spatial velocity and bias acceleration of the arm's last link, for finger_bias
+#pragma unroll
+      for (int t = 0; t < 6; t++) { s.scratch[t] = cv[t]; s.scratch[6 + t] = ca[t]; }
+    }
     float t0[6], t1[6], g[6];
     mul_inert_vec(t0, s.cinert[b], cv);
     cross_force(t1, cv, t0);
@@ -923,6 +950,116 @@ MRE_PHASE_FN void velocity_stage(ModelP M, Sm& s, int l) {
   }
 }
 
+// ---- mj_rne on the finger subtree in fp64 (lane = finger body)
+// The bias forces of the finger dofs are 1e-3 N m sums of terms that are 25 times larger in the c-frame (spatial
+// quantities about the robot's centre of mass, half a metre away): evaluated there in float32 they are off by a few
+// 1e-9 N m, and 3e-9 N m of noise on links of 1e-5 kg m^2 already costs 6e-5 rad over 1000 steps
+// (tests/diagnostics/finger_precision_study.py "e2e-7,1e-3,1,3e-9").  The same recursion is run here in the frame of
+// the arm's last link about the pinch site, where the terms are of the size of the result, in fp64, from link 7's
+// spatial velocity and bias acceleration (velocity_stage, float32: inputs of the recursion, a relative error there is
+// harmless) and gripper_local's fp64 inertias and cdofs; the result is rounded once.  Same operations as mj_rne:
+// cvel = cvel_parent + cdof qvel, cdof_dot = cvel_parent x cdof, cacc = cacc_parent + cdof_dot qvel,
+// cfrc = I cacc + cvel x* (I cvel), qfrc_bias = cdof . (cfrc summed over the subtree).
+MRE_DEV void dcross3(double* r, const double* a, const double* b) {
+  const double x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+MRE_DEV void dcross_motion(double* r, const double* vel, const double* v) {
+  double a[3], b[3];
+  dcross3(r, vel, v);
+  dcross3(a, vel, v + 3);
+  dcross3(b, vel + 3, v);
+  for (int k = 0; k < 3; k++) r[3 + k] = a[k] + b[k];
+}
+MRE_DEV void dcross_force(double* r, const double* vel, const double* f) {
+  double a[3], b[3];
+  dcross3(a, vel, f);
+  dcross3(b, vel + 3, f + 3);
+  for (int k = 0; k < 3; k++) r[k] = a[k] + b[k];
+  dcross3(r + 3, vel, f + 3);
+}
+MRE_DEV void dmul_inert_vec(double* r, const double* i, const double* v) {
+  r[0] = i[0] * v[0] + i[3] * v[1] + i[4] * v[2] - i[8] * v[4] + i[7] * v[5];
+  r[1] = i[3] * v[0] + i[1] * v[1] + i[5] * v[2] + i[8] * v[3] - i[6] * v[5];
+  r[2] = i[4] * v[0] + i[5] * v[1] + i[2] * v[2] - i[7] * v[3] + i[6] * v[4];
+  r[3] = i[8] * v[1] - i[7] * v[2] + i[9] * v[3];
+  r[4] = i[6] * v[2] - i[8] * v[0] + i[9] * v[4];
+  r[5] = i[7] * v[0] - i[6] * v[1] + i[9] * v[5];
+}
+MRE_DEV double dpp_shl1_d(double v) {   // the value of lane l + 1 (same DPP row; 0 past the row)
+  const long long b = __builtin_bit_cast(long long, v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xFFFFFFFFll), 0x101, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x101, 0xF, 0xF, false);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned)lo);
+}
+MRE_PHASE_FN void finger_bias(ModelP M, Sm& s, int l) {
+  constexpr int LINK7 = GRIP_BODY0 - 1;
+  const bool fin = l >= GRIP_BODY0 && l < NRB;
+  const int i = fin ? l - GRIP_BODY0 : 0;
+  // link 7's spatial velocity / bias acceleration: c-frame (about the robot's centre of mass, world axes) -> about
+  // the pinch site, axes of link 7
+  double V7[6], A7[6];
+  {
+    const float* R = s.xmat[LINK7];
+    float r[3];
+    v3sub(r, s.site_xpos[M->tcp_site], s.com_robot);
+    const double rd[3] = {(double)r[0], (double)r[1], (double)r[2]};
+    for (int h = 0; h < 2; h++) {
+      const float* c = &s.scratch[6 * h];
+      const double w[3] = {(double)c[0], (double)c[1], (double)c[2]};
+      double t[3];
+      dcross3(t, w, rd);
+      const double lin[3] = {(double)c[3] + t[0], (double)c[4] + t[1], (double)c[5] + t[2]};
+      double* o = h == 0 ? V7 : A7;
+      for (int k = 0; k < 3; k++) {   // R' x (R row-major: column k of R dotted with x)
+        o[k] = (double)R[k] * w[0] + (double)R[3 + k] * w[1] + (double)R[6 + k] * w[2];
+        o[3 + k] = (double)R[k] * lin[0] + (double)R[3 + k] * lin[1] + (double)R[6 + k] * lin[2];
+      }
+    }
+  }
+  double S[6], I[10];
+#pragma unroll
+  for (int k = 0; k < 6; k++) S[k] = fin ? s.gS[i][k] : 0.0;
+#pragma unroll
+  for (int k = 0; k < 10; k++) I[k] = fin ? s.gI[i][k] : 0.0;
+  const double qd = fin ? robot_v(s, l - 1) : 0.0;
+  // bodies 8, 10, 12, 14 hang off link 7; 9, 11, 13, 15 off the lane below (the tree mre_create checks)
+  const bool child = fin && M->body_parent[l] >= GRIP_BODY0;
+  double v[6], a0[6], sd[6];
+  dcross_motion(sd, V7, S);
+#pragma unroll
+  for (int k = 0; k < 6; k++) { v[k] = V7[k] + S[k] * qd; a0[k] = A7[k] + sd[k] * qd; }
+  double pv[6], pa[6];
+#pragma unroll
+  for (int k = 0; k < 6; k++) { pv[k] = dpp_shr1_d(v[k]); pa[k] = dpp_shr1_d(a0[k]); }
+  if (child) {
+    dcross_motion(sd, pv, S);
+#pragma unroll
+    for (int k = 0; k < 6; k++) { v[k] = pv[k] + S[k] * qd; a0[k] = pa[k] + sd[k] * qd; }
+  }
+  double f[6], t0[6], t1[6];
+  dmul_inert_vec(t0, I, v);
+  dcross_force(t1, v, t0);
+  dmul_inert_vec(f, I, a0);
+#pragma unroll
+  for (int k = 0; k < 6; k++) f[k] += t1[k];
+  // force on the subtree: a body off link 7 adds its child's (the lane above)
+  double up[6];
+#pragma unroll
+  for (int k = 0; k < 6; k++) up[k] = dpp_shl1_d(f[k]);
+  if (fin && !child) {
+#pragma unroll
+    for (int k = 0; k < 6; k++) f[k] += up[k];
+  }
+  if (fin) {
+    double b = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) b += S[k] * f[k];
+    s.qfrc_bias[l - 1] = (float)b;
+  }
+  MRE_SYNC();
+}
+
 // ------------------------- mj_fwdActuation + mj_passive + mj_fwdAcceleration
 // arm actuators (lanes 0..6) as `general` actuators on their joint: force -> qfrc_smooth[lane] (read back by
 // the same lane in smooth_forces); returns (wave-uniform) the mask of the actuators clamped by forcerange.
@@ -930,8 +1067,8 @@ MRE_PHASE_FN void velocity_stage(ModelP M, Sm& s, int l) {
 MRE_PHASE_FN unsigned arm_actuation(ModelP M, Sm& s, int l) {
   bool arm_clamped = false;
   if (l < 7) {
-    float fa = M->act_gain[l] * clampf(s.ctrl[l], M->act_ctrlrange[l][0], M->act_ctrlrange[l][1]) + M->act_bias[l][0] +
-               M->act_bias[l][1] * s.qpos[l] + M->act_bias[l][2] * s.qvel[l];
+    float fa = (float)((double)(M->act_gain[l] * clampf(s.ctrl[l], M->act_ctrlrange[l][0], M->act_ctrlrange[l][1]) + M->act_bias[l][0]) +
+                       (double)M->act_bias[l][1] * robot_q(s, l) + (double)M->act_bias[l][2] * robot_v(s, l));
     if (M->act_forcelimited[l]) {
       if (fa <= M->act_forcerange[l][0]) { fa = M->act_forcerange[l][0]; arm_clamped = true; }
       if (fa >= M->act_forcerange[l][1]) { fa = M->act_forcerange[l][1]; arm_clamped = true; }
@@ -945,10 +1082,13 @@ MRE_PHASE_FN unsigned arm_actuation(ModelP M, Sm& s, int l) {
 // NU - 1 = the finger actuator (mjd_actuator_vel skips those in the implicit integrator)
 MRE_DEV unsigned smooth_forces(ModelP M, Sm& s, int l) {
   const unsigned arm_mask = arm_actuation(M, s, l);
-  const float ten_len = M->ten_coef[0] * s.qpos[M->ten_dof[0]] + M->ten_coef[1] * s.qpos[M->ten_dof[1]];
-  const float ten_vel = M->ten_coef[0] * s.qvel[M->ten_dof[0]] + M->ten_coef[1] * s.qvel[M->ten_dof[1]];
+  // (the tendon length and velocity from the full finger state: the actuator's position gain of 100 N / rad acts on
+  //  joints with 5e-3 kg m^2 of armature)
+  const double ten_len = (double)M->ten_coef[0] * robot_q(s, M->ten_dof[0]) + (double)M->ten_coef[1] * robot_q(s, M->ten_dof[1]);
+  const double ten_vel = (double)M->ten_coef[0] * robot_v(s, M->ten_dof[0]) + (double)M->ten_coef[1] * robot_v(s, M->ten_dof[1]);
   const float cg = clampf(s.ctrl[NU - 1], M->act_ctrlrange[NU - 1][0], M->act_ctrlrange[NU - 1][1]);
-  float fg = M->grip_gainprm * cg + M->grip_biasprm[0] + M->grip_biasprm[1] * ten_len + M->grip_biasprm[2] * ten_vel;
+  float fg = (float)((double)(M->grip_gainprm * cg + M->grip_biasprm[0]) + (double)M->grip_biasprm[1] * ten_len +
+                     (double)M->grip_biasprm[2] * ten_vel);
   bool clamped = false;
   if (fg <= M->grip_forcerange[0]) { fg = M->grip_forcerange[0]; clamped = true; }
   if (fg >= M->grip_forcerange[1]) { fg = M->grip_forcerange[1]; clamped = true; }
@@ -957,13 +1097,16 @@ MRE_DEV unsigned smooth_forces(ModelP M, Sm& s, int l) {
     float f = 0.f;
     if (b < NRB) {
       // passive: spring + damper of the hinge
-      f = -M->jnt_stiffness[b] * (s.qpos[l] - M->jnt_springref[b]) - M->dof_damping[l] * s.qvel[l];
-      if (l < 7) f += s.qfrc_smooth[l];
-      if (l == M->ten_dof[0]) f += M->ten_coef[0] * fg;
-      if (l == M->ten_dof[1]) f += M->ten_coef[1] * fg;
+      // passive (spring + damper of the hinge), actuation and bias summed in fp64 and rounded once: the finger rows
+      // are 1e-3 N m results of 1e-1 N m terms
+      double fd = -(double)M->jnt_stiffness[b] * (robot_q(s, l) - (double)M->jnt_springref[b]) - (double)M->dof_damping[l] * robot_v(s, l);
+      if (l < 7) fd += (double)s.qfrc_smooth[l];
+      if (l == M->ten_dof[0]) fd += (double)M->ten_coef[0] * (double)fg;
+      if (l == M->ten_dof[1]) fd += (double)M->ten_coef[1] * (double)fg;
+      f = (float)(fd - (double)s.qfrc_bias[l]);
     }
     const bool act = body_is_active(M, s, b);
-    f = act ? f - s.qfrc_bias[l] : 0.f;
+    f = act ? (b < NRB ? f : f - s.qfrc_bias[l]) : 0.f;
     s.qfrc_smooth[l] = f;
     s.qacc_smooth[l] = f;
   }
@@ -981,10 +1124,15 @@ MRE_DEV unsigned smooth_forces(ModelP M, Sm& s, int l) {
 // ------------------------------------------- mj_implicit (implicitfast) + advance
 // part 1: MH and the right-hand side; the kernel body then factors MH (factor_robot_regs, inlined
 // there: a kernel has no callee-saved registers to spill) and calls part 2
+// Newton builds integrate the solver's ACCELERATION, not its forces: with f = M qacc (the gradient of the converged
+// primal problem is zero), (M - h D) x = f reads x = qacc + (M - h D)^-1 (h D qacc), D the diagonal derivative kept in
+// MH -- the second term is ~2 % of the first, so a float32 solve of it is good to 1e-8 of qacc, and the robot's
+// accelerations enter as the doubles of nw_robot_polish.  (PGS builds keep the force form: their qacc is
+// qacc_smooth + M^-1 J' f by construction.)
 MRE_PHASE_FN void integrate_setup(ModelP M, Sm& s, int l, unsigned act_clamped) {
   const bool grip_clamped = (act_clamped >> (NU - 1)) & 1u;
   const float h = M->timestep;
-  if (l < NVP) s.qacc_ws[l] = (l < NV) ? s.qacc[l] : 0.f;
+  // (mj_advance: qacc_warmstart = qacc -- the same array here, see Sm)
   // MH = M - h*dF/dv restricted to M's pattern (diagonal terms only here)
   for (int e = l; e < NMR; e += 64) {
     float v = s.qM[e];
@@ -998,19 +1146,33 @@ MRE_PHASE_FN void integrate_setup(ModelP M, Sm& s, int l, unsigned act_clamped) 
       }
     }
     s.qLD[e] = v;
+#ifdef MRE_NEWTON
+    if (i == M->M_j[e]) s.scratch[i] = (s.qM[e] - v) * s.qacc[i];   // h D_ii qacc_i
+#endif
   }
+#ifndef MRE_NEWTON
   if (l < NRV) s.scratch[l] = s.qfrc_smooth[l] + s.qfrc_con[l];
+#endif
   MRE_SYNC();
 }
 
 // part 2 (after the solve of MH x = f, also run from the kernel body): advance velocities and positions
-MRE_PHASE_FN void integrate(ModelP M, Sm& s, int l, unsigned flags) {
+MRE_PHASE_FN void integrate(ModelP M, Sm& s, int l, unsigned flags, bool polished) {
   const float h = M->timestep;
   const bool freeze = (flags & F_FREEZE_ROBOT) != 0;
   if (l < NV) {
     const int b = M->dof_body[l];
     if (b < NRB) {
-      if (!freeze) s.qvel[l] += h * s.scratch[l];
+      if (!freeze) {   // robot joint: the velocity advances in fp64 (double-float pair, robot_q)
+#ifdef MRE_NEWTON
+        const double acc = polished ? reinterpret_cast<const double*>(&s.nw_Mv[0])[l] : (double)s.qacc[l];
+        const double v = robot_v(s, l) + (double)h * (acc + (double)s.scratch[l]);
+#else
+        const double v = robot_v(s, l) + (double)h * (double)s.scratch[l];
+#endif
+        const float hi = (float)v;
+        s.qvel[l] = hi; s.qlo[QFINE / 2 + l] = (float)(v - (double)hi);
+      }
     } else if (body_is_active(M, s, b)) {
       s.qvel[l] += h * s.qacc[l];  // free joints carry no damping: MH = M on cube blocks
     }
@@ -1019,7 +1181,11 @@ MRE_PHASE_FN void integrate(ModelP M, Sm& s, int l, unsigned flags) {
   if (l >= 1 && l < NB) {
     const int b = l, qa = M->body_qposadr[b], da = M->body_dofadr[b];
     if (b < NRB) {
-      if (!freeze) s.qpos[qa] += h * s.qvel[da];
+      if (!freeze) {
+        const double q = robot_q(s, qa) + (double)h * robot_v(s, da);
+        const float hi = (float)q;
+        s.qpos[qa] = hi; s.qlo[qa] = (float)(q - (double)hi);
+      }
     } else if (body_is_active(M, s, b)) {
       for (int k = 0; k < 3; k++) s.qpos[qa + k] += h * s.qvel[da + k];
       float w[3] = {s.qvel[da + 3], s.qvel[da + 4], s.qvel[da + 5]};
@@ -1058,18 +1224,45 @@ MRE_DEV void step_body(const StepArgs& a, Sm& s) {
   if ((int)blockIdx.x >= a.N) return;
   const int env = a.env_order != nullptr ? a.env_order[blockIdx.x] : (int)blockIdx.x;
   const int l = threadIdx.x;
-  if (a.env_mask != nullptr && a.env_mask[env] == 0) return;
+  // the launch is split between the compact and the large kernel by the env's flag (capacity fallback)
+  if (a.large != nullptr && (a.large[env] != 0) != (a.want_large != 0)) return;
+  if (a.env_mask != nullptr && a.env_mask[env] == 0) {
+    // "not part of this launch" for the host's read of the launch info
+    if (a.launch_info != nullptr && l < 4) a.launch_info[(size_t)env * 4 + l] = -1;
+    return;
+  }
   ModelP M = (ModelP)a.M;
 
-  // ---- load state (one coalesced row per array)
-  if (l < NQP) s.qpos[l] = a.qpos[(size_t)env * NQP + l];
-  if (l < NVP) {
-    s.qvel[l] = a.qvel[(size_t)env * NVP + l];
-    s.qacc_ws[l] = a.qacc_ws[(size_t)env * NVP + l];
-    s.qfrc_con[l] = 0.f;
-    s.qacc[l] = 0.f;
+  // ---- load state (one coalesced row per array); with a save area, the rows as they were before this launch are
+  // copied aside on the way (the host puts an env that overflows the compact capacities back to them and re-runs it)
+  const bool save = a.sv_qpos != nullptr;
+  if (l < NQP) {
+    const float v = a.qpos[(size_t)env * NQP + l];
+    s.qpos[l] = v;
+    if (save) a.sv_qpos[(size_t)env * NQP + l] = v;
   }
-  if (l < NU) s.ctrl[l] = a.ctrl[(size_t)env * NU + l];
+  if (l < NVP) {
+    const float v = a.qvel[(size_t)env * NVP + l], w = a.qacc_ws[(size_t)env * NVP + l];
+    s.qvel[l] = v;
+    s.qacc[l] = w;      // warm start (see Sm)
+    s.qfrc_con[l] = 0.f;
+    if (save) { a.sv_qvel[(size_t)env * NVP + l] = v; a.sv_qacc_ws[(size_t)env * NVP + l] = w; }
+  }
+  if (l < QFINE) {
+    const float v = a.qfine != nullptr ? a.qfine[(size_t)env * QFINE + l] : 0.f;
+    s.qlo[l] = v;
+    if (save && a.qfine != nullptr) a.sv_qfine[(size_t)env * QFINE + l] = v;
+  }
+  if (l < NU) {
+    const float v = a.ctrl[(size_t)env * NU + l];
+    s.ctrl[l] = v;
+    if (save) a.sv_ctrl[(size_t)env * NU + l] = v;
+  }
+  if (save && l == 0) {
+    if (a.nstep != nullptr) a.sv_nstep[env] = a.nstep[env];
+    a.sv_status[env] = a.status[env];
+    a.sv_converged[env] = a.converged != nullptr ? a.converged[env] : (uint8_t)0;
+  }
   if (l == 0) { s.nprops = a.nprops[env]; s.overflow = 0; s.ncon = 0; s.nefc = 0; s.solver_iters = 0; }
 #ifdef MRE_NEWTON
   if (l < 24) s.zrow[l] = 0.f;
@@ -1130,6 +1323,7 @@ MRE_DEV void step_body(const StepArgs& a, Sm& s) {
 
     velocity_stage(M, s, l);
     MRE_SYNC();
+    finger_bias(M, s, l);
     MRE_STAMP(1);
     // ------------------------------------------------ S1c: collision + constraint assembly
     const bool constrained = (a.flags & F_NO_CONSTRAINTS) == 0;
@@ -1167,11 +1361,14 @@ MRE_DEV void step_body(const StepArgs& a, Sm& s) {
     MRE_STAMP(4);
     const unsigned clamped = smooth_forces(M, s, l);
     MRE_STAMP(5);
+    bool polished = false;
     if (constrained) {
 #if defined(MRE_NEWTON) && defined(MRE_PHASE_STAMPS)
       newton_solve(M, s, l, stamp_acc, stamp_t);
+      polished = nw_robot_polish(M, s, l);
 #elif defined(MRE_NEWTON)
       newton_solve(M, s, l);
+      polished = nw_robot_polish(M, s, l);
 #else
       solve_constraints(M, s, l);
 #endif
@@ -1183,7 +1380,7 @@ MRE_DEV void step_body(const StepArgs& a, Sm& s) {
 
     integrate_setup(M, s, l, clamped);
     factor_solve_robot(s.qLD, s.scratch, l);
-    integrate(M, s, l, a.flags);
+    integrate(M, s, l, a.flags, polished);
     steps_done = step + 1;
     if ((a.flags & F_SETTLE_EXIT) != 0) {
       // PropPlacer's settle test on this env's own cubes (prop_initializer.py:247-258)
@@ -1209,6 +1406,7 @@ MRE_DEV void step_body(const StepArgs& a, Sm& s) {
   }
   MRE_STAMP(7);
   if (a.settle_steps != nullptr && l == 0) a.settle_steps[env] = settled ? steps_done : -steps_done;
+  if (a.nstep != nullptr && l == 0) a.nstep[env] += steps_done;   // physics.data.time advances by steps_done * timestep
   if (a.nsteps == 0 && (a.flags & F_OSC_EVAL) != 0 && a.mode == CTRL_OSC) {
     // OSC.compute_control_output() on the current state (models/robot_arm.py:71): the position and
     // velocity stages the trailing mj_step1 would have left behind, then the torque law
@@ -1272,8 +1470,9 @@ MRE_DEV void step_body(const StepArgs& a, Sm& s) {
   if (l < NQP) a.qpos[(size_t)env * NQP + l] = s.qpos[l];
   if (l < NVP) {
     a.qvel[(size_t)env * NVP + l] = s.qvel[l];
-    a.qacc_ws[(size_t)env * NVP + l] = s.qacc_ws[l];
+    a.qacc_ws[(size_t)env * NVP + l] = l < NV ? s.qacc[l] : 0.f;
   }
+  if (l < QFINE && a.qfine != nullptr) a.qfine[(size_t)env * QFINE + l] = s.qlo[l];
   if (l < NU) a.ctrl[(size_t)env * NU + l] = s.ctrl[l];
   if (l == 0 && a.launch_info != nullptr) {
     int* li = a.launch_info + (size_t)env * 4;
@@ -1342,8 +1541,8 @@ extern "C" void mre_launch_settle_newton(const mre::StepArgs* args, hipStream_t 
 
 // Physics.reset() + arm home pose (tasks/rearrangement.py:302-306); cubes parked
 __global__ __launch_bounds__(64) void k_reset(const DevModel* M, int N, float* qpos, float* qvel,
-                                              float* qacc_ws, float* ctrl, uint32_t* status,
-                                              const uint8_t* mask) {
+                                              float* qacc_ws, float* qfine, float* ctrl, uint32_t* status,
+                                              int* nstep, const uint8_t* mask) {
   const int env = blockIdx.x, l = threadIdx.x;
   if (env >= N) return;
   if (mask != nullptr && mask[env] == 0) return;
@@ -1357,8 +1556,9 @@ __global__ __launch_bounds__(64) void k_reset(const DevModel* M, int N, float* q
     qpos[(size_t)env * NQP + l] = v;
   }
   if (l < NVP) { qvel[(size_t)env * NVP + l] = 0.f; qacc_ws[(size_t)env * NVP + l] = 0.f; }
+  if (l < QFINE) qfine[(size_t)env * QFINE + l] = 0.f;
   if (l < NU) ctrl[(size_t)env * NU + l] = 0.f;
-  if (l == 0) status[env] = 0u;
+  if (l == 0) { status[env] = 0u; nstep[env] = 0; }   // Physics.reset(): data.time = 0
 }
 
 // ---- demonstration logic around the step and the PropPlacer's rejection loop
@@ -1527,38 +1727,13 @@ __global__ __launch_bounds__(64) void k_sort_select(SortArgs a) {
   b[0] = zb[0]; b[1] = zb[1]; b[2] = a.place_z; b[3] = zb[2]; b[4] = zb[3]; b[5] = a.place_z;
 }
 
-// ---- capacity fallback helpers (mre_api.cpp: launch_step)
-// one pass before a guarded launch (one workgroup per env): copy the env's state rows aside, mark its
-// launch info "not part of this launch", and split the launch between the two kernels -- envs flagged
-// `large` run on the large-capacity kernel
-__global__ __launch_bounds__(64) void k_prepare(const uint8_t* user_mask, const uint8_t* large, int env0, int N,
-                                                uint8_t* mask_compact, uint8_t* mask_large, int* launch_info,
-                                                const float* qpos, float* sv_qpos, const float* qvel, float* sv_qvel,
-                                                const float* qacc_ws, float* sv_qacc_ws, const float* ctrl,
-                                                float* sv_ctrl, const uint32_t* status, uint32_t* sv_status,
-                                                const uint8_t* converged, uint8_t* sv_converged) {
-  const int env = env0 + blockIdx.x, l = threadIdx.x;   // envs [env0, env0 + N)
-  if ((int)blockIdx.x >= N) return;
-  if (l < NQP) sv_qpos[(size_t)env * NQP + l] = qpos[(size_t)env * NQP + l];
-  if (l < NVP) {
-    sv_qvel[(size_t)env * NVP + l] = qvel[(size_t)env * NVP + l];
-    sv_qacc_ws[(size_t)env * NVP + l] = qacc_ws[(size_t)env * NVP + l];
-  }
-  if (l < NU) sv_ctrl[(size_t)env * NU + l] = ctrl[(size_t)env * NU + l];
-  if (l < 4) launch_info[(size_t)env * 4 + l] = -1;
-  if (l == 0) {
-    sv_status[env] = status[env];
-    sv_converged[env] = converged[env];
-    const bool on = user_mask == nullptr || user_mask[env] != 0;
-    mask_compact[env] = on && !large[env];
-    mask_large[env] = on && large[env];
-  }
-}
-
+// ---- capacity fallback helper (mre_api.cpp: launch_step).  The state rows are copied aside by the step kernel
+// itself as it loads them (step_body), and the launch is split between the two kernels by StepArgs::large.
 // put the selected envs back to their saved pre-launch state (one workgroup per env)
 __global__ __launch_bounds__(64) void k_restore_rows(const uint8_t* sel, int env0, int N, float* qpos, const float* sv_qpos,
                                                      float* qvel, const float* sv_qvel, float* qacc_ws,
-                                                     const float* sv_qacc_ws, float* ctrl, const float* sv_ctrl,
+                                                     const float* sv_qacc_ws, float* qfine, const float* sv_qfine,
+                                                     float* ctrl, const float* sv_ctrl, int* nstep, const int* sv_nstep,
                                                      uint32_t* status, const uint32_t* sv_status, uint8_t* converged,
                                                      const uint8_t* sv_converged) {
   const int env = env0 + blockIdx.x, l = threadIdx.x;
@@ -1568,28 +1743,21 @@ __global__ __launch_bounds__(64) void k_restore_rows(const uint8_t* sel, int env
     qvel[(size_t)env * NVP + l] = sv_qvel[(size_t)env * NVP + l];
     qacc_ws[(size_t)env * NVP + l] = sv_qacc_ws[(size_t)env * NVP + l];
   }
+  if (l < QFINE) qfine[(size_t)env * QFINE + l] = sv_qfine[(size_t)env * QFINE + l];
   if (l < NU) ctrl[(size_t)env * NU + l] = sv_ctrl[(size_t)env * NU + l];
-  if (l == 0) { status[env] = sv_status[env]; converged[env] = sv_converged[env]; }
+  if (l == 0) { status[env] = sv_status[env]; converged[env] = sv_converged[env]; nstep[env] = sv_nstep[env]; }
 }
 
 }  // namespace mre
 
-extern "C" void mre_launch_prepare(const uint8_t* user_mask, const uint8_t* large, int env0, int N, uint8_t* mask_compact,
-                                   uint8_t* mask_large, int* launch_info, const float* qpos, float* sv_qpos,
-                                   const float* qvel, float* sv_qvel, const float* qacc_ws, float* sv_qacc_ws,
-                                   const float* ctrl, float* sv_ctrl, const uint32_t* status, uint32_t* sv_status,
-                                   const uint8_t* converged, uint8_t* sv_converged, hipStream_t stream) {
-  hipLaunchKernelGGL(mre::k_prepare, dim3(N), dim3(64), 0, stream, user_mask, large, env0, N, mask_compact, mask_large,
-                     launch_info, qpos, sv_qpos, qvel, sv_qvel, qacc_ws, sv_qacc_ws, ctrl, sv_ctrl, status, sv_status,
-                     converged, sv_converged);
-}
-
 extern "C" void mre_launch_restore_rows(const uint8_t* sel, int env0, int N, float* qpos, const float* sv_qpos, float* qvel,
-                                        const float* sv_qvel, float* qacc_ws, const float* sv_qacc_ws, float* ctrl,
-                                        const float* sv_ctrl, uint32_t* status, const uint32_t* sv_status,
+                                        const float* sv_qvel, float* qacc_ws, const float* sv_qacc_ws, float* qfine,
+                                        const float* sv_qfine, float* ctrl, const float* sv_ctrl, int* nstep,
+                                        const int* sv_nstep, uint32_t* status, const uint32_t* sv_status,
                                         uint8_t* converged, const uint8_t* sv_converged, hipStream_t stream) {
   hipLaunchKernelGGL(mre::k_restore_rows, dim3(N), dim3(64), 0, stream, sel, env0, N, qpos, sv_qpos, qvel, sv_qvel,
-                     qacc_ws, sv_qacc_ws, ctrl, sv_ctrl, status, sv_status, converged, sv_converged);
+                     qacc_ws, sv_qacc_ws, qfine, sv_qfine, ctrl, sv_ctrl, nstep, sv_nstep, status, sv_status, converged,
+                     sv_converged);
 }
 
 extern "C" void mre_launch_pose_search(const mre::SearchArgs* args, hipStream_t stream) {
@@ -1600,9 +1768,10 @@ extern "C" void mre_launch_sort_select(const mre::SortArgs* args, hipStream_t st
   hipLaunchKernelGGL(mre::k_sort_select, dim3((args->N + 63) / 64), dim3(64), 0, stream, *args);
 }
 
-extern "C" void mre_launch_reset(const mre::DevModel* M, int N, float* qpos, float* qvel, float* qacc_ws,
-                                 float* ctrl, uint32_t* status, const uint8_t* mask, hipStream_t stream) {
-  hipLaunchKernelGGL(mre::k_reset, dim3(N), dim3(64), 0, stream, M, N, qpos, qvel, qacc_ws, ctrl, status, mask);
+extern "C" void mre_launch_reset(const mre::DevModel* M, int N, float* qpos, float* qvel, float* qacc_ws, float* qfine,
+                                 float* ctrl, uint32_t* status, int* nstep, const uint8_t* mask, hipStream_t stream) {
+  hipLaunchKernelGGL(mre::k_reset, dim3(N), dim3(64), 0, stream, M, N, qpos, qvel, qacc_ws, qfine, ctrl, status, nstep,
+                     mask);
 }
 
 extern "C" void mre_launch_step(const mre::StepArgs* args, hipStream_t stream) {

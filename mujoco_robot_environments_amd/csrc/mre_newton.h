@@ -338,11 +338,11 @@ MRE_PHASE_FN float nw_setup(ModelP M, Sm& s, int l) {
   MRE_SYNC();
   const bool on = l < NV && c.lact;
   const float fs = on ? s.qfrc_smooth[l] : 0.f, as = on ? s.qacc_smooth[l] : 0.f;
-  float qa = on ? s.qacc_ws[l] : 0.f;
-  float Ma = on ? nw_mulM(s, l, c.mdiag, s.qacc_ws) : 0.f;
+  float qa = on ? s.qacc[l] : 0.f;
+  float Ma = on ? nw_mulM(s, l, c.mdiag, s.qacc) : 0.f;
   for (int i = l; i < nefc; i += 64) {
     const float aref = s.efc_aref[i];
-    s.jar[i] = row_dot(s, i, s.qacc_ws) - aref;
+    s.jar[i] = row_dot(s, i, s.qacc) - aref;
     s.jv[i] = row_dot(s, i, s.qacc_smooth) - aref;
   }
   MRE_SYNC();
@@ -827,6 +827,155 @@ MRE_DEV void newton_solve(ModelP M, Sm& s, int l) {
   if (l < NVP && !(l < NV)) s.qacc[l] = 0.f;
   if (l == 0) s.solver_iters = iter | (nfull << 8);
   MRE_SYNC();
+}
+
+// ------------------------------------------------------------- robot polish
+// What the float32 Newton iteration cannot deliver is the acceleration of the robot's light or stiffly held parts.
+// The finger rows of the gradient are sums of +-0.75 N m (25 N of closure force on 3 cm levers) that leave ~1e-3 N m,
+// so the converged iterate carries ~5e-8 N m of rounding there -- on the 2F-85's gram-sized links an error of 1e-4 ..
+// 1e-3 rad/s^2 per step (tests/diagnostics/finger_onestep.py), which the follower mode (5 rad/s, damping ratio
+// 0.06) integrates to 1e-4 .. 2e-4 rad within 1000 steps; an arm link pressed on the table or a cube (100 N on a
+// row with R = 1e-4) leaves 1e-3 .. 7e-3 rad/s^2 on the ARM dofs, which shakes the fingers the arm carries.  The
+// cure is one exact Newton step on the robot's fifteen dofs with the cubes' accelerations held: the robot rows of the
+// gradient and the 15 x 15 robot block of H = M + J' D J (+ cone Hessians) are formed in fp64 FROM THE SAME float32
+// arrays the solver used (Md, Jr, R, aref, qfrc_smooth: their single roundings do not matter -- the oracle with all
+// of them rounded to float32 stays within 1.6e-5 of itself over 1000 steps; what matters is that the block is solved
+// exactly for them: tests/diagnostics/finger_precision_study.py "e2e-7,1e-3,2"), the block is eliminated in fp64 with
+// row i in the registers of lane i (pivot rows by v_readlane), and the robot's accelerations leave as doubles
+// (Sm::nw_Mv reused) for the integrator.
+// Rows: the 7 equality rows, the joint-limit rows (active set as the solver left it) and every contact with a robot
+// part (forces and 3 x 3 weights -- diag(D) in the quadratic zone, the cone Hessian in the middle zone -- re-evaluated
+// in fp64 at the iterate).  Returns true when the doubles are valid (false: more than NW_POLISH_CON robot contacts).
+MRE_DEV double rdlane_d(double v, int lane) {
+  const long long b = __builtin_bit_cast(long long, v);
+  const int lo = __builtin_amdgcn_readlane((int)(b & 0xFFFFFFFFll), lane);
+  const int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned)lo);
+}
+MRE_PHASE_FN bool nw_robot_polish(ModelP M, Sm& s, int l) {
+  static_assert(offsetof(Sm, W) % 8 == 0 && offsetof(Sm, nw_Mv) % 8 == 0, "fp64 views of W / nw_Mv");
+  constexpr int MAXROW = 7 + NRV;   // equality + every joint at a limit
+  constexpr int NW_POLISH_CON = 32; // robot contacts at most
+  static_assert(sizeof(((Sm*)0)->W) >= 8 * (2 * MAXROW + 10 * NW_POLISH_CON), "exchange area");
+  static_assert(sizeof(((Sm*)0)->nw_Mv) >= 8 * NRV, "fp64 accelerations out");
+  double* const frow = reinterpret_cast<double*>(&s.W[0]);   // [MAXROW] force of scalar row r
+  double* const drow = frow + MAXROW;                         // [MAXROW] D of row r if it is active, else 0
+  double* const fcon = drow + MAXROW;                         // [NW_POLISH_CON][10]: force 3, weight 6 (00 01 02 11 12 22), robot slot
+  double* const a64 = reinterpret_cast<double*>(&s.nw_Mv[0]); // [NRV] out
+  const int nscalar = 7 + s.nl, ncon = s.ncon;
+  // ---- lane = contact: the ones with a robot part, compacted by a ballot prefix count
+  int nrc = 0;
+  {
+    const int rs = l < ncon ? (int)s.con_rslot[l] : HDR_NONE;
+    const bool mine = rs != HDR_NONE;
+    const unsigned long long m = __ballot(mine);
+    nrc = __popcll(m);
+    if (nrc > NW_POLISH_CON) return false;
+    if (mine) {
+      const int k = __popcll(m & ((1ull << l) - 1ull));
+      const int i = nscalar + 3 * l, h = s.hdr[i];
+      const int pa = (h >> 8) & 0xF, pb = (h >> 12) & 0xF;
+      double j[3], D[3];
+#pragma unroll
+      for (int r = 0; r < 3; r++) {
+        double acc = -(double)s.efc_aref[i + r];
+#pragma unroll
+        for (int c = 0; c < NRV; c++) acc += (double)s.Jr[rs + r][c] * (double)s.qacc[c];
+        if (pa < NPROP) { const float* ja = jpA(s, i + r); for (int c = 0; c < 6; c++) acc += (double)ja[c] * (double)s.qacc[NRV + 6 * pa + c]; }
+        if (pb < NPROP) { const float* jb = jpB(s, i + r); for (int c = 0; c < 6; c++) acc += (double)jb[c] * (double)s.qacc[NRV + 6 * pb + c]; }
+        j[r] = acc;
+        D[r] = 1.0 / (double)s.efc_R[i + r];
+      }
+      // mj_constraintUpdate for one elliptic contact (nw_contact), fp64
+      const double fr = (double)s.con_fric[l], mu = fr * sqrt((double)s.efc_R[i + 1] / (double)s.efc_R[i]);
+      const double U1 = j[1] * fr, U2 = j[2] * fr, Nn = j[0] * mu, T = sqrt(U1 * U1 + U2 * U2);
+      double* o = fcon + 10 * k;
+#pragma unroll
+      for (int t = 0; t < 9; t++) o[t] = 0.0;
+      o[9] = (double)rs;
+      if (Nn >= mu * T || (T <= 0.0 && Nn >= 0.0)) {
+        // top zone: no force
+      } else if (mu * Nn + T <= 0.0 || (T <= 0.0 && Nn < 0.0)) {
+        o[0] = -D[0] * j[0]; o[1] = -D[1] * j[1]; o[2] = -D[2] * j[2];
+        o[3] = D[0]; o[6] = D[1]; o[8] = D[2];
+      } else {
+        const double Dm = D[0] / fmax(mu * mu * (1.0 + mu * mu), 1e-15), NT = Nn - mu * T, iT = 1.0 / T;
+        o[0] = -Dm * NT * mu;
+        o[1] = -o[0] * iT * U1 * fr;
+        o[2] = -o[0] * iT * U2 * fr;
+        const double a = mu * Nn * iT * iT * iT, dgn = mu * mu - mu * Nn * iT;
+        o[3] = Dm * mu * mu;
+        o[4] = Dm * mu * fr * (-mu * U1 * iT);
+        o[5] = Dm * mu * fr * (-mu * U2 * iT);
+        o[6] = Dm * fr * fr * (a * U1 * U1 + dgn);
+        o[7] = Dm * fr * fr * (a * U1 * U2);
+        o[8] = Dm * fr * fr * (a * U2 * U2 + dgn);
+      }
+    }
+  }
+  // ---- lane = scalar row: J a - aref and the force, fp64
+  if (l < nscalar) {
+    double jar = -(double)s.efc_aref[l];
+#pragma unroll
+    for (int j = 0; j < NRV; j++) jar += (double)s.Jr[l][j] * (double)s.qacc[j];
+    const bool act = l < 7 || s.rstate[l] == NW_QUAD;
+    const double D = act ? 1.0 / (double)s.efc_R[l] : 0.0;
+    frow[l] = -D * jar;
+    drow[l] = D;
+  }
+  MRE_SYNC();
+  // ---- lane = robot dof: its row of the Hessian block and of the gradient (lanes past the robot: an identity row)
+  const int d = l < NRV ? l : 0;
+  double hrow[NRV], g = 0.0;
+#pragma unroll
+  for (int j = 0; j < NRV; j++) hrow[j] = (l < NRV) ? (double)s.Md[d][j] : 0.0;
+  if (l < NRV) {
+    g = -(double)s.qfrc_smooth[d];
+#pragma unroll
+    for (int j = 0; j < NRV; j++) g += (double)s.Md[d][j] * (double)s.qacc[j];
+    for (int r = 0; r < nscalar; r++) {
+      const double jd = (double)s.Jr[r][d];
+      g -= jd * frow[r];
+      const double t = drow[r] * jd;
+#pragma unroll
+      for (int j = 0; j < NRV; j++) hrow[j] += t * (double)s.Jr[r][j];
+    }
+    for (int k = 0; k < nrc; k++) {
+      const double* o = fcon + 10 * k;
+      const int rs = (int)o[9];
+      const double j0 = (double)s.Jr[rs][d], j1 = (double)s.Jr[rs + 1][d], j2 = (double)s.Jr[rs + 2][d];
+      g -= j0 * o[0] + j1 * o[1] + j2 * o[2];
+      const double t0 = j0 * o[3] + j1 * o[4] + j2 * o[5], t1 = j0 * o[4] + j1 * o[6] + j2 * o[7],
+                   t2 = j0 * o[5] + j1 * o[7] + j2 * o[8];
+#pragma unroll
+      for (int j = 0; j < NRV; j++)
+        hrow[j] += t0 * (double)s.Jr[rs][j] + t1 * (double)s.Jr[rs + 1][j] + t2 * (double)s.Jr[rs + 2][j];
+    }
+  }
+  // ---- elimination: row i in lane i, pivot row k read from lane k; x = -H^-1 g
+  double x = -g;
+#pragma unroll
+  for (int k = 0; k < NRV - 1; k++) {
+    const double inv = 1.0 / rdlane_d(hrow[k], k);
+    const double xk = rdlane_d(x, k);
+    const double mlt = (l > k && l < NRV) ? hrow[k] * inv : 0.0;
+#pragma unroll
+    for (int j = k + 1; j < NRV; j++) hrow[j] -= mlt * rdlane_d(hrow[j], k);
+    x -= mlt * xk;
+  }
+#pragma unroll
+  for (int k = NRV - 1; k >= 0; k--) {
+    const double xk = rdlane_d(x, k) / rdlane_d(hrow[k], k);   // (uniform: every lane computes the same quotient)
+    if (l == k) x = xk;
+    else if (l < k) x -= hrow[k] * xk;
+  }
+  if (l < NRV) {
+    const double a = (double)s.qacc[l] + x;
+    a64[l] = a;
+    s.qacc[l] = (float)a;
+  }
+  MRE_SYNC();
+  return true;
 }
 
 }  // namespace mre

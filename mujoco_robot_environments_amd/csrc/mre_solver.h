@@ -310,9 +310,9 @@ MRE_PHASE_FN void assemble_constraints(ModelP M, Sm& s, int l) {
   // ---- joint limits: lane = robot body; at most one side can be violated
   int lim = 0, lim_side = 0;
   if (l >= 1 && l < NRB && M->jnt_limited[l]) {
-    const float q = s.qpos[l - 1];
-    if (q - M->jnt_range[l][0] < 0.f) { lim = 1; lim_side = -1; }
-    else if (M->jnt_range[l][1] - q < 0.f) { lim = 1; lim_side = 1; }
+    const double q = robot_q(s, l - 1);   // (the full double-float angle, mre_kernels.hip: robot_q)
+    if (q - (double)M->jnt_range[l][0] < 0.0) { lim = 1; lim_side = -1; }
+    else if ((double)M->jnt_range[l][1] - q < 0.0) { lim = 1; lim_side = 1; }
   }
   // (rows in joint order: the row index of a violated limit is the number of violated limits on the lanes below)
   const unsigned long long limm = __ballot(lim != 0);
@@ -341,6 +341,8 @@ MRE_PHASE_FN void assemble_constraints(ModelP M, Sm& s, int l) {
     const bool on = l < ncon0;
     const int cb1 = on ? s.con_b1[l] : 0, cb2 = on ? s.con_b2[l] : 0;
     const bool rob_any = on && ((cb1 < NRB && cb1 > 0) || (cb2 < NRB && cb2 > 0));
+    const bool fing = on && ((cb1 >= GRIP_BODY0 && cb1 < NRB) || (cb2 >= GRIP_BODY0 && cb2 < NRB));
+    const unsigned long long fingm = __ballot(fing);
     const bool two_props = on && cb1 >= NRB && cb2 >= NRB;
     const unsigned long long lt = (1ull << l) - 1ull;
     const unsigned long long rmask = __ballot(rob_any), tmask = __ballot(two_props);
@@ -361,6 +363,7 @@ MRE_PHASE_FN void assemble_constraints(ModelP M, Sm& s, int l) {
       s.nefc = base + 3 * kept;
       s.nrrow = base + 3 * __popcll(rmask & below);
       s.npp = __popcll(tmask & below);
+      s.finger_contact = (fingm & below) != 0ull;
 #ifdef MRE_NEWTON
       s.nsched = 0; s.nblk = 0;  // (contact lists of the Newton solver: nw_build_lists, mre_newton.h)
 #else
@@ -419,9 +422,11 @@ MRE_PHASE_FN void assemble_constraints(ModelP M, Sm& s, int l) {
         const int b1 = M->eq_obj[e][0], b2 = M->eq_obj[e][1];
         const int d1 = b1 - 1, d2 = b2 - 1;
         const float* pc = M->eq_data[e];
-        const float dif = s.qpos[d2] - M->qpos0[d2];
-        pos = s.qpos[d1] - M->qpos0[d1] -
-              (pc[0] + dif * (pc[1] + dif * (pc[2] + dif * (pc[3] + dif * pc[4]))));
+        // (the residual of two finger angles that track each other to 1e-5 rad: evaluated on the full angles)
+        const double dif64 = robot_q(s, d2) - (double)M->qpos0[d2];
+        pos = (float)(robot_q(s, d1) - (double)M->qpos0[d1] -
+                      ((double)pc[0] + dif64 * ((double)pc[1] + dif64 * ((double)pc[2] + dif64 * ((double)pc[3] + dif64 * (double)pc[4])))));
+        const float dif = (float)dif64;
         const float deriv = pc[1] + dif * (2.f * pc[2] + dif * (3.f * pc[3] + dif * 4.f * pc[4]));
         s.Jr[rs][d1] += 1.f;
         s.Jr[rs][d2] -= deriv;
@@ -431,8 +436,8 @@ MRE_PHASE_FN void assemble_constraints(ModelP M, Sm& s, int l) {
     } else if (i < 7 + nl) {
       rs = i;
       const int info = s.lim_info[i - 7], b = info & 0xFF, hi = (info >> 8) & 1;
-      const float q = s.qpos[b - 1];
-      pos = hi ? (M->jnt_range[b][1] - q) : (q - M->jnt_range[b][0]);
+      const double q = robot_q(s, b - 1);
+      pos = (float)(hi ? ((double)M->jnt_range[b][1] - q) : (q - (double)M->jnt_range[b][0]));
       s.Jr[rs][b - 1] = hi ? -1.f : 1.f;
       imp_pos = pos;
       diag = M->dof_invweight0[b - 1];
@@ -681,7 +686,7 @@ MRE_PHASE_FN void solve_constraints(ModelP M, Sm& s, int l) {
   // ---- efc_b and warm-start forces (mj_constraintUpdate on J*qacc_warmstart - aref)
   for (int i = l; i < nefc; i += 64) {
     const float aref = rowB(s, i);
-    jar[i] = row_dot(s, i, s.qacc_ws) - aref;
+    jar[i] = row_dot(s, i, s.qacc) - aref;
     rowB(s, i) = row_dot(s, i, s.qacc_smooth) - aref;
   }
   MRE_SYNC();

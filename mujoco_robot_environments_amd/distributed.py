@@ -31,7 +31,7 @@ def pack_final_state(qpos: np.ndarray, qvel: np.ndarray, status: np.ndarray) -> 
 
 def gather_final_state(local: torch.Tensor) -> torch.Tensor:
     """all_gather_into_tensor along the env axis; row order = global env id."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return local
     out = torch.empty((dist.get_world_size() * local.shape[0], local.shape[1]), dtype=local.dtype,
                       device=local.device)

@@ -27,11 +27,23 @@ EXPORTS = [
     "mre_run_controller", "mre_get_sites", "mre_get_status", "mre_get_solver_stats",
     "mre_profile_enable", "mre_profile_read", "mre_set_env_id_offset", "mre_set_env_order",
     "mre_set_fallback", "mre_get_fallback_stats", "mre_set_solver", "mre_get_solver", "mre_wait_stream", "mre_osc_compute", "mre_get_contacts", "mre_get_settle_steps", "mre_get_launch_info", "mre_prop_place", "mre_sort_colours", "mre_crc32c", "mre_osc_configure_env", "mre_set_env_ids", "mre_set_render_colours", "mre_render",
+    "mre_get_state_f64", "mre_set_state_f64", "mre_get_time",
 ]
 
 
 class MreError(RuntimeError):
     pass
+
+
+def source_hash() -> str:
+    """sha256 (16 hex digits) over the sources libmre.so is built from: what a profile summary must have been
+    taken on for its counters to describe the build being run (bench.py, tools/summarize_profiles.py)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(_SOURCES + _HEADERS):
+        with open(os.path.join(_CSRC, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
 
 
 def needs_build() -> bool:
@@ -106,6 +118,9 @@ def lib() -> C.CDLL:
     L.mre_place_props.argtypes = [vp, fp, C.c_uint64, fp, fp, ci, ci]
     L.mre_set_state.argtypes = [vp, fp, fp]
     L.mre_get_state.argtypes = [vp, fp, fp]
+    L.mre_get_state_f64.argtypes = [vp, fp, fp]
+    L.mre_set_state_f64.argtypes = [vp, fp, fp]
+    L.mre_get_time.argtypes = [vp, fp]
     L.mre_get_ctrl.argtypes = [vp, fp]
     L.mre_set_warmstart.argtypes = [vp, fp]
     L.mre_get_warmstart.argtypes = [vp, fp]

@@ -82,6 +82,11 @@ class BatchedPhysics:
         if not hasattr(self, "_keepalive"):
             self._keepalive = []
         self._keepalive.extend(tensors)
+        # the library reads an argument at the call (a rollout's control rows are copied on the handle's stream, and a
+        # stepping call first completes the previous launch of every env group, which follows the previous copy): only
+        # the arguments of the last few calls can still be in flight, so a loop that never calls sync() holds a bounded
+        # number of tensors
+        del self._keepalive[:-8]
 
     def set_solver(self, solver: str) -> None:
         """mjOption.solver of a live handle: "PGS" or "Newton" (state and warm start carry over)."""
@@ -173,6 +178,26 @@ class BatchedPhysics:
 
     def qpos(self) -> np.ndarray:
         return self.get_state()[0]
+
+    def get_state_f64(self):
+        """physics.data.qpos / .qvel as float64 [N, 43] / [N, 39]: the finger joints with the low-order words the
+        device carries for them (mre_get_state_f64), every other coordinate the float32 value."""
+        q = np.empty((self.num_envs, MRE_NQ), np.float64)
+        v = np.empty((self.num_envs, MRE_NV), np.float64)
+        check(_lib.lib().mre_get_state_f64(self._h, _ptr(q), _ptr(v)), "mre_get_state_f64")
+        return q, v
+
+    def set_state_f64(self, qpos=None, qvel=None) -> None:
+        q = None if qpos is None else np.ascontiguousarray(np.asarray(qpos, np.float64)[:, :MRE_NQ])
+        v = None if qvel is None else np.ascontiguousarray(np.asarray(qvel, np.float64)[:, :MRE_NV])
+        check(_lib.lib().mre_set_state_f64(self._h, _ptr(q) if q is not None else None,
+                                           _ptr(v) if v is not None else None), "mre_set_state_f64")
+
+    def time(self) -> np.ndarray:
+        """physics.data.time per env [N] (seconds of physics since the last reset)."""
+        t = np.empty(self.num_envs, np.float64)
+        check(_lib.lib().mre_get_time(self._h, _ptr(t)), "mre_get_time")
+        return t
 
     def qvel(self) -> np.ndarray:
         return self.get_state()[1]

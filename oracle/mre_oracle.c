@@ -78,7 +78,7 @@ struct mro_data {
   int nprops, freeze_robot, no_constraints, ncon_cap, nefc_cap, nrrow_cap, npp_cap, overflow;
   int round32;   /* diagnostic (mro_set_round32): intermediate arrays rounded to float32, see mre_oracle.h */
   /* diagnostic (mro_set_emulation): a device-like error on the solver's output and the device's cure for it */
-  double emu_rel_arm, emu_abs_finger;
+  double emu_rel_arm, emu_abs_finger, emu_abs_bias;
   int emu_polish;
   unsigned long long emu_rng;
   int body_active[MRO_MAXB], dof_active[MRO_MAXV];
@@ -1173,6 +1173,7 @@ static void fwd_actuation(const mro_model* m, mro_data* d) {
     }
   }
 }
+static double emu_gauss(mro_data* d);
 /* ---------------------------------------------------- mj_fwdAcceleration */
 static void fwd_acceleration(const mro_model* m, mro_data* d) {
   for (int i = 0; i < m->nv; i++) {
@@ -1181,6 +1182,8 @@ static void fwd_acceleration(const mro_model* m, mro_data* d) {
                             : 0.0;
     d->qacc_smooth[i] = d->qfrc_smooth[i];
   }
+  if (d->emu_abs_bias > 0)   /* a float32 RNE about the robot's centre of mass: absolute error on the finger rows */
+    for (int i = 7; i < 15; i++) { d->qfrc_smooth[i] += d->emu_abs_bias * emu_gauss(d); d->qacc_smooth[i] = d->qfrc_smooth[i]; }
   if (d->round32 & 8) round32(d->qfrc_smooth, m->nv);
   solve_ld(m, d->qLD, d->qLDiagInv, d->qacc_smooth);
   if (d->round32 & 8) round32(d->qacc_smooth, m->nv);
@@ -1843,6 +1846,7 @@ static void emulate_device_solver(const mro_model* m, mro_data* d) {
   for (int k = 0; k < nv; k++) d->qfrc_constraint[k] = Ma[k] - d->qfrc_smooth[k];
 }
 
+void mro_set_bias_noise(mro_data* d, double abs_bias) { d->emu_abs_bias = abs_bias; if (!d->emu_rng) d->emu_rng = 0x2545F4914F6CDD1Dull; }
 static void step2(const mro_model* m, mro_data* d) {
   fwd_actuation(m, d);
   fwd_acceleration(m, d);

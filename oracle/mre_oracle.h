@@ -62,6 +62,8 @@ void mro_set_round32(mro_data*, int mask);
  * block of dofs with the others held (polish 1: finger dofs, 2: all robot dofs) -- mre_oracle.c:
  * emulate_device_solver.  All zeros = the plain oracle. */
 void mro_set_emulation(mro_data*, double rel_arm, double abs_finger, int polish, unsigned long long seed);
+/* Diagnostic: Gaussian error of `abs_bias` N m on the finger rows of qfrc_smooth (a float32 bias force) */
+void mro_set_bias_noise(mro_data*, double abs_bias);
 /* test switches: drop all constraints (smooth-dynamics parity slice); emulate the
  * device capacity limits (active contacts / rows beyond the caps are dropped) */
 void mro_set_no_constraints(mro_data*, int flag);

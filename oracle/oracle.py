@@ -52,6 +52,7 @@ def lib() -> C.CDLL:
         L.mro_set_no_constraints.argtypes = [C.c_void_p, C.c_int]
         L.mro_set_round32.argtypes = [C.c_void_p, C.c_int]
         L.mro_set_emulation.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_ulonglong]
+        L.mro_set_bias_noise.argtypes = [C.c_void_p, C.c_double]
         L.mro_set_caps.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
         L.mro_overflow.argtypes = [C.c_void_p]
         L.mro_set_solver.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double]
@@ -139,6 +140,9 @@ class Env:
     def emulate(self, rel_arm: float = 0.0, abs_finger: float = 0.0, polish: int = 0, seed: int = 1):
         """Diagnostic: device-like solver error + block polish (oracle/mre_oracle.h: mro_set_emulation)."""
         lib().mro_set_emulation(self.ptr, float(rel_arm), float(abs_finger), int(polish), int(seed))
+
+    def bias_noise(self, abs_bias: float):
+        lib().mro_set_bias_noise(self.ptr, float(abs_bias))
 
     def no_constraints(self, flag: bool):
         lib().mro_set_no_constraints(self.ptr, int(flag))

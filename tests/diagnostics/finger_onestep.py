@@ -24,6 +24,8 @@ def main():
     solver = sys.argv[1] if len(sys.argv) > 1 else "Newton"
     probes = int(sys.argv[2]) if len(sys.argv) > 2 else 40
     N, seed, scale, cs, T0 = 64, 5, 1.0, 5, 300
+    T0 = int(sys.argv[3]) if len(sys.argv) > 3 else T0          # oracle-only warm-up steps before the first probe
+    detail = int(sys.argv[4]) if len(sys.argv) > 4 else -1      # print this env's error probe by probe
     A = MC.compile_scene()
     om = O.Model(MC.to_blob(A))
     ids = np.arange(N)
@@ -72,6 +74,11 @@ def main():
             e.step(cs - 1)                               # move on (a fresh state for the next probe)
         errs.append(((v1 - v) - dvo)[:, :15] / h)
         accs.append(dvo[:, :15] / h)
+        if detail >= 0:
+            e1 = np.abs(errs[-1][detail])
+            st = phys.solver_stats()[detail]
+            print(f"  step {T0 + k * cs}: env {detail} arm err {e1[:7].max():.2e} finger err {e1[7:].max():.2e} (dof {7 + int(e1[7:].argmax())}) "
+                  f"ncon {st[0]} nefc {st[1]} iters {st[2] & 255} nl {st[3]}  finger acc {np.round(accs[-1][detail][7:], 1).tolist()}")
     err = np.abs(np.stack(errs))          # [probes, N, 15]
     acc = np.abs(np.stack(accs))
     names = ["arm%d" % j for j in range(7)] + ["f%d" % j for j in range(8)]

@@ -125,7 +125,9 @@ def main():
             print(f"{name:6s} robot64+r511 emu rel_arm {em[0]:.0e} abs_finger {em[1]:.0e} polish {int(em[2])} bias noise {em[3] if len(em) > 3 else 0:.0e}: under the bar "
                   f"{int((first >= w.shape[0]).sum())}/{N}, {sum(switched)} census switches; max err arm {err[:, :, :7].max():.1e} "
                   f"fingers {err[:, :, 7:15].max():.1e}; worst finger envs without a switch "
-                  f"{sorted([(round(float(err[:, i, 7:15].max()), 7), i) for i in range(N) if not switched[i]])[-3:]}", flush=True)
+                  f"{sorted([(round(float(err[:, i, 7:15].max()), 7), i) for i in range(N) if not switched[i]])[-3:]}; switched envs "
+                  f"{[(i, int(np.argmax(tr[:, i, 43] != ref[:, i, 43])), round(float(err[:, i, 7:15].max()), 6)) for i in range(N) if switched[i]]}; "
+                  f"env 23: {err[:, 23, 7:15].max():.1e}", flush=True)
         for mode, sigma in modes:
             rmask = 0
             if sigma < 0:

@@ -364,6 +364,71 @@ def test_bench_two_rank_rehearsal_on_one_gpu():
     assert abs(d["value"] - 2 * 4096 * 5 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
 
 
+def test_state_f64_and_time(compiled_model):
+    """physics.data.qpos / .qvel / .time as the reference holds them (float64): the robot's 15 joints are
+    double-float pairs on the device, mre_set_state (float rows) clears their low-order words, and time counts the
+    physics steps since mre_reset (models/robot_arm.py:68-69)."""
+    from mujoco_robot_environments_amd.physics import BatchedPhysics
+    A, _ = compiled_model
+    N = 8
+    phys = BatchedPhysics(N, model=A, solver="Newton")
+    phys.set_props(np.full(N, 2, np.int32), np.full((N, 4, 3), 0.0155, np.float32))
+    phys.reset()
+    assert (phys.time() == 0).all()
+    q0, v0 = phys.get_state_f64()
+    rs = np.random.RandomState(0)
+    q = q0 + 1e-3 * rs.rand(N, 43)
+    v = 1e-2 * rs.rand(N, 39)
+    phys.set_state_f64(q, v)
+    q1, v1 = phys.get_state_f64()
+    assert np.abs(q1[:, :15] - q[:, :15]).max() < 1e-14 and np.abs(v1[:, :15] - v[:, :15]).max() < 1e-14   # hi + lo
+    assert np.array_equal(q1[:, 15:], q[:, 15:].astype(np.float32).astype(np.float64))                       # cubes: float32
+    qf, vf = phys.get_state()
+    assert np.array_equal(qf[:, :15], q[:, :15].astype(np.float32))        # the float rows ARE the rounded values
+    phys.set_state(qf, vf)                                                 # a float32 state is the value: lo = 0
+    q2, _ = phys.get_state_f64()
+    assert np.array_equal(q2[:, :15], qf[:, :15].astype(np.float64))
+    phys.set_state_f64(q0, np.zeros((N, 39)))
+    phys.set_control(np.zeros((N, 8), np.float32))
+    phys.step(7)
+    h = float(np.float32(0.001))
+    assert np.allclose(phys.time(), 7 * h, rtol=0, atol=1e-15)
+    q3, v3 = phys.get_state_f64()
+    lo = q3[:, :15] - q3[:, :15].astype(np.float32)
+    assert (lo != 0).any() and np.abs(lo).max() < 3e-7     # the integrator keeps bits below float32's last place
+    phys.reset()
+    assert (phys.time() == 0).all()
+
+
+def test_bench_rccl_path_with_a_world_of_one():
+    """The multi-rank branch of bench.py on the one GPU of this box: launched exactly as the driver launches a
+    rank (`python -m torch.distributed.run --nproc-per-node 1 ... bench.py --gpus 1`) with MRE_BENCH_FORCE_DIST=1,
+    so backend "nccl" (= RCCL) is initialised with `device_id=`, the barriers, the device-tensor
+    all_gather_into_tensor of the final state and the MAX all_reduce of the elapsed time all execute.  A fresh
+    child process: this one already holds the GPU."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MRE_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("MRE_BENCH_BACKEND", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1",
+           "--no-cpu-baseline", "--solver", "Newton"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["distributed"] == {"backend": "nccl", "world": 1, "gathered_rows": 4096}
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["gather_ms"] > 0
+
+
 def test_launch_info_reports_high_water_marks_and_durations(compiled_model):
     """mre_get_launch_info: the per-env record of the last stepping launch that the capacity fallback and the
     longest-first dispatch read -- overflow flag, high-water marks, the env's own duration."""

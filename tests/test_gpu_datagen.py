@@ -99,8 +99,11 @@ def test_datagen_loop_64_envs_against_oracle(compiled_model, oracle_model):
         print(f"{names[k]:16s} converged gpu {conv.mean():.2f} oracle {oconv.mean():.2f} flags equal {agree[-1]:.2f}  "
               f"arm |dq| median {np.median(arm):.1e} max {arm.max():.1e}")
         if k == 0:
-            assert arm.max() < 1e-4 and agree[-1] == 1.0       # contact-free: the bar, every env
-    assert np.mean(agree) >= 0.95 and min(agree) >= 0.85
+            assert arm.max() < 1e-5 and agree[-1] == 1.0       # contact-free: two orders inside the bar, every env
+        # every phase: the median env stays two orders inside the bar; the maxima are envs whose fingers met the cube
+        # or the table (measured: 1.8e-3 while the gripper closes on the cube, <= 6e-5 elsewhere)
+        assert np.median(arm) < 2e-5 and arm.max() < 5e-3, (names[k], np.median(arm), arm.max())
+    assert min(agree) == 1.0                                   # converged flags identical in every phase of every env
     # task outcome: which cube was picked (the first misplaced one), is it held after the pick,
     # where does it lie after the place
     tgt_cube = np.array([np.argmin(np.linalg.norm(q0[i, 15:15 + 7 * env.nprops[i]].reshape(-1, 7)[:, :2] - pick[i, :2], axis=1))
@@ -115,9 +118,20 @@ def test_datagen_loop_64_envs_against_oracle(compiled_model, oracle_model):
     print(f"cube in the gripper after pick(): gpu {held_g.mean():.2f} oracle {held_o.mean():.2f}, same outcome in "
           f"{(held_g == held_o).mean():.2f} of the envs; placed cubes (held by both, {both.sum()} envs): final "
           f"position differs by median {np.median(d[both]) * 1e3:.2f} mm")
-    assert (held_g == held_o).mean() >= 0.85
-    if both.sum() >= 4:   # a released cube tumbles off the pads: centimetres, not millimetres
-        assert np.median(d[both]) < 3e-2
+    assert (held_g == held_o).mean() >= 0.95
+    # the cubes the arm did not go for stay where they were, in both (unless the arm swept them: < 1 mm then)
+    other_err = []
+    for i in range(N):
+        for p in range(int(env.nprops[i])):
+            if p != tgt_cube[i]:
+                other_err.append(np.abs(log[9][2][i, 15 + 7 * p:18 + 7 * p] - ora[i][9][1][15 + 7 * p:18 + 7 * p]).max())
+    other_err = np.array(other_err)
+    print(f"cubes the arm did not go for: |dx| median {np.median(other_err):.1e}, 95 % {np.quantile(other_err, 0.95):.1e}, max {other_err.max():.1e}")
+    assert np.median(other_err) < 1e-6 and np.quantile(other_err, 0.95) < 1e-3
+    # a cube released above the table tumbles off the pads: where it comes to rest is chaotic at the centimetre scale
+    # (reported above, not asserted); what both must agree on is the outcome that the reference's loop acts on
+    if both.sum() >= 4:
+        assert np.median(d[both]) < 6e-2
     env.close()
 
 
@@ -178,8 +192,8 @@ def test_env_to_tfds_shards_8_envs(tmp_path):
     ts0 = env.reset()
     rgb0 = ts0.observation["overhead_camera/rgb"].cpu().numpy().copy()
     depth0 = ts0.observation["overhead_camera/depth"].cpu().numpy().copy()
-    again = env.render(rgb=True, depth=True)            # a second mre_render of the same state: same bytes
-    assert np.array_equal(again["overhead_camera/rgb"].cpu().numpy(), rgb0)
+    again = env.render(rgb=True, depth=True, seg=False)   # a second mre_render of the same state: same bytes
+    assert np.array_equal(again[0].cpu().numpy(), rgb0) and np.array_equal(again[1].cpu().numpy(), depth0)
     cam = "overhead_camera/overhead_camera"
     name = f"{cfg.name}_test"
     w = D.EpisodeWriter(str(tmp_path), name, env.overhead_camera_height, env.overhead_camera_width,
@@ -191,8 +205,11 @@ def test_env_to_tfds_shards_8_envs(tmp_path):
         log.reset(ts0)
         for pose in (pick, place):
             a = {"pose": pose.copy(), "pixel_coords": env.world_2_pixel(cam, pose[:, :3]), "gripper_rot": 0.0}
-            acts.append({k: np.array(v).copy() if not np.isscalar(v) else v for k, v in a.items()})
             ts = env.step(a)
+            # (pick() / place() write the grasp height into the caller's pose, tasks/rearrangement.py:362,405 -- and
+            #  envlogger stores the action dict after step() returned: z = 0.575 is what lands in the shard)
+            assert np.allclose(a["pose"][in_progress, 2], 0.575)
+            acts.append({k: np.array(v).copy() if not np.isscalar(v) else v for k, v in a.items()})
             log.step(a, ts, in_progress)
     info = w.close()
     assert info["splits"][0]["shardLengths"] == [str(N)]                       # 8 episodes, 10 per file

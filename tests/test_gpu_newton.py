@@ -2,21 +2,16 @@
 tasks/rearrangement.py:77-80 sets no solver): HIP kernels through the C ABI vs the fp64 oracle's
 Newton on identical seeded inputs.
 
-Bar: max |qpos_gpu - qpos_oracle| < 1e-4 on ALL 43 coordinates (arm, finger linkage, cube positions
-and quaternions).  A converged solver leaves one legitimate source of divergence: MuJoCo's constraint
-set is discontinuous in the state (a joint-limit row exists iff dist < 0, a contact row iff
-dist < margin), so a crossing that lands within fp32 rounding of the threshold is taken one step
-apart by the two arithmetics.  The tests therefore record, per env, the first step at which any
-coordinate leaves the bar and require that the constraint census (active contacts, active limit rows)
-of device and oracle differed at or before that step; envs whose census never differed must meet
-the bar over the whole rollout.
+Bar (BASELINE.json north_star): max |qpos_gpu - qpos_oracle| < 1e-4 on ALL 43 coordinates (arm, finger linkage,
+cube positions and quaternions) over 1000 steps -- asserted for EVERY env, not for a fraction of them.
 
-A second source is the state precision itself: the 2F-85 four-bars (links of a few grams closed by
-1e4-stiff soft rows) amplify a perturbation of one float32 ulp of the state to more than 1e-4 rad
-within a few hundred steps in some envs.  This is measured, not assumed: a second fp64 oracle run
-whose state is rounded to float32 after every step (arithmetic still fp64) leaves the bar against the
-plain oracle in the same envs at about the same steps as the device does, and the long tests
-require every device exit to be explained by a census switch or by that run.
+One legitimate source of divergence is left to a converged solver: MuJoCo's constraint set is discontinuous in the
+state (a joint-limit row exists iff dist < 0, a contact row iff dist < margin), so a crossing that lands within fp32
+rounding of the threshold is taken one step apart by the two arithmetics.  The tests therefore record the constraint
+census (active contacts, active limit rows) of device and oracle at every step; an env may leave the bar only AFTER
+its census differed, every other env must meet it over the whole rollout.  On the two 64-env workloads below no
+census differs at all since the robot's state is carried in double-float form and its accelerations are polished in
+fp64 (csrc/mre_newton.h: nw_robot_polish), so the bar holds in 64 of 64 envs.
 """
 import numpy as np
 import pytest
@@ -28,25 +23,15 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
 
-def _divergence_report(name, gq, oq, nprops, gcen, ocen, tol=TOL, bq=None):
-    """Returns (envs under the bar, envs diverged after a census switch, envs diverged without one).
-    bq: qpos trace of the oracle run with float32-rounded state (see the module docstring); a device exit
-    without a census switch counts as explained when that run has left the bar too by then (+ 10 %)."""
+def _divergence_report(name, gq, oq, nprops, gcen, ocen, tol=TOL):
+    """Returns (envs under the bar, envs that left it after a census switch, envs that left it without one, max error
+    among the envs whose census never differed)."""
     err = np.abs(gq - oq)
     T, N = err.shape[:2]
     for i in range(N):
         err[:, i, 15 + 7 * int(nprops[i]):] = 0
     worst = err.max(axis=2)                       # [T, N]
-    bworst = None
-    if bq is not None:
-        berr = np.abs(bq - oq)
-        for i in range(N):
-            berr[:, i, 15 + 7 * int(nprops[i]):] = 0
-        bworst = berr.max(axis=2)
-        bfirst = [int(np.argmax(bworst[:, i] > tol)) if bworst[:, i].max() > tol else T for i in range(N)]
-        print(f"{name}: fp64 oracle with float32-rounded state vs plain oracle: {sum(f >= T for f in bfirst)}/{N} envs stay under "
-              f"{tol:g}; exits (env, step): {sorted([(i, f) for i, f in enumerate(bfirst) if f < T], key=lambda x: x[1])}")
-    under, switched, unexplained, state_precision = [], [], [], []
+    under, switched, unexplained = [], [], []
     for i in range(N):
         bad = np.nonzero(worst[:, i] > tol)[0]
         diff = np.nonzero(gcen[:, i] != ocen[:, i])[0]
@@ -54,24 +39,16 @@ def _divergence_report(name, gq, oq, nprops, gcen, ocen, tol=TOL, bq=None):
             under.append(i)
         elif diff.size and diff[0] <= bad[0]:
             switched.append((i, int(diff[0]), int(bad[0])))
-        elif bworst is not None and bfirst[i] < T and bfirst[i] <= 1.1 * bad[0] + 20:
-            state_precision.append((i, int(bad[0]), bfirst[i]))
         else:
             unexplained.append((i, int(bad[0]), float(worst[:, i].max())))
-    if bq is not None:
-        print(f"{name}: {len(state_precision)} device exits coincide with an exit of the float32-state oracle "
-              f"(env, device step, oracle step): {state_precision}")
     clean = [i for i in range(N) if not np.any(gcen[:, i] != ocen[:, i])]
     cmax = err[:, clean].max() if clean else 0.0
+    top = sorted(((float(err[:, i].max()), i, int(err[:, i].max(axis=0).argmax())) for i in clean), reverse=True)[:3]
     print(f"{name}: {len(under)}/{N} envs under {tol:g} on all 43 coordinates over {T} steps; "
-          f"{len(switched)} diverged after a constraint-set switch {switched[:6]}; {len(unexplained)} unexplained {unexplained[:6]}; "
+          f"{len(switched)} left the bar after a constraint-set switch {switched[:6]}; {len(unexplained)} without one {unexplained[:6]}; "
           f"{len(clean)} envs never switched, max err among them {cmax:.2e} "
           f"(arm {err[:, clean, :7].max() if clean else 0:.2e} fingers {err[:, clean, 7:15].max() if clean else 0:.2e} "
-          f"cubes {err[:, clean, 15:].max() if clean else 0:.2e})")
-    if bq is not None:
-        # the device must be as close to the oracle as the oracle is to itself under float32 state rounding
-        nb_under = sum(f >= T for f in bfirst)
-        assert len(under) >= nb_under - 3, (len(under), nb_under)
+          f"cubes {err[:, clean, 15:].max() if clean else 0:.2e}); worst (err, env, coordinate) {[(f'{e:.1e}', i, c) for e, i, c in top]}")
     return under, switched, unexplained, cmax
 
 
@@ -85,60 +62,45 @@ def test_newton_resting_contact_parity(compiled_model, oracle_model):
     st = phys.solver_stats()
     print("newton iterations per step: mean %.2f max %d; factorisations mean %.2f" % (st[:, 2].mean(), st[:, 2].max(), phys.last_factorizations.mean()))
     assert (phys.status() == 0).all()
-    assert not unexplained and cmax < TOL
-    assert len(under) >= 30
+    assert not unexplained and not switched and cmax < TOL and len(under) == 32
     assert st[:, 2].max() <= 10
 
 
 def test_newton_long_rollout_1000_steps_all_coordinates(compiled_model, oracle_model):
-    """BASELINE.json north_star: max |qpos - qpos_ref| < 1e-4 over 1000 steps -- on all 43 coordinates
+    """BASELINE.json north_star: max |qpos - qpos_ref| < 1e-4 over 1000 steps -- on all 43 coordinates, in every env
     (64 envs, gravity compensation + 10 % torque noise, random gripper command)."""
-    gq, oq, nprops, phys, gcen, ocen, bq = _rollout_both(compiled_model, oracle_model, N=64, T=200, flags=0, scale=0.1,
-                                                         seed=11, z_extra=0.0005, gravity_comp=True, yaw=True,
-                                                         solver="Newton", census=True, fp32_state=True)
-    under, switched, unexplained, cmax = _divergence_report("newton 1000 steps", gq, oq, nprops, gcen, ocen, bq=bq)
+    N = 64
+    gq, oq, nprops, phys, gcen, ocen = _rollout_both(compiled_model, oracle_model, N=N, T=200, flags=0, scale=0.1,
+                                                     seed=11, z_extra=0.0005, gravity_comp=True, yaw=True,
+                                                     solver="Newton", census=True)
+    under, switched, unexplained, cmax = _divergence_report("newton 1000 steps", gq, oq, nprops, gcen, ocen)
     assert (phys.status() == 0).all()
-    # exits: a census switch, the state precision itself in the same env, or the same mechanism in another env
-    # (which env tips over first is chaotic: the RATE is what the float32-state oracle predicts, asserted above)
-    assert len(unexplained) <= 6, unexplained
-    # arm and cube coordinates meet the bar in every env whose constraint set never switched; the
-    # finger linkage (links of a few grams, inertias of 1e-5 kg m^2, closed by stiff soft constraints)
-    # meets it in >= 80 % of the envs and stays within 1e-3 rad in the rest (DESIGN section 7)
-    err = np.abs(gq - oq)
-    clean = [i for i in range(gq.shape[1]) if not np.any(gcen[:, i] != ocen[:, i])]
-    assert err[:, clean, :7].max() < TOL and err[:, clean][:, :, 15:].max() < TOL
-    assert len(under) >= 52 and cmax < 1e-3
+    assert not unexplained, unexplained                    # nobody leaves the bar without a census switch
+    assert cmax < TOL                                      # the envs whose census never differed: the bar, all coordinates
+    assert len(under) + len(switched) == N
+    assert len(under) >= N - 2                             # (a census switch is rare on this law: none measured)
 
 
 def test_newton_bench_action_law_1000_steps(compiled_model, oracle_model):
     """The bench's own action law (configs[1]: full-range torques +-87 / +-12 N m re-drawn every tick,
-    gripper command U(0, 255)) over 1000 steps.  The arm is thrown against its joint limits and onto
-    the table, so constraint-set switches are frequent; every divergence must follow one."""
-    gq, oq, nprops, phys, gcen, ocen, bq = _rollout_both(compiled_model, oracle_model, N=64, T=200, flags=0, scale=1.0,
-                                                         seed=5, z_extra=0.0005, yaw=True, solver="Newton", census=True,
-                                                         fp32_state=True)
-    under, switched, unexplained, cmax = _divergence_report("newton bench law", gq, oq, nprops, gcen, ocen, bq=bq)
-    # exits: a census switch, the state precision itself in the same env, or the same mechanism in another env
-    # (which env tips over first is chaotic: the RATE is what the float32-state oracle predicts, asserted above)
-    assert len(unexplained) <= 6, unexplained
-    err = np.abs(gq - oq)
-    for i in range(gq.shape[1]):
-        err[:, i, 15 + 7 * int(nprops[i]):] = 0
-    first = np.array([np.argmax(err[:, i].max(axis=1) > TOL) if (err[:, i].max() > TOL) else err.shape[0]
-                      for i in range(err.shape[1])])
-    print("steps until the first coordinate leaves the bar: median %d, min %d; fraction under the bar at 250 / 500 / 1000 steps: "
-          "%.2f / %.2f / %.2f" % (np.median(first), first.min(), (first >= 250).mean(), (first >= 500).mean(),
-                                  (first >= 1000).mean()))
+    gripper command U(0, 255)) over 1000 steps.  The arm is thrown against its joint limits, onto the table and into
+    the cubes; the bar holds on all 43 coordinates of every env whose constraint census never differed from the
+    oracle's -- which is every env here."""
+    N = 64
+    gq, oq, nprops, phys, gcen, ocen = _rollout_both(compiled_model, oracle_model, N=N, T=200, flags=0, scale=1.0,
+                                                     seed=5, z_extra=0.0005, yaw=True, solver="Newton", census=True)
+    under, switched, unexplained, cmax = _divergence_report("newton bench law", gq, oq, nprops, gcen, ocen)
     assert np.isfinite(gq).all()
-    clean = [i for i in range(gq.shape[1]) if not np.any(gcen[:, i] != ocen[:, i])]
-    assert err[:, clean, :7].max() < TOL and err[:, clean][:, :, 15:].max() < TOL   # arm and cubes: the bar
-    assert (first >= 500).mean() >= 0.95 and (first >= 1000).mean() >= 0.8          # all 43 coordinates
-    assert cmax < 1e-3                                                               # finger drift bounded
+    assert not unexplained, unexplained
+    assert cmax < TOL
+    assert len(under) + len(switched) == N
+    assert len(under) >= N - 4                             # (census switches: none measured; a few would be legitimate)
 
 
 def test_newton_run_controller_parity(compiled_model, oracle_model):
     """RobotArm.run_controller (models/robot_arm.py:61-94) with the Newton solver: in-kernel OSC + MinMax,
-    16 envs x 200 ticks towards a reachable target; converged flags identical."""
+    16 envs x 400 ticks (the 2 s of a scripted phase), half of them towards a reachable pre-pick pose, half towards a
+    point out of reach; converged flags identical and of both kinds."""
     import torch  # noqa: F401
     from mujoco_robot_environments_amd import rng
     from mujoco_robot_environments_amd.physics import BatchedPhysics
@@ -164,13 +126,19 @@ def test_newton_run_controller_parity(compiled_model, oracle_model):
         envs[i].arr("qpos")[:43] = qp[i]
         envs[i].forward()
     phys.set_state(qp, np.zeros((N, 39), np.float32))
-    tgt = rng.uniform(seed + 1, ids, [0], 3)[0] * [0.1, 0.3, 0.15] + [0.35, -0.15, 0.6]
-    quat = np.array([0.0, 1.0, 0.0, 0.0])
-    phys.osc_set_target(position=tgt.astype(np.float32), quat=quat.astype(np.float32),
+    # even envs: a pre-pick pose of the scripted phases (tasks/rearrangement.py:362-372: z = 0.9 above the workspace,
+    # gripper pointing down) -- reached within the 2 s the reference gives the phase; odd envs: 1.5 m away, out of reach
+    from mujoco_robot_environments_amd.tasks.rearrangement import home_quat
+    u = rng.uniform(seed + 1, ids, [0], 3)[0]
+    tgt = u * [0.2, 0.5, 0.0] + [0.35, -0.25, 0.9]
+    tgt[1::2, 0] = 1.5
+    quat = home_quat()
+    phys.osc_set_target(position=tgt.astype(np.float32), quat=np.tile(quat.astype(np.float32), (N, 1)),
                         velocity=np.zeros(3, np.float32), angular_velocity=np.zeros(3, np.float32))
-    grip = (ids % 2).astype(np.uint8)
+    grip = ((ids // 2) % 2).astype(np.uint8)
     phys.gripper_set(grip)
-    conv = phys.run_controller(200, 5)
+    ticks = 400
+    conv = phys.run_controller(ticks, 5)
     phys.sync()
     gq = phys.qpos()
     oconv = np.zeros(N, bool)
@@ -178,13 +146,15 @@ def test_newton_run_controller_parity(compiled_model, oracle_model):
     for i, e in enumerate(envs):
         p = O.make_osc()
         p.target_pos[:] = tgt[i].astype(np.float32)
-        p.target_quat[:] = quat
-        oconv[i] = e.run_controller(p, 255.0 if grip[i] else 0.0, 200, 5)
+        p.target_quat[:] = quat.astype(np.float32)
+        oconv[i] = e.run_controller(p, 255.0 if grip[i] else 0.0, ticks, 5)
         n = int(nprops[i])
         worst[i] = np.abs(gq[i, :15 + 7 * n] - e.arr("qpos")[:15 + 7 * n]).max()
     print("newton run_controller: max err per env", np.round(worst, 6).tolist(), "converged", conv.tolist())
     assert (conv == oconv).all()
-    assert np.median(worst) < TOL and (worst < TOL).mean() >= 0.8
+    assert conv[0::2].all() and not conv[1::2].any()      # the flag is exercised both ways
+    assert (worst[0::2] < TOL).all()                      # 2000 steps of OSC + MinMax at the bar, every reachable env
+    assert np.median(worst) < TOL
 
 
 def test_arm_link_hulls_collide_with_cubes(compiled_model, oracle_model):
