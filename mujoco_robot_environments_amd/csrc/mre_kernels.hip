@@ -496,6 +496,12 @@ MRE_DEV double dpp_shr1_d(double v) {   // the value of lane l - 1 (same DPP row
   const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x111, 0xF, 0xF, false);
   return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned)lo);
 }
+MRE_DEV double dpp_shl1_d(double v) {   // the value of lane l + 1 (same DPP row; 0 past the row)
+  const long long b = __builtin_bit_cast(long long, v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xFFFFFFFFll), 0x101, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x101, 0xF, 0xF, false);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned)lo);
+}
 MRE_PHASE_FN void gripper_pose(ModelP M, Sm& s, int l) {
   const bool fin = l >= GRIP_BODY0 && l < NRB;
   double p[3] = {0.0, 0.0, 0.0}, q[4] = {1.0, 0.0, 0.0, 0.0};
@@ -522,19 +528,25 @@ MRE_PHASE_FN void gripper_pose(ModelP M, Sm& s, int l) {
   MRE_SYNC();
 }
 MRE_PHASE_FN void gripper_local(ModelP M, Sm& s, int l) {
-  if (l >= GRIP_BODY0 && l < NRB) {
-    const int b = l;
-    const double* pose = s.gpose[b - GRIP_BODY0];
-    const double p[3] = {pose[0], pose[1], pose[2]}, q[4] = {pose[3], pose[4], pose[5], pose[6]};
-    const int ts = M->tcp_site;
-    const double O[3] = {(double)M->site_pos[ts][0], (double)M->site_pos[ts][1], (double)M->site_pos[ts][2]};
-    double ci[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    inert_about_d(M, b, p, q, O, ci);
+  const bool fin = l >= GRIP_BODY0 && l < NRB;
+  const int b = fin ? l : GRIP_BODY0;
+  const double* pose = s.gpose[b - GRIP_BODY0];
+  const double p[3] = {pose[0], pose[1], pose[2]}, q[4] = {pose[3], pose[4], pose[5], pose[6]};
+  const int ts = M->tcp_site;
+  const double O[3] = {(double)M->site_pos[ts][0], (double)M->site_pos[ts][1], (double)M->site_pos[ts][2]};
+  // the body's own spatial inertia; a body off link 7 adds its child's, which the lane above has just computed
+  // (bodies 9, 11, 13, 15 hang off 8, 10, 12, 14: the dof tree mre_create checks)
+  double ci[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (fin) inert_about_d(M, b, p, q, O, ci);
+  double up[10];
+#pragma unroll
+  for (int k = 0; k < 10; k++) up[k] = dpp_shl1_d(ci[k]);
+  if (fin) {
+#pragma unroll
     for (int k = 0; k < 10; k++) s.gI[b - GRIP_BODY0][k] = ci[k];
-    for (int c = b + 1; c < NRB; c++) {
-      if (M->body_parent[c] != b) continue;
-      const double* cp = s.gpose[c - GRIP_BODY0];
-      inert_about_d(M, c, cp, cp + 3, O, ci);
+    if (M->body_parent[b] < GRIP_BODY0 && b + 1 < NRB && M->body_parent[b + 1] == b) {
+#pragma unroll
+      for (int k = 0; k < 10; k++) ci[k] += up[k];
     }
     double ax[3] = {(double)M->jnt_axis[b][0], (double)M->jnt_axis[b][1], (double)M->jnt_axis[b][2]};
     double jp[3] = {(double)M->jnt_pos[b][0], (double)M->jnt_pos[b][1], (double)M->jnt_pos[b][2]};
@@ -985,12 +997,6 @@ MRE_DEV void dmul_inert_vec(double* r, const double* i, const double* v) {
   r[3] = i[8] * v[1] - i[7] * v[2] + i[9] * v[3];
   r[4] = i[6] * v[2] - i[8] * v[0] + i[9] * v[4];
   r[5] = i[7] * v[0] - i[6] * v[1] + i[9] * v[5];
-}
-MRE_DEV double dpp_shl1_d(double v) {   // the value of lane l + 1 (same DPP row; 0 past the row)
-  const long long b = __builtin_bit_cast(long long, v);
-  const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xFFFFFFFFll), 0x101, 0xF, 0xF, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x101, 0xF, 0xF, false);
-  return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned)lo);
 }
 MRE_PHASE_FN void finger_bias(ModelP M, Sm& s, int l) {
   constexpr int LINK7 = GRIP_BODY0 - 1;

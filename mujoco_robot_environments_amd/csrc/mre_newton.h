@@ -852,6 +852,12 @@ MRE_DEV double rdlane_d(double v, int lane) {
   const int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
   return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned)lo);
 }
+MRE_DEV double rcp_d(double x) {   // 1 / x: v_rcp_f64 and two Newton steps (the IEEE division sequence is 25 instructions)
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+}
 MRE_PHASE_FN bool nw_robot_polish(ModelP M, Sm& s, int l) {
   static_assert(offsetof(Sm, W) % 8 == 0 && offsetof(Sm, nw_Mv) % 8 == 0, "fp64 views of W / nw_Mv");
   constexpr int MAXROW = 7 + NRV;   // equality + every joint at a limit
@@ -864,13 +870,20 @@ MRE_PHASE_FN bool nw_robot_polish(ModelP M, Sm& s, int l) {
   double* const a64 = reinterpret_cast<double*>(&s.nw_Mv[0]); // [NRV] out
   const int nscalar = 7 + s.nl, ncon = s.ncon;
   // ---- lane = contact: the ones with a robot part, compacted by a ballot prefix count
+  // `full`: a contact touches an ARM body, so the arm block of H carries a stiff row and the arm dofs are polished
+  // with the fingers; otherwise the arm's float32 accelerations are good to 2e-7 of their size (harmless: the study's
+  // "e2e-7,0,0") and only the eight finger dofs are eliminated -- a quarter of the work
+  constexpr int F0 = GRIP_BODY0 - 1;
   int nrc = 0;
+  bool full = false;
   {
     const int rs = l < ncon ? (int)s.con_rslot[l] : HDR_NONE;
     const bool mine = rs != HDR_NONE;
     const unsigned long long m = __ballot(mine);
     nrc = __popcll(m);
     if (nrc > NW_POLISH_CON) return false;
+    const int cb1 = mine ? (int)s.con_b1[l] : 0, cb2 = mine ? (int)s.con_b2[l] : 0;
+    full = __ballot(mine && ((cb1 >= 1 && cb1 < GRIP_BODY0) || (cb2 >= 1 && cb2 < GRIP_BODY0))) != 0ull;
     if (mine) {
       const int k = __popcll(m & ((1ull << l) - 1ull));
       const int i = nscalar + 3 * l, h = s.hdr[i];
@@ -884,7 +897,7 @@ MRE_PHASE_FN bool nw_robot_polish(ModelP M, Sm& s, int l) {
         if (pa < NPROP) { const float* ja = jpA(s, i + r); for (int c = 0; c < 6; c++) acc += (double)ja[c] * (double)s.qacc[NRV + 6 * pa + c]; }
         if (pb < NPROP) { const float* jb = jpB(s, i + r); for (int c = 0; c < 6; c++) acc += (double)jb[c] * (double)s.qacc[NRV + 6 * pb + c]; }
         j[r] = acc;
-        D[r] = 1.0 / (double)s.efc_R[i + r];
+        D[r] = rcp_d((double)s.efc_R[i + r]);
       }
       // mj_constraintUpdate for one elliptic contact (nw_contact), fp64
       const double fr = (double)s.con_fric[l], mu = fr * sqrt((double)s.efc_R[i + 1] / (double)s.efc_R[i]);
@@ -919,17 +932,19 @@ MRE_PHASE_FN bool nw_robot_polish(ModelP M, Sm& s, int l) {
 #pragma unroll
     for (int j = 0; j < NRV; j++) jar += (double)s.Jr[l][j] * (double)s.qacc[j];
     const bool act = l < 7 || s.rstate[l] == NW_QUAD;
-    const double D = act ? 1.0 / (double)s.efc_R[l] : 0.0;
+    const double D = act ? rcp_d((double)s.efc_R[l]) : 0.0;
     frow[l] = -D * jar;
     drow[l] = D;
   }
   MRE_SYNC();
-  // ---- lane = robot dof: its row of the Hessian block and of the gradient (lanes past the robot: an identity row)
+  // ---- lane = robot dof: its row of the Hessian block and of the gradient.  Without `full` the block is the finger
+  // block: arm lanes carry x = 0, and the arm columns of the finger rows are never read
   const int d = l < NRV ? l : 0;
+  const bool row = l < NRV && (full || l >= F0);
   double hrow[NRV], g = 0.0;
 #pragma unroll
-  for (int j = 0; j < NRV; j++) hrow[j] = (l < NRV) ? (double)s.Md[d][j] : 0.0;
-  if (l < NRV) {
+  for (int j = 0; j < NRV; j++) hrow[j] = row ? (double)s.Md[d][j] : 0.0;
+  if (row) {
     g = -(double)s.qfrc_smooth[d];
 #pragma unroll
     for (int j = 0; j < NRV; j++) g += (double)s.Md[d][j] * (double)s.qacc[j];
@@ -937,8 +952,12 @@ MRE_PHASE_FN bool nw_robot_polish(ModelP M, Sm& s, int l) {
       const double jd = (double)s.Jr[r][d];
       g -= jd * frow[r];
       const double t = drow[r] * jd;
+      if (full) {
 #pragma unroll
-      for (int j = 0; j < NRV; j++) hrow[j] += t * (double)s.Jr[r][j];
+        for (int j = 0; j < F0; j++) hrow[j] += t * (double)s.Jr[r][j];
+      }
+#pragma unroll
+      for (int j = F0; j < NRV; j++) hrow[j] += t * (double)s.Jr[r][j];
     }
     for (int k = 0; k < nrc; k++) {
       const double* o = fcon + 10 * k;
@@ -947,30 +966,58 @@ MRE_PHASE_FN bool nw_robot_polish(ModelP M, Sm& s, int l) {
       g -= j0 * o[0] + j1 * o[1] + j2 * o[2];
       const double t0 = j0 * o[3] + j1 * o[4] + j2 * o[5], t1 = j0 * o[4] + j1 * o[6] + j2 * o[7],
                    t2 = j0 * o[5] + j1 * o[7] + j2 * o[8];
+      if (full) {
 #pragma unroll
-      for (int j = 0; j < NRV; j++)
+        for (int j = 0; j < F0; j++)
+          hrow[j] += t0 * (double)s.Jr[rs][j] + t1 * (double)s.Jr[rs + 1][j] + t2 * (double)s.Jr[rs + 2][j];
+      }
+#pragma unroll
+      for (int j = F0; j < NRV; j++)
         hrow[j] += t0 * (double)s.Jr[rs][j] + t1 * (double)s.Jr[rs + 1][j] + t2 * (double)s.Jr[rs + 2][j];
     }
   }
   // ---- elimination: row i in lane i, pivot row k read from lane k; x = -H^-1 g
   double x = -g;
+  double pinv[NRV];   // reciprocal pivots (wave-uniform), kept for the back substitution
 #pragma unroll
-  for (int k = 0; k < NRV - 1; k++) {
-    const double inv = 1.0 / rdlane_d(hrow[k], k);
+  for (int k = 0; k < NRV; k++) pinv[k] = 1.0;
+  if (full) {
+#pragma unroll
+    for (int k = 0; k < F0; k++) {
+      pinv[k] = rcp_d(rdlane_d(hrow[k], k));
+      const double xk = rdlane_d(x, k);
+      const double mlt = (l > k && l < NRV) ? hrow[k] * pinv[k] : 0.0;
+#pragma unroll
+      for (int j = k + 1; j < NRV; j++) hrow[j] -= mlt * rdlane_d(hrow[j], k);
+      x -= mlt * xk;
+    }
+  }
+#pragma unroll
+  for (int k = F0; k < NRV; k++) {
+    pinv[k] = rcp_d(rdlane_d(hrow[k], k));
+    if (k == NRV - 1) break;
     const double xk = rdlane_d(x, k);
-    const double mlt = (l > k && l < NRV) ? hrow[k] * inv : 0.0;
+    const double mlt = (l > k && l < NRV) ? hrow[k] * pinv[k] : 0.0;
 #pragma unroll
     for (int j = k + 1; j < NRV; j++) hrow[j] -= mlt * rdlane_d(hrow[j], k);
     x -= mlt * xk;
   }
 #pragma unroll
-  for (int k = NRV - 1; k >= 0; k--) {
-    const double xk = rdlane_d(x, k) / rdlane_d(hrow[k], k);   // (uniform: every lane computes the same quotient)
+  for (int k = NRV - 1; k >= F0; k--) {
+    const double xk = rdlane_d(x, k) * pinv[k];   // (uniform: every lane forms the same product)
     if (l == k) x = xk;
-    else if (l < k) x -= hrow[k] * xk;
+    else if (l < k && row) x -= hrow[k] * xk;
+  }
+  if (full) {
+#pragma unroll
+    for (int k = F0 - 1; k >= 0; k--) {
+      const double xk = rdlane_d(x, k) * pinv[k];
+      if (l == k) x = xk;
+      else if (l < k) x -= hrow[k] * xk;
+    }
   }
   if (l < NRV) {
-    const double a = (double)s.qacc[l] + x;
+    const double a = (double)s.qacc[l] + x;    // (x = 0 on the arm lanes of a finger-only polish)
     a64[l] = a;
     s.qacc[l] = (float)a;
   }
