@@ -138,16 +138,6 @@ MRE_PHASE_FN void collide(ModelP M, Sm& s, int l, bool detect) {
       if (M->geom_type[g1] == 0) n = plane_box(p1, R1, p2, R2, s2, inc, normal, buf);
       else n = box_box(p1, R1, s1, p2, R2, s2, inc, normal, buf);
       MRE_DBG_STAMP(6, 2);
-      // mesh stand-in pairs keep one contact (deepest point), like MuJoCo's convex-mesh test
-      if (M->pair_single[pr] && n > 1) {
-        int best = 0;
-        for (int c = 1; c < n; c++) if (cand_dist(buf, c) < cand_dist(buf, best)) best = c;
-        if (best != 0) {
-          for (int k = 0; k < 3; k++) cand_xyz(buf, 0)[k] = cand_xyz(buf, best)[k];
-          cand_dist(buf, 0) = cand_dist(buf, best);
-        }
-        n = 1;
-      }
       // instantiate only contacts with dist < includemargin
       int m = 0;
       for (int c = 0; c < n; c++)
@@ -159,6 +149,26 @@ MRE_PHASE_FN void collide(ModelP M, Sm& s, int l, bool detect) {
           m++;
         }
       n = m;
+      // mesh stand-in pairs keep ONE contact, like MuJoCo's convex-mesh test: depth of the deepest candidate, position
+      // = the centroid of the active candidates weighted by their depth below the threshold (the deepest point alone
+      // jumps between the corners of the clip polygon when two faces are nearly parallel; oracle: collision())
+      if (M->pair_single[pr] && n > 1) {
+        const float incw = M->pair_margin[pr] - M->pair_gap[pr];
+        int best = 0;
+        float wsum = 0.f, px = 0.f, py = 0.f, pz = 0.f;
+        for (int c = 0; c < n; c++) {
+          const float dc = cand_dist(buf, c);
+          if (dc < cand_dist(buf, best)) best = c;
+          const float w = incw - dc;
+          if (w > 0.f) { wsum += w; px += w * cand_xyz(buf, c)[0]; py += w * cand_xyz(buf, c)[1]; pz += w * cand_xyz(buf, c)[2]; }
+        }
+        const float dmin = cand_dist(buf, best);
+        if (wsum > 0.f) { const float iw = 1.0f / wsum; px *= iw; py *= iw; pz *= iw; }
+        else { px = cand_xyz(buf, best)[0]; py = cand_xyz(buf, best)[1]; pz = cand_xyz(buf, best)[2]; }
+        cand_xyz(buf, 0)[0] = px; cand_xyz(buf, 0)[1] = py; cand_xyz(buf, 0)[2] = pz;
+        cand_dist(buf, 0) = dmin;
+        n = 1;
+      }
     }
     // exclusive prefix sum of n (<= 8) over the lanes, bit by bit through ballots
     int off = base, tot = base;

@@ -288,6 +288,9 @@ def _mix_pair(g1, g2):
     return condim, fr, solref, solimp, margin, gap
 
 
+SELF_PAIR_MIN_LINKS = 4   # robot self-collision pairs: bodies at least this many arm links apart (see the pair filter)
+
+
 def compile_scene(scene: dict = None) -> Dict[str, np.ndarray]:
     scene = scene or _spec.default_scene()
     bodies: List[_Body] = []
@@ -445,6 +448,20 @@ def compile_scene(scene: dict = None) -> Dict[str, np.ndarray]:
     for gi in range(ng):
         geom_propid[gi] = body_propid[geom_body[gi]]
 
+    # arm link (1..7) a robot body hangs off (gripper and finger bodies: 7), 0 for the rest; finger side by the
+    # branch below the arm's last link (bodies of one finger share the ancestor that hangs off link 7)
+    arm_link_of_body = np.zeros(nb, np.int32)
+    finger_side_of_body = np.zeros(nb, np.int32)
+    arm_chain = [bi for bi in range(1, nb) if body_propid[bi] < 0 and int(jtype[bi]) == 1]   # hinge bodies, tree order
+    n_arm = min(7, len(arm_chain))
+    for k, bi in enumerate(arm_chain[:n_arm]):
+        arm_link_of_body[bi] = k + 1
+    for bi in arm_chain[n_arm:]:
+        arm_link_of_body[bi] = 7
+        r = bi
+        while body_parent[r] != arm_chain[n_arm - 1] and body_parent[r] > 0:
+            r = body_parent[r]
+        finger_side_of_body[bi] = r
     # collision pairs with MuJoCo's static filters (engine_collision_driver.c:
     # contype/conaffinity, same body, filterparent, both bodies welded to world)
     pairs = []
@@ -464,13 +481,22 @@ def compile_scene(scene: dict = None) -> Dict[str, np.ndarray]:
                 continue
             if (body_parent[ba] == bc and bc != 0) or (body_parent[bc] == ba and ba != 0):
                 continue
-            # robot self-collisions: the menagerie meshes never touch in this
-            # task's workspace; box hulls are coarser, so robot-robot pairs are
-            # dropped (documented deviation)
+            # robot self-collisions.  The reference's CPU env keeps them (MuJoCo's only static filter between two
+            # robot geoms is parent - child; the author switches arm collisions off in the MJX port alone,
+            # tasks/rearrangement_mjx.py:184-189).  The box hulls that stand in for the menagerie meshes are coarser
+            # than the meshes, so hulls of NEARBY links overlap where the meshes clear each other (three links apart, the
+            # finger hulls meet the hull of link 4 before joint 6 reaches its lower limit -- oracle KAT): a
+            # robot-robot pair is kept when its two bodies are at least FOUR arm links apart (gripper and fingers
+            # count as link 7), and the pads of opposite fingers collide with each other (a closing gripper)
             ra = ga["group"] in ("robot", "pad")
             rc = gc["group"] in ("robot", "pad")
             if ra and rc:
-                continue
+                if not scene.get("robot_self_pairs", False):
+                    continue
+                la, lc = arm_link_of_body[ba], arm_link_of_body[bc]
+                pads_across = ga["group"] == "pad" and gc["group"] == "pad" and finger_side_of_body[ba] != finger_side_of_body[bc]
+                if not (abs(la - lc) >= SELF_PAIR_MIN_LINKS or pads_across):
+                    continue
             # robot vs ground: unreachable (ground is 0.4 m below the base)
             if not scene.get("robot_ground_pairs", False) and \
                     ((ra and gc["group"] == "ground") or (rc and ga["group"] == "ground")):

@@ -831,10 +831,25 @@ static void collision(const mro_model* m, mro_data* d) {
       int n = mro_boxbox(d->geom_xpos[g1], d->geom_xmat[g1], d->geom_size[g1], d->geom_xpos[g2],
                          d->geom_xmat[g2], d->geom_size[g2], margin, normal, pos, dist);
       if (m->pair_single[k] && n > 1) {
-        /* mesh stand-in: one contact per pair (deepest point), like mjc_Convex */
+        /* mesh stand-in: one contact per pair, like mjc_Convex.  Depth = the deepest candidate's; position = the
+         * centroid of the ACTIVE candidates (dist < margin - gap) weighted by their depth below that threshold.
+         * (The deepest point alone jumps between the corners of the clip polygon when two faces are nearly
+         * parallel -- a discontinuity of centimetres in the lever of a 100 N force that no arithmetic can follow;
+         * MuJoCo's MPR likewise returns a point inside the overlap region, not a corner.) */
+        const double inc = m->pair_margin[k] - m->pair_gap[k];
         int best = 0;
+        double wsum = 0, p[3] = {0, 0, 0};
         for (int c = 1; c < n; c++) if (dist[c] < dist[best]) best = c;
-        add_contact(m, d, k, pos + 3 * best, normal, dist[best]);
+        for (int c = 0; c < n; c++) {
+          const double w = inc - dist[c];
+          if (w > 0) { wsum += w; for (int t = 0; t < 3; t++) p[t] += w * pos[3 * c + t]; }
+        }
+        if (wsum > 0) {
+          for (int t = 0; t < 3; t++) p[t] /= wsum;
+          add_contact(m, d, k, p, normal, dist[best]);
+        } else {
+          add_contact(m, d, k, pos + 3 * best, normal, dist[best]);
+        }
       } else {
         for (int c = 0; c < n; c++) add_contact(m, d, k, pos + 3 * c, normal, dist[c]);
       }

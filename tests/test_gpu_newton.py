@@ -215,3 +215,66 @@ def test_arm_link_hulls_collide_with_cubes(compiled_model, oracle_model):
     assert (phys.status() & 6 == 0).all()
     assert on_link >= N - 2 and same_pairs >= N - 1
     assert worst < 1e-4
+
+
+def test_robot_self_collision_is_opt_in_and_matches_the_oracle():
+    """Robot self-collision (the reference's CPU env keeps arm / gripper collisions, the author switches them off only in
+    the MJX port: tasks/rearrangement_mjx.py:184-189) is opt-in here -- spec.default_scene(robot_self_pairs=True): hull
+    pairs at least four arm links apart and the pads of opposite fingers.  Four envs start with the arm folded onto
+    itself (link 7 / link 5 / a finger hull 1-4 mm inside the hull of link 1), held by gravity compensation; device vs
+    oracle (Newton) over 200 steps: the same hull pairs touch, and the arm stays at the bar."""
+    from mujoco_robot_environments_amd.model import compile as MC, spec as S
+    from mujoco_robot_environments_amd.physics import BatchedPhysics
+    from oracle import oracle as O
+    A = MC.compile_scene(S.default_scene(dict(robot_self_pairs=True, solver="Newton")))
+    om = O.Model(MC.to_blob(A))
+    names = A["_names"]["geoms"]
+    poses = [([-1.033, 0.2979, 0.9313, -2.9544, 2.4252, 3.739, 0.5605], ("link7_hull", "link1_hull")),
+             ([-1.1966, -1.1065, -0.8863, -2.9083, -0.5843, 1.4801, -1.6409], ("left_follower_hull", "link1_hull")),
+             ([-2.0616, 1.4247, -1.3656, -2.9859, -1.666, 0.4936, -2.0112], ("link5_hull", "link1_hull")),
+             ([2.3779, 1.415, 1.2628, -2.6712, -0.855, 0.6729, 0.2459], ("left_follower_hull", "link1_hull"))]
+    N = len(poses)
+    nprops = np.full(N, 2, np.int32)
+    sizes = np.full((N, 4, 3), 0.0155)
+    phys = BatchedPhysics(N, model=A, solver="Newton")
+    phys.set_props(nprops, sizes)
+    phys.reset()
+    qp = phys.qpos().copy()
+    envs, ctrl = [], np.zeros((N, 8), np.float32)
+    for i, (qa, _) in enumerate(poses):
+        e = O.Env(om, 2, sizes[i])
+        e.set_solver("Newton")
+        q = e.arr("qpos")
+        q[:43] = qp[i]
+        q[:7] = np.asarray(qa, np.float32)
+        q[15:22] = [0.5, 0.25, 0.4155, 1, 0, 0, 0]
+        q[22:29] = [0.45, -0.25, 0.4155, 1, 0, 0, 0]
+        q[:43] = q[:43].astype(np.float32)
+        e.forward()
+        qp[i] = q[:43]
+        ctrl[i, :7] = e.arr("qfrc_bias")[:7]
+        envs.append(e)
+    phys.set_state(qp, np.zeros((N, 39), np.float32))
+    phys.set_control(ctrl)
+    T = 200
+    phys.step(T)
+    phys.sync()
+    gq = phys.qpos()
+    cnt, con = phys.contacts()
+    worst = 0.0
+    for i, (e, (_, pair)) in enumerate(zip(envs, poses)):
+        e.arr("ctrl")[:] = ctrl[i].astype(np.float64)
+        hit = False
+        for _ in range(T):
+            e.step(1)
+            hit = hit or any((names[int(c[13])], names[int(c[14])]) == pair and c[12] < 0 for c in e.contacts())
+        assert hit, pair                                      # the pair did push on the arm in the oracle
+        ok = lambda a, b: "hull" in a and "hull" in b and not a.startswith(("table", "prop")) and not b.startswith(("table", "prop"))  # noqa: E731
+        opairs = sorted({(names[int(c[13])], names[int(c[14])]) for c in e.contacts() if c[12] < 0 and ok(names[int(c[13])], names[int(c[14])])})
+        gpairs = sorted({(names[int(con[i, k, 0])], names[int(con[i, k, 1])]) for k in range(abs(int(cnt[i])))
+                         if con[i, k, 2] < 0 and ok(names[int(con[i, k, 0])], names[int(con[i, k, 1])])})
+        assert opairs == gpairs, (i, opairs, gpairs)
+        worst = max(worst, float(np.abs(gq[i, :15] - e.arr("qpos")[:15]).max()))
+    print(f"self-collision: arm + fingers max |dq| vs oracle after {T} steps {worst:.2e}; status {np.unique(phys.status()).tolist()}")
+    assert (phys.status() & 6 == 0).all()
+    assert worst < TOL

@@ -154,3 +154,44 @@ def test_tuned_gain_helper_only_touches_the_gains():
         assert gb.gains[k].kp == kp and gb.gains[k].kd == kd
     assert list(ga.nullspace.joint_config) == list(gb.nullspace.joint_config)
     assert ga.convergence.position_threshold == gb.convergence.position_threshold
+
+
+def test_robot_self_collision_pairs_are_opt_in():
+    """spec.default_scene(robot_self_pairs=True): robot-robot pairs whose bodies are at least four arm links apart
+    (gripper and fingers count as link 7) and the pads of opposite fingers -- 31 pairs on top of the 84; the emitted
+    MJCF lists them as explicit <pair>s.  Nothing touches at the home pose; a gripper closing on nothing ends on its
+    pads (driver 0.78 rad, short of the 0.8 limit); folding joint 6 to its lower limit stays free of the link-4 hull."""
+    import os
+    import sys
+    import xml.etree.ElementTree as ET
+    from mujoco_robot_environments_amd.model import spec as S
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import emit_mjcf
+    from oracle import oracle as O
+    scene = S.default_scene(dict(robot_self_pairs=True))
+    A = MC.compile_scene(scene)
+    assert int(A["npair"][0]) == 115 <= 128
+    names = A["_names"]["geoms"]
+    rr = [(names[a], names[b]) for a, b in A["pair_geom"]
+          if not names[a].startswith(("table", "ground", "prop")) and not names[b].startswith(("table", "ground", "prop"))]
+    assert len(rr) == 31 and ("right_pad1", "left_pad1") in rr and ("link5_hull", "link1_hull") in rr
+    assert not any("link4" in a + b and ("pad" in a + b or "follower" in a + b) for a, b in rr)   # three links apart: dropped
+    root = ET.fromstring(emit_mjcf.emit(scene, nprops=2))
+    assert len(root.find("contact")) == 31
+    om = O.Model(MC.to_blob(A))
+    e = O.Env(om, 2, np.full((4, 3), 0.0155))
+    e.set_solver("Newton")
+    q = e.arr("qpos")
+    q[:7] = A["home_qpos"]
+    q[15:22] = [0.5, 0.2, 0.4155, 1, 0, 0, 0]
+    q[22:29] = [0.45, -0.2, 0.4155, 1, 0, 0, 0]
+    e.forward()
+
+    def self_contacts():
+        return sorted({(names[int(c[13])], names[int(c[14])]) for c in e.contacts() if c[12] < 0 and
+                       not names[int(c[13])].startswith(("table", "prop")) and not names[int(c[14])].startswith(("table", "prop"))})
+    assert self_contacts() == []
+    e.arr("ctrl")[:7] = e.arr("qfrc_bias")[:7]
+    e.arr("ctrl")[7] = 255.0
+    e.step(600)
+    assert self_contacts() == [("right_pad1", "left_pad1")] and 0.77 < q[7] < 0.8 and abs(q[7] - q[11]) < 1e-4

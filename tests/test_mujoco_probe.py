@@ -49,7 +49,10 @@ def test_emitted_mjcf_has_the_compiled_model_structure(compiled_model):
         # table x ground is filtered by MuJoCo (both static); every other colliding pair is in the table
         pg = A["pair_geom"]
         active = [k for k in range(len(pg)) if A["geom_propid"][pg[k][0]] < n and A["geom_propid"][pg[k][1]] < n]
-        assert ncoll - 0 == len(active), (ncoll, len(active))
+        # robot x robot is off in the masks; the self-collision pairs the compiled table keeps are explicit <pair>s
+        explicit = len(root.find("contact")) if root.find("contact") is not None else 0
+        assert explicit == 0                       # (robot self-collision is opt-in: spec.default_scene(robot_self_pairs=True))
+        assert ncoll + explicit == len(active), (ncoll, explicit, len(active))
 
 
 def test_oracle_against_mujoco_when_available(compiled_model, oracle_model):

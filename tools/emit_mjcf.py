@@ -56,6 +56,16 @@ def _geom(g: dict, size=None, masks=None) -> str:
     return "<geom " + " ".join(a) + "/>"
 
 
+def _geom_groups(body: dict, acc=None) -> dict:
+    """geom name -> group ("robot", "pad", "prop", "table", "ground") over a body tree of the scene spec."""
+    acc = {} if acc is None else acc
+    for g in body.get("geoms", []):
+        acc[g["name"]] = g["group"]
+    for c in body.get("children", []):
+        _geom_groups(c, acc)
+    return acc
+
+
 def _joint(j: dict) -> str:
     if j["type"] == "free":
         return f"<freejoint name={quoteattr(j['name'])}/>"
@@ -133,6 +143,25 @@ def emit(scene: Optional[dict] = None, nprops: int = 4, prop_sizes: Optional[Seq
         masks["ground"] = (0, 3)
     _body(scene["world"], out, 2, prop_sizes, nprops, masks)
     out.append('  </worldbody>')
+    # robot self-collision: the compiled pair table keeps robot-robot pairs whose bodies are far enough apart along the
+    # arm (model/compile.py: SELF_PAIR_MIN_LINKS) and the pads of opposite fingers.  The bit masks above switch
+    # robot x robot off wholesale, so these pairs are listed explicitly, with every parameter spelled out
+    from mujoco_robot_environments_amd.model import compile as MC
+    A = MC.compile_scene(scene)
+    gname = A["_names"]["geoms"]
+    group = _geom_groups(scene["world"])
+    pairs = []
+    for k, (g1, g2) in enumerate(A["pair_geom"]):
+        n1, n2 = gname[int(g1)], gname[int(g2)]
+        if group.get(n1) in ("robot", "pad") and group.get(n2) in ("robot", "pad"):
+            f = A["pair_friction"][k]
+            pairs.append(f'    <pair geom1={quoteattr(n1)} geom2={quoteattr(n2)} condim="{int(A["pair_condim"][k])}" '
+                         f'friction="{_v([f[0], f[0], f[1], f[2], f[2]])}" solref="{_v(A["pair_solref"][k])}" '
+                         f'solimp="{_v(A["pair_solimp"][k])}" margin="{float(A["pair_margin"][k])!r}" gap="{float(A["pair_gap"][k])!r}"/>')
+    if pairs:
+        out.append('  <contact>')
+        out += pairs
+        out.append('  </contact>')
     out.append('  <equality>')
     for e in scene["equality"]:
         if e["type"] == "connect":
