@@ -249,8 +249,10 @@ int mre_get_solver(mre_env*);
 int mre_get_fallback_stats(mre_env*, long long* out4);
 
 /* measurement support for bench.py: when enabled every step-kernel launch is
- * bracketed by hipEvents on the handle's stream; mre_profile_read synchronises and
- * returns the summed kernel time [ms] and launch count since enable (and resets). */
+ * bracketed by hipEvents on its stream; mre_profile_read synchronises and returns the SUM of the
+ * bracketed durations [ms] and the launch count since enable (and resets).  The env-group launches of a
+ * stepping call overlap on the GPU, so the sum can exceed the wall time: it is a per-launch figure
+ * (total / launches), not a tick time. */
 int mre_profile_enable(mre_env*, int on);
 int mre_profile_read(mre_env*, float* total_ms, int* launches);
 

@@ -265,9 +265,22 @@ static void guard_args(mre_env* e, StepArgs& a) {
 }
 
 // One group's part of a stepping call: finish its previous launch, enqueue the new one, do not wait.
+static int launch_group_enqueue(mre_env* e, mre_env::Group& G, const StepArgs& a_full);
 static int launch_group(mre_env* e, mre_env::Group& G, const StepArgs& a_full) {
   int rc = finish_group(e, G);
   if (rc) return rc;
+  rc = launch_group_enqueue(e, G, a_full);
+  if (rc) {
+    // something failed after part of the launch was enqueued: nothing may stay in flight behind an event that was
+    // never recorded (a later drain() would skip this group and race its kernels)
+    (void)hipStreamSynchronize(G.st);
+    (void)hipStreamSynchronize(G.st2);
+    G.pending = false;
+  }
+  return rc;
+}
+static int launch_group_enqueue(mre_env* e, mre_env::Group& G, const StepArgs& a_full) {
+  int rc;
   StepArgs a = a_full;
   a.N = G.n; a.env_order = e->grp_order + G.lo; a.seq_stride = e->N;
   rc = profile_events(e, &G.p0, &G.p1);
@@ -1022,10 +1035,10 @@ extern "C" int mre_set_fallback(mre_env* e, int mode) {
 
 // CRC-32C (Castagnoli) of a host buffer: the checksum of TFRecord framing (dataset.py writes the
 // reference's RLDS episodes, transporter_network_data_generation.py:56-111); slicing-by-8 tables
-extern "C" uint32_t mre_crc32c(const void* data, size_t n) {
-  static uint32_t T[8][256];
-  static bool init = false;
-  if (!init) {
+namespace {
+struct Crc32cTables {   // built once, by the C++ runtime's thread-safe initialisation of the function-local static
+  uint32_t T[8][256];
+  Crc32cTables() {
     for (uint32_t i = 0; i < 256; i++) {
       uint32_t c = i;
       for (int k = 0; k < 8; k++) c = (c >> 1) ^ ((c & 1u) ? 0x82F63B78u : 0u);
@@ -1033,8 +1046,12 @@ extern "C" uint32_t mre_crc32c(const void* data, size_t n) {
     }
     for (int k = 1; k < 8; k++)
       for (uint32_t i = 0; i < 256; i++) T[k][i] = (T[k - 1][i] >> 8) ^ T[0][T[k - 1][i] & 0xFFu];
-    init = true;
   }
+};
+}  // namespace
+extern "C" uint32_t mre_crc32c(const void* data, size_t n) {
+  static const Crc32cTables tables;
+  const uint32_t (*T)[256] = tables.T;
   const unsigned char* p = (const unsigned char*)data;
   uint32_t crc = 0xFFFFFFFFu;
   while (n >= 8) {

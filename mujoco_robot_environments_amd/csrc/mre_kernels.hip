@@ -1086,8 +1086,9 @@ MRE_PHASE_FN unsigned arm_actuation(ModelP M, Sm& s, int l) {
 
 // returns (wave-uniform) the actuators whose force is clamped by forcerange: bit a = arm actuator a, bit
 // NU - 1 = the finger actuator (mjd_actuator_vel skips those in the implicit integrator)
-MRE_DEV unsigned smooth_forces(ModelP M, Sm& s, int l) {
-  const unsigned arm_mask = arm_actuation(M, s, l);
+// (the force assembly is a phase function of its own: its fp64 terms would otherwise sit in the kernel body's register
+//  budget next to the unrolled robot solve -- 16 B/lane of scratch when it was inlined)
+MRE_PHASE_FN unsigned smooth_forces_assemble(ModelP M, Sm& s, int l, unsigned arm_mask) {
   // (the tendon length and velocity from the full finger state: the actuator's position gain of 100 N / rad acts on
   //  joints with 5e-3 kg m^2 of armature)
   const double ten_len = (double)M->ten_coef[0] * robot_q(s, M->ten_dof[0]) + (double)M->ten_coef[1] * robot_q(s, M->ten_dof[1]);
@@ -1117,6 +1118,11 @@ MRE_DEV unsigned smooth_forces(ModelP M, Sm& s, int l) {
     s.qacc_smooth[l] = f;
   }
   MRE_SYNC();
+  return arm_mask | (clamped ? 1u << (NU - 1) : 0u);
+}
+MRE_DEV unsigned smooth_forces(ModelP M, Sm& s, int l) {
+  const unsigned arm_mask = arm_actuation(M, s, l);
+  const unsigned mask = smooth_forces_assemble(M, s, l, arm_mask);
   solve_robot_one(s.qLD, s.qLDinv, s.qacc_smooth, l);
   if (l >= NRV && l < NV) {
     const int p = (l - NRV) / 6, k = (l - NRV) % 6;
@@ -1124,7 +1130,7 @@ MRE_DEV unsigned smooth_forces(ModelP M, Sm& s, int l) {
     s.qacc_smooth[l] = s.qacc_smooth[l] / md;
   }
   MRE_SYNC();
-  return arm_mask | (clamped ? 1u << (NU - 1) : 0u);
+  return mask;
 }
 
 // ------------------------------------------- mj_implicit (implicitfast) + advance

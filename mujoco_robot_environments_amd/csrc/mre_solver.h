@@ -149,27 +149,11 @@ MRE_PHASE_FN void collide(ModelP M, Sm& s, int l, bool detect) {
           m++;
         }
       n = m;
-      // mesh stand-in pairs keep ONE contact, like MuJoCo's convex-mesh test: depth of the deepest candidate, position
-      // = the centroid of the active candidates weighted by their depth below the threshold (the deepest point alone
-      // jumps between the corners of the clip polygon when two faces are nearly parallel; oracle: collision())
-      if (M->pair_single[pr] && n > 1) {
-        const float incw = M->pair_margin[pr] - M->pair_gap[pr];
-        int best = 0;
-        float wsum = 0.f, px = 0.f, py = 0.f, pz = 0.f;
-        for (int c = 0; c < n; c++) {
-          const float dc = cand_dist(buf, c);
-          if (dc < cand_dist(buf, best)) best = c;
-          const float w = incw - dc;
-          if (w > 0.f) { wsum += w; px += w * cand_xyz(buf, c)[0]; py += w * cand_xyz(buf, c)[1]; pz += w * cand_xyz(buf, c)[2]; }
-        }
-        const float dmin = cand_dist(buf, best);
-        if (wsum > 0.f) { const float iw = 1.0f / wsum; px *= iw; py *= iw; pz *= iw; }
-        else { px = cand_xyz(buf, best)[0]; py = cand_xyz(buf, best)[1]; pz = cand_xyz(buf, best)[2]; }
-        cand_xyz(buf, 0)[0] = px; cand_xyz(buf, 0)[1] = py; cand_xyz(buf, 0)[2] = pz;
-        cand_dist(buf, 0) = dmin;
-        n = 1;
-      }
     }
+    // mesh stand-in pairs keep ONE contact, like MuJoCo's convex-mesh test (formed at the write-out below)
+    const bool single = pr >= 0 && n > 1 && M->pair_single[pr] != 0;
+    const int ncand = n;
+    if (single) n = 1;
     // exclusive prefix sum of n (<= 8) over the lanes, bit by bit through ballots
     int off = base, tot = base;
     for (int bit = 0; bit < 4; bit++) {
@@ -180,6 +164,24 @@ MRE_PHASE_FN void collide(ModelP M, Sm& s, int l, bool detect) {
     if (l == 0) {
       s.ncon = tot < NCON_MAX ? tot : NCON_MAX;
       if (tot > NCON_MAX) s.overflow = 1;
+    }
+    if (single) {
+      // depth of the deepest candidate, position = the centroid of the active candidates weighted by their depth
+      // below the threshold (the deepest point alone jumps between the corners of the clip polygon when two faces are
+      // nearly parallel; oracle: collision()).  Written into candidate slot 0, which the loop below stores.
+      const float incw = M->pair_margin[pr] - M->pair_gap[pr];
+      float wsum = 0.f, px = 0.f, py = 0.f, pz = 0.f, dmin = cand_dist(buf, 0);
+      int best = 0;
+      for (int c = 0; c < ncand; c++) {
+        const float dc = cand_dist(buf, c);
+        if (dc < dmin) { dmin = dc; best = c; }
+        const float w = incw - dc;
+        if (w > 0.f) { wsum += w; px += w * cand_xyz(buf, c)[0]; py += w * cand_xyz(buf, c)[1]; pz += w * cand_xyz(buf, c)[2]; }
+      }
+      if (wsum > 0.f) { const float iw = 1.0f / wsum; px *= iw; py *= iw; pz *= iw; }
+      else { px = cand_xyz(buf, best)[0]; py = cand_xyz(buf, best)[1]; pz = cand_xyz(buf, best)[2]; }
+      cand_xyz(buf, 0)[0] = px; cand_xyz(buf, 0)[1] = py; cand_xyz(buf, 0)[2] = pz;
+      cand_dist(buf, 0) = dmin;
     }
     if (n > 0) {
       float f[9];
