@@ -1601,13 +1601,23 @@ extern "C" int mre_place_props(mre_env* e, const uint8_t* mask, uint64_t seed, c
     if (rc) return rc;
     if ((rc = copy_out(e, hs.data(), e->settle_steps, N * 4))) return rc;
     bool again = false;
+    if (getenv("MRE_DEBUG_PLACE")) {
+      int nt = 0, ns = 0;
+      for (size_t i = 0; i < N; i++) if (todo[i]) { nt++; ns += hs[i] >= 0; }
+      fprintf(stderr, "mre_place_props round %d: %d envs placed, %d settled\n", round, nt, ns);
+    }
+    int settled_now = 0;
     for (size_t i = 0; i < N; i++) {
       if (!todo[i]) continue;
       const int n = hs[i] < 0 ? -hs[i] : hs[i];
       if (n > e->last_settle_max) e->last_settle_max = n;
-      if (hs[i] >= 0) todo[i] = 0;                                  // settled
+      if (hs[i] >= 0) { todo[i] = 0; settled_now++; }               // settled
       else if (round + 1 < max_settle_attempts) again = true;       // placed again in the next round
     }
+    // a round in which NO env came to rest is not bad luck of a placement but the solver: PGS at 100 sweeps leaves a
+    // friction creep of 1e-3 rad/s on resting cubes that never passes the velocity test (all 4096 envs of the bench,
+    // in every one of ten rounds; with Newton all settle in the first).  Placing again cannot help: stop, flag them
+    if (settled_now == 0) break;
     if (again) {
       // `physics.data.time = original_time` of a failed attempt (:258): the clock goes back for the envs placed again
       std::vector<int> now(N);

@@ -36,11 +36,13 @@ class MreError(RuntimeError):
 
 
 def source_hash() -> str:
-    """sha256 (16 hex digits) over the sources libmre.so is built from: what a profile summary must have been
-    taken on for its counters to describe the build being run (bench.py, tools/summarize_profiles.py)."""
+    """sha256 (16 hex digits) over the DEVICE sources of libmre.so (the .hip files and their headers; not the host
+    side of the C ABI, which decides how launches are issued but not what a launch executes): what a profile summary
+    must have been taken on for its per-launch counters to describe the build being run (bench.py,
+    tools/summarize_profiles.py)."""
     import hashlib
     h = hashlib.sha256()
-    for f in sorted(_SOURCES + _HEADERS):
+    for f in sorted(f for f in _SOURCES + _HEADERS if not f.endswith(("mre_api.cpp", "mre.h"))):
         with open(os.path.join(_CSRC, f), "rb") as fh:
             h.update(f.encode() + b"\0" + fh.read())
     return h.hexdigest()[:16]
