@@ -364,6 +364,40 @@ def test_bench_two_rank_rehearsal_on_one_gpu():
     assert abs(d["value"] - 2 * 4096 * 5 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
 
 
+def test_placement_failure_is_per_env(compiled_model):
+    """PropPlacer raises _REJECTION_SAMPLING_FAILED for ITS env when a prop finds no collision-free pose within
+    max_attempts_per_prop (environment/prop_initializer.py:230-233).  Batched: that env gets MRE_ST_PLACEMENT_FAILED
+    and keeps its remaining cubes parked; the other envs are placed and settled as usual (round 2 returned an error
+    for the whole batch and left it half placed)."""
+    from mujoco_robot_environments_amd.physics import BatchedPhysics
+    A, _ = compiled_model
+    N = 8
+    nprops = np.array([1, 3, 1, 2, 1, 4, 1, 1], np.int32)
+    phys = BatchedPhysics(N, model=A, solver="Newton")
+    phys.set_props(nprops, np.full((N, 4, 3), 0.0155, np.float32))
+    phys.reset()
+    # a 2 cm square: one cube fits, a second can never keep the 15 cm of detection margin to the first
+    phys.place_props(7, np.array([0.45, 0.0, 0.43], np.float32), np.array([0.47, 0.02, 0.435], np.float32),
+                     max_attempts=50, settle_steps=300)
+    st = phys.status()
+    failed = (st & 16) != 0
+    assert failed.tolist() == (nprops > 1).tolist()
+    assert (st[~failed] == 0).all()                       # placed, settled, nothing else flagged
+    q = phys.qpos()
+    for i in range(N):
+        c0 = q[i, 15:18]
+        assert 0.45 - 1e-3 <= c0[0] <= 0.47 + 1e-3 and -1e-3 <= c0[1] <= 0.02 + 1e-3
+        if nprops[i] == 1:
+            assert abs(c0[2] - 0.4155) < 2e-3            # placed and settled on the table
+        if nprops[i] > 1:
+            assert 0.43 <= c0[2] <= 0.435                # a failed env is not settled: cube 0 stays where it was drawn
+            assert (np.abs(q[i, 22:25] - [2.5, 2.0, -5.0]) < 1e-6).all()                      # cube 1 stayed parked (mre_api.cpp: park_pos)
+    steps = np.zeros(N, np.int32)
+    from mujoco_robot_environments_amd import lib as _lib
+    _lib.check(_lib.lib().mre_get_settle_steps(phys._h, steps.ctypes.data), "settle_steps")
+    assert (steps[~failed] >= 300).all() and (steps[~failed] < 2000).all()
+
+
 def test_state_f64_and_time(compiled_model):
     """physics.data.qpos / .qvel / .time as the reference holds them (float64): the robot's 15 joints are
     double-float pairs on the device, mre_set_state (float rows) clears their low-order words, and time counts the
