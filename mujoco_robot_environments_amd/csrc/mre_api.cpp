@@ -551,6 +551,10 @@ static int build_model(const void* blob, size_t nbytes, DevModel& m) {
   m.solver = MRE_SOLVER_PGS;  // older blobs carry no opt_solver
   { uint32_t c, cnt; uint64_t off; if (b.find("opt_solver", &c, &cnt, &off)) RI("opt_solver", &m.solver, 1); }
   if (m.solver != MRE_SOLVER_PGS && m.solver != MRE_SOLVER_NEWTON) return fail(MRE_ERR_MODEL, "opt_solver must be 0 (PGS) or 2 (Newton)");
+  { uint32_t c, cnt; uint64_t off; int cone = 1;  // mjtCone; older blobs carry no opt_cone (elliptic)
+    if (b.find("opt_cone", &c, &cnt, &off)) RI("opt_cone", &cone, 1);
+    if (cone != 0 && cone != 1) return fail(MRE_ERR_MODEL, "opt_cone must be 0 (pyramidal) or 1 (elliptic)");
+    m.cone = cone; }
   RF("home_qpos", m.home_qpos, 7);
   float M0d[NV];
   RF("M0_diag", M0d, NV);

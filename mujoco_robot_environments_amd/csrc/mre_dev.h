@@ -120,6 +120,7 @@ struct DevModel {
   float timestep, gravity[3], impratio, tolerance;
   int iterations;
   int solver;                    // 0 = PGS, 2 = Newton (mjtSolver); selects the kernel instantiation
+  int cone;                      // mjtCone: 0 = pyramidal, 1 = elliptic (mre_solver.h: assemble_constraints)
   float home_qpos[7];
   float park_pos[NPROP][3];      // where inactive cube slots are parked
 };

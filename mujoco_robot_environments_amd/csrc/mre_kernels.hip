@@ -82,7 +82,9 @@ struct Sm {
 #ifdef MRE_NEWTON
     struct { float jar[NEFC_MAX], frc[NEFC_MAX], jv[NEFC_MAX]; };
 #else
-    struct { float jar[NEFC_MAX], frc[NEFC_MAX]; };
+    // pyr_f: pyramidal cones -- the four edge forces of every contact (frc holds their image on the contact's
+    // three rows); rides in the room the contact geometry leaves behind jar and frc
+    struct { float jar[NEFC_MAX], frc[NEFC_MAX], pyr_f[4 * NCON_MAX]; };
 #endif
   };
   float com_robot[3];
@@ -1382,7 +1384,8 @@ MRE_DEV void step_body(const StepArgs& a, Sm& s) {
       newton_solve(M, s, l);
       polished = nw_robot_polish(M, s, l);
 #else
-      solve_constraints(M, s, l);
+      if (M->cone == 0) solve_constraints_pyramidal(M, s, l);
+      else solve_constraints(M, s, l);
 #endif
       MRE_STAMP(6);
     } else {

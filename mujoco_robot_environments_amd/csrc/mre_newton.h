@@ -102,10 +102,38 @@ MRE_DEV NwContact nw_contact(float j0, float j1, float j2, float D0, float D1, f
   return o;
 }
 
+// One pyramidal contact (condim 3) on the same three rows: MuJoCo's four one-sided rows are the edges
+// e = j0 +- fr j1, j0 +- fr j2 with one D (assemble_constraints); cost = D/2 sum min(0, e)^2, the force on
+// (normal, t1, t2) is minus its gradient, the Hessian D sum_active (1, +-fr, 0)(..)' resp. (1, 0, +-fr)(..)'.
+// A contact with any active edge is reported in state NW_CONE (its 3 x 3 Hessian goes through hc like a
+// middle-zone elliptic contact's); none active: NW_SAT.
+template <bool HESS>
+MRE_DEV NwContact nw_pyramid(float j0, float j1, float j2, float D, float fr, float* hc) {
+  NwContact o;
+  const float e0 = j0 + fr * j1, e1 = j0 - fr * j1, e2 = j0 + fr * j2, e3 = j0 - fr * j2;
+  const float a0 = fminf(e0, 0.f), a1 = fminf(e1, 0.f), a2 = fminf(e2, 0.f), a3 = fminf(e3, 0.f);
+  o.f0 = -D * ((a0 + a1) + (a2 + a3));
+  o.f1 = -D * fr * (a0 - a1);
+  o.f2 = -D * fr * (a2 - a3);
+  o.cost = 0.5f * D * ((a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3));
+  const float n0 = e0 < 0.f ? 1.f : 0.f, n1 = e1 < 0.f ? 1.f : 0.f, n2 = e2 < 0.f ? 1.f : 0.f, n3 = e3 < 0.f ? 1.f : 0.f;
+  o.st = (n0 + n1 + n2 + n3) > 0.f ? NW_CONE : NW_SAT;
+  if (HESS) {
+    hc[0] = D * ((n0 + n1) + (n2 + n3));
+    hc[1] = D * fr * (n0 - n1);
+    hc[2] = D * fr * (n2 - n3);
+    hc[3] = D * fr * fr * (n0 + n1);
+    hc[4] = 0.f;
+    hc[5] = D * fr * fr * (n2 + n3);
+  }
+  return o;
+}
+
 // mj_constraintUpdate on `jar` (LDS): lane = scalar row and lane = contact.  FULL: forces,
 // states and cone Hessians are stored; otherwise only the cost is evaluated.  Returns s(jar).
-template <bool FULL>
+template <bool FULL, bool PYR>
 MRE_DEV float nw_update(Sm& s, int l, int nscalar, int ncon, float mu_scale, const float* jar) {
+  constexpr bool pyr = PYR;
   float cost = 0.f;
   if (l < nscalar) {
     const float D = 1.0f / s.efc_R[l], j = jar[l];
@@ -122,7 +150,8 @@ MRE_DEV float nw_update(Sm& s, int l, int nscalar, int ncon, float mu_scale, con
     const float D0 = 1.0f / s.efc_R[i], D1 = 1.0f / s.efc_R[i + 1], D2 = 1.0f / s.efc_R[i + 2];
     const float fr = s.con_fric[l];
     float hc[6];
-    const NwContact o = nw_contact<FULL>(jar[i], jar[i + 1], jar[i + 2], D0, D1, D2, fr, fr * mu_scale, hc);
+    const NwContact o = pyr ? nw_pyramid<FULL>(jar[i], jar[i + 1], jar[i + 2], D0, fr, hc)
+                            : nw_contact<FULL>(jar[i], jar[i + 1], jar[i + 2], D0, D1, D2, fr, fr * mu_scale, hc);
     cost += o.cost;
     if (FULL) {
       s.frc[i] = o.f0; s.frc[i + 1] = o.f1; s.frc[i + 2] = o.f2;
@@ -307,8 +336,9 @@ MRE_DEV NwLane nw_lane(ModelP M, const Sm& s, int l) {
 
 // constraint update on s.jar, qfrc_con = J' f, gradient; returns the primal cost.
 // In: s.qacc (current iterate), s.nw_Ma.  Out: s.frc, s.rstate, s.hc, s.qfrc_con, s.nw_grad.
+template <bool PYR>
 MRE_DEV float nw_update_gradient(Sm& s, int l, const NwLane& c, int nscalar, int ncon) {
-  const float sc = nw_update<true>(s, l, nscalar, ncon, c.mu_scale, s.jar);
+  const float sc = nw_update<true, PYR>(s, l, nscalar, ncon, c.mu_scale, s.jar);
   MRE_SYNC();
   const float qc = nw_JTf(s, l, c.lp, c.lk, nscalar);
   const bool on = l < NV && c.lact;
@@ -325,7 +355,8 @@ MRE_DEV float nw_update_gradient(Sm& s, int l, const NwLane& c, int nscalar, int
 
 // Phase 1: dense robot M, warm start (the cheaper of qacc_warmstart and qacc_smooth in primal
 // cost), first constraint update and gradient.  Returns the cost.
-MRE_PHASE_FN float nw_setup(ModelP M, Sm& s, int l) {
+template <bool PYR>
+MRE_DEV float nw_setup_impl(ModelP M, Sm& s, int l) {
   const NwLane c = nw_lane(M, s, l);
   const int nefc = s.nefc, ncon = s.ncon, nscalar = 7 + s.nl;
   for (int e = l; e < NRV * MD_LD; e += 64) (&s.Md[0][0])[e] = 0.f;
@@ -347,16 +378,18 @@ MRE_PHASE_FN float nw_setup(ModelP M, Sm& s, int l) {
   }
   MRE_SYNC();
   const float gauss = wave_sum(0.5f * (Ma - fs) * (qa - as));
-  const float cost_ws = gauss + nw_update<false>(s, l, nscalar, ncon, c.mu_scale, s.jar);
-  const float cost_sm = nw_update<false>(s, l, nscalar, ncon, c.mu_scale, s.jv);
+  const float cost_ws = gauss + nw_update<false, PYR>(s, l, nscalar, ncon, c.mu_scale, s.jar);
+  const float cost_sm = nw_update<false, PYR>(s, l, nscalar, ncon, c.mu_scale, s.jv);
   if (cost_ws > cost_sm || !(cost_ws == cost_ws)) {
     qa = as; Ma = fs;  // M qacc_smooth = qfrc_smooth
     for (int i = l; i < nefc; i += 64) s.jar[i] = s.jv[i];
   }
   if (l < NVP) { s.qacc[l] = qa; s.nw_Ma[l] = Ma; }
   MRE_SYNC();
-  return nw_update_gradient(s, l, c, nscalar, ncon);
+  return nw_update_gradient<PYR>(s, l, c, nscalar, ncon);
 }
+MRE_PHASE_FN float nw_setup(ModelP M, Sm& s, int l) { return nw_setup_impl<false>(M, s, l); }
+MRE_PHASE_FN float nw_setup_pyramidal(ModelP M, Sm& s, int l) { return nw_setup_impl<true>(M, s, l); }
 
 // Phase 2: search = -H^-1 grad.  H = M + J' D J (+ cone Hessians) with its rows in registers,
 // block-sparse factorisation H = W W', both triangular solves.
@@ -607,7 +640,8 @@ MRE_PHASE_FN void nw_direction_reuse(ModelP M, Sm& s, int l) {
 
 // Phase 3: exact line search along s.nw_search (PrimalSearch), move, constraint update, gradient.
 // Returns the new cost; s.scratch[0] = step (0 when no step was possible), s.scratch[1] = |grad|.
-MRE_PHASE_FN float nw_search_move(ModelP M, Sm& s, int l) {
+template <bool PYR>
+MRE_DEV float nw_search_move_impl(ModelP M, Sm& s, int l) {
   MRE_DBG_T0();
   const NwLane c = nw_lane(M, s, l);
   const int nefc = s.nefc, ncon = s.ncon, nscalar = 7 + s.nl;
@@ -639,7 +673,19 @@ MRE_PHASE_FN float nw_search_move(ModelP M, Sm& s, int l) {
     }
     float cq0 = 0.f, cq1 = 0.f, cq2 = 0.f, U0 = 0.f, V0 = 0.f, UU = 0.f, UV = 0.f, VV = 0.f, Dm = 0.f, mu = 0.f;
     const bool c_on = l < ncon;
-    if (c_on) {
+    constexpr bool pyr = PYR;
+    // pyramidal cones: the four edges' jar and J*search (nw_pyramid), one D
+    float pe0 = 0.f, pe1 = 0.f, pe2 = 0.f, pe3 = 0.f, pv0 = 0.f, pv1 = 0.f, pv2 = 0.f, pv3 = 0.f, pD = 0.f;
+    if (c_on && pyr) {
+      const int i = nscalar + 3 * l;
+      const float fr = s.con_fric[l];
+      const float j0 = s.jar[i], j1 = fr * s.jar[i + 1], j2 = fr * s.jar[i + 2];
+      const float v0 = s.jv[i], v1 = fr * s.jv[i + 1], v2 = fr * s.jv[i + 2];
+      pe0 = j0 + j1; pe1 = j0 - j1; pe2 = j0 + j2; pe3 = j0 - j2;
+      pv0 = v0 + v1; pv1 = v0 - v1; pv2 = v0 + v2; pv3 = v0 - v2;
+      pD = 1.0f / s.efc_R[i];
+    }
+    if (c_on && !pyr) {
       const int i = nscalar + 3 * l;
       const float fr = s.con_fric[l];
       mu = fr * mu_scale;
@@ -662,7 +708,15 @@ MRE_PHASE_FN float nw_search_move(ModelP M, Sm& s, int l) {
       NW_DBG_EVAL();
       float q0 = 0.f, q1 = 0.f, q2 = 0.f, ec = 0.f, e1 = 0.f, e2 = 0.f;
       if (s_on && (s_eq || sj + a * svv < 0.f)) { q0 = sq0; q1 = sq1; q2 = sq2; }
-      if (c_on) {
+      if (c_on && pyr) {
+        const float x0 = fminf(pe0 + a * pv0, 0.f), x1 = fminf(pe1 + a * pv1, 0.f);
+        const float x2 = fminf(pe2 + a * pv2, 0.f), x3 = fminf(pe3 + a * pv3, 0.f);
+        ec = 0.5f * pD * ((x0 * x0 + x1 * x1) + (x2 * x2 + x3 * x3));
+        e1 = pD * ((x0 * pv0 + x1 * pv1) + (x2 * pv2 + x3 * pv3));
+        e2 = pD * (((x0 < 0.f ? pv0 * pv0 : 0.f) + (x1 < 0.f ? pv1 * pv1 : 0.f)) +
+                   ((x2 < 0.f ? pv2 * pv2 : 0.f) + (x3 < 0.f ? pv3 * pv3 : 0.f)));
+      }
+      if (c_on && !pyr) {
         const float N = U0 + a * V0, Tsqr = UU + a * (2.f * UV + a * VV);
         bool quad = false;
         if (Tsqr <= 0.f) {
@@ -734,7 +788,7 @@ MRE_PHASE_FN float nw_search_move(ModelP M, Sm& s, int l) {
   if (l < NVP) { s.qacc[l] = qa; s.nw_Ma[l] = Ma; }
   for (int i = l; i < nefc; i += 64) s.jar[i] = fmaf(alpha, s.jv[i], s.jar[i]);
   MRE_SYNC();
-  const float cost = nw_update_gradient(s, l, c, nscalar, ncon);
+  const float cost = nw_update_gradient<PYR>(s, l, c, nscalar, ncon);
   const float gr = l < NVP ? s.nw_grad[l] : 0.f;
   const float gn = sqrtf(wave_sum(gr * gr));
   if (l == 0) s.scratch[1] = gn;
@@ -742,6 +796,8 @@ MRE_PHASE_FN float nw_search_move(ModelP M, Sm& s, int l) {
   MRE_DBG_STAMP(7, 2);
   return cost;
 }
+MRE_PHASE_FN float nw_search_move(ModelP M, Sm& s, int l) { return nw_search_move_impl<false>(M, s, l); }
+MRE_PHASE_FN float nw_search_move_pyramidal(ModelP M, Sm& s, int l) { return nw_search_move_impl<true>(M, s, l); }
 
 // ------------------------------------------------------------- mj_fwdConstraint (Newton)
 // Runs from the kernel body (the phases above are real functions and never nest calls).
@@ -775,7 +831,9 @@ MRE_DEV void newton_solve(ModelP M, Sm& s, int l) {
   for (int p = 0; p < s.nprops; p++)
     msum += 3.f * s.prop_mass[p] + s.prop_inertia[p][0] + s.prop_inertia[p][1] + s.prop_inertia[p][2];
   const float scale = 1.0f / msum;
-  nw_setup(M, s, l);
+  const bool pyr = M->cone == 0;
+  if (pyr) nw_setup_pyramidal(M, s, l);
+  else nw_setup(M, s, l);
   NW_STAMP(0);
   // The decrement test runs at MuJoCo's own tolerance.  (Round 2 ran it a decade lower to shrink the residual force
   // a solve that stops AT the threshold leaves on the finger mechanism; the fp64 polish of the robot block now
@@ -813,7 +871,8 @@ MRE_DEV void newton_solve(ModelP M, Sm& s, int l) {
       if (0.5f * scale * dec < 100.f * tol_eff && ++stalls >= 2) break;
     }
     prev_dec = dec; mprev = mk; force_full = false;
-    nw_search_move(M, s, l);
+    if (pyr) nw_search_move_pyramidal(M, s, l);
+    else nw_search_move(M, s, l);
     NW_STAMP(3);
     const float alpha = s.scratch[0];
     if (alpha == 0.f) {
@@ -908,7 +967,21 @@ MRE_PHASE_FN bool nw_robot_polish(ModelP M, Sm& s, int l) {
 #pragma unroll
       for (int t = 0; t < 9; t++) o[t] = 0.0;
       o[9] = (double)rs;
-      if (Nn >= mu * T || (T <= 0.0 && Nn >= 0.0)) {
+      if (M->cone == 0) {
+        // pyramidal cone: nw_pyramid in fp64
+        const double e[4] = {j[0] + fr * j[1], j[0] - fr * j[1], j[0] + fr * j[2], j[0] - fr * j[2]};
+        double a[4], n[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) { a[t] = e[t] < 0.0 ? e[t] : 0.0; n[t] = e[t] < 0.0 ? 1.0 : 0.0; }
+        o[0] = -D[0] * (a[0] + a[1] + a[2] + a[3]);
+        o[1] = -D[0] * fr * (a[0] - a[1]);
+        o[2] = -D[0] * fr * (a[2] - a[3]);
+        o[3] = D[0] * (n[0] + n[1] + n[2] + n[3]);
+        o[4] = D[0] * fr * (n[0] - n[1]);
+        o[5] = D[0] * fr * (n[2] - n[3]);
+        o[6] = D[0] * fr * fr * (n[0] + n[1]);
+        o[8] = D[0] * fr * fr * (n[2] + n[3]);
+      } else if (Nn >= mu * T || (T <= 0.0 && Nn >= 0.0)) {
         // top zone: no force
       } else if (mu * Nn + T <= 0.0 || (T <= 0.0 && Nn < 0.0)) {
         o[0] = -D[0] * j[0]; o[1] = -D[1] * j[1]; o[2] = -D[2] * j[2];

@@ -488,6 +488,18 @@ MRE_PHASE_FN void assemble_constraints(ModelP M, Sm& s, int l) {
         // R1 = R0/impratio ; R2 = R1 * mu0^2/mu1^2 (mu0 == mu1 for condim 3)
         R0scale = 1.0f / fmaxf(M->impratio, kMinVal);
       }
+      if (M->cone == 0) {
+        // Pyramidal cone (mj_instantiateContact / mj_makeImpedance): MuJoCo's four rows are the edges
+        // n +- mu t_k, each with the contact's distance, margin and impedance, diagApprox = tran (1 + mu^2) and
+        // one regulariser Rpy = 2 (mu^2 / impratio) R0.  Every edge is a combination of the three rows kept here:
+        // J_e = J_n +- mu J_tk, and aref_e = aref_n +- mu aref_tk exactly (the friction rows carry K = 0 and the
+        // same B and impedance), so jar_e = jar_n +- mu jar_tk: the edges are never stored, the solvers evaluate
+        // the pyramid's cost on the three rows (mre_newton.h: nw_pyramid; PGS: the edge updates of a contact
+        // block).  All three rows carry Rpy.
+        const float fr = M->pair_friction[pr][0];
+        diag = dg * (1.f + fr * fr);
+        R0scale = 2.f * fr * fr / fmaxf(M->impratio, kMinVal);
+      }
     }
     s.hdr[i] = rs | (pa << 8) | (pb << 12);
     // impedance of the block's leading row, stiffness / damping from solref
@@ -502,6 +514,7 @@ MRE_PHASE_FN void assemble_constraints(ModelP M, Sm& s, int l) {
     } else { K = -tc / (dmax * dmax); B = -dr / dmax; }
     if (fric_row) K = 0.f;
     float R = fmaxf((1.f - imp) * diag / imp, kMinVal) * R0scale;
+    if (M->cone == 0) R = fmaxf(R, kMinVal);
     // reference acceleration (mj_referenceConstraint)
     const float vel = row_dot(s, i, s.qvel);
     const float efc_margin = fric_row ? 0.f : margin;
@@ -685,7 +698,10 @@ MRE_DEV void build_schedule(ModelP M, Sm& s) {
 
 // ------------------------------------------------------------- mj_fwdConstraint
 // On exit: s.qacc = qacc_smooth + M^-1 J' f, s.qfrc_con = J' f.
-MRE_PHASE_FN void solve_constraints(ModelP M, Sm& s, int l) {
+// PYR: pyramidal friction cones (opt.cone == 0); the two instantiations are separate phase functions, so the
+// elliptic one carries nothing of the other
+template <bool PYR>
+MRE_DEV void solve_constraints_impl(ModelP M, Sm& s, int l) {
   const int nefc = s.nefc, nl = s.nl;
   const int isl = lane_island(l);
   const int ldof = lane_dof(l);
@@ -695,6 +711,12 @@ MRE_PHASE_FN void solve_constraints(ModelP M, Sm& s, int l) {
   const float linvM = (lp >= 0 && lvalid) ? prop_invM(s, lp, lk) : 0.f;
   const bool leader = (l == 0) || (l >= 16 && l < 48 && lk == 0);
   float* jar = s.jar;
+  // Pyramidal cones (opt.cone): MuJoCo's PGS walks the four edge rows e = n +- mu t_k of a contact as scalar
+  // one-sided rows with one regulariser Rpy.  The edges are combinations of the contact's three rows
+  // (assemble_constraints), so a contact stays ONE block: its residual J a + b and its 3 x 3 block of J M^-1 J' are
+  // those of the three rows, the four sequential edge updates run inside the block step on them, and the edge
+  // forces (pyr_f) are kept beside their image f = E' f_e that everything outside the block sees.
+  constexpr bool pyr = PYR;
   // ---- efc_b and warm-start forces (mj_constraintUpdate on J*qacc_warmstart - aref)
   for (int i = l; i < nefc; i += 64) {
     const float aref = rowB(s, i);
@@ -709,6 +731,14 @@ MRE_PHASE_FN void solve_constraints(ModelP M, Sm& s, int l) {
     else if ((i - 7 - nl) % 3 == 0) {
       const int c = (i - 7 - nl) / 3;
       const float fr0 = s.blkrec[8 + c][15];
+      if (pyr) {
+        const float j0 = jar[i], j1 = fr0 * jar[i + 1], j2 = fr0 * jar[i + 2];
+        const float g0 = -D * fminf(j0 + j1, 0.f), g1 = -D * fminf(j0 - j1, 0.f);
+        const float g2 = -D * fminf(j0 + j2, 0.f), g3 = -D * fminf(j0 - j2, 0.f);
+        s.pyr_f[4 * c] = g0; s.pyr_f[4 * c + 1] = g1; s.pyr_f[4 * c + 2] = g2; s.pyr_f[4 * c + 3] = g3;
+        s.frc[i] = (g0 + g1) + (g2 + g3); s.frc[i + 1] = fr0 * (g0 - g1); s.frc[i + 2] = fr0 * (g2 - g3);
+        continue;
+      }
       const float D1 = 1.0f / rowR(s, i + 1), D2 = 1.0f / rowR(s, i + 2);
       const float mu = fr0 * sqrtf(rowR(s, i + 1) / rowR(s, i));
       const float j0 = jar[i], j1 = jar[i + 1], j2 = jar[i + 2];
@@ -751,14 +781,20 @@ MRE_PHASE_FN void solve_constraints(ModelP M, Sm& s, int l) {
   float part = 0.f;
   for (int i = l; i < nefc; i += 64) {
     const float fi = s.frc[i];
-    const float Af = row_dot(s, i, s.scratch) + rowR(s, i) * fi;
+    const bool prow = pyr && i >= 7 + nl;   // the regulariser acts on the edge forces, not on their image
+    const float Af = row_dot(s, i, s.scratch) + (prow ? 0.f : rowR(s, i) * fi);
     part += fi * (0.5f * Af + rowB(s, i));
+    if (prow && (i - 7 - nl) % 3 == 0) {
+      const float* g = &s.pyr_f[4 * ((i - 7 - nl) / 3)];
+      part += 0.5f * rowR(s, i) * ((g[0] * g[0] + g[1] * g[1]) + (g[2] * g[2] + g[3] * g[3]));
+    }
   }
   const float cost = wave_sum(part);
   MRE_SYNC();
   if (cost > 0.f) {
     a = 0.f; w = 0.f;
     for (int i = l; i < nefc; i += 64) s.frc[i] = 0.f;
+    if (pyr) for (int i = l; i < 4 * s.ncon; i += 64) s.pyr_f[i] = 0.f;
   }
   MRE_SYNC();
   // ---- PGS sweeps over the island schedule
@@ -920,6 +956,35 @@ MRE_PHASE_FN void solve_constraints(ModelP M, Sm& s, int l) {
           d2 = ch2 > 1e-10f ? 0.f : d2;
           ch2 = ch2 > 1e-10f ? 0.f : ch2;
           change = ch0 + ch1 + ch2;
+        } else if (pyr) {
+          // four sequential scalar updates on the edges (1, +-fr, 0), (1, 0, +-fr); g = J a + b on the three rows
+          // follows every update through the block's J M^-1 J' (the record's A carries Rpy on its diagonal)
+          const float fr = q3.w, Rp = r0.x;
+          const float B00 = A00 - Rp, B11 = A11 - Rp, B22 = A22 - Rp;
+          float g0 = p0 + r0.y, g1 = p1 + r1.y, g2 = p2 + r2.y;
+          float* const fe = &s.pyr_f[4 * ((row0 - nscalar) / 3)];
+          float e0 = fe[0], e1 = fe[1], e2 = fe[2], e3 = fe[3];
+          auto edge1 = [&](float& f, float sf) {
+            const float res = g0 + sf * g1 + Rp * f;
+            const float AR = B00 + 2.f * sf * A01 + sf * sf * B11 + Rp;
+            float d = fmaxf(f - res * fast_rcp(AR), 0.f) - f;
+            float ch = d * (0.5f * d * AR + res);
+            if (ch > 1e-10f) { d = 0.f; ch = 0.f; }
+            g0 += (B00 + sf * A01) * d; g1 += (A01 + sf * B11) * d; g2 += (A02 + sf * A12) * d;
+            f += d; change += ch;
+          };
+          auto edge2 = [&](float& f, float sf) {
+            const float res = g0 + sf * g2 + Rp * f;
+            const float AR = B00 + 2.f * sf * A02 + sf * sf * B22 + Rp;
+            float d = fmaxf(f - res * fast_rcp(AR), 0.f) - f;
+            float ch = d * (0.5f * d * AR + res);
+            if (ch > 1e-10f) { d = 0.f; ch = 0.f; }
+            g0 += (B00 + sf * A02) * d; g1 += (A01 + sf * A12) * d; g2 += (A02 + sf * B22) * d;
+            f += d; change += ch;
+          };
+          edge1(e0, fr); edge1(e1, -fr); edge2(e2, fr); edge2(e3, -fr);
+          d0 = ((e0 + e1) + (e2 + e3)) - f0; d1 = fr * (e0 - e1) - f1; d2 = fr * (e2 - e3) - f2;
+          if (leader) { fe[0] = e0; fe[1] = e1; fe[2] = e2; fe[3] = e3; }
         } else {
           const float fr = q3.w;
           float n0 = f0, n1 = f1, n2 = f2;
@@ -996,6 +1061,9 @@ MRE_PHASE_FN void solve_constraints(ModelP M, Sm& s, int l) {
   if (l == 0) s.solver_iters = iters;
   MRE_SYNC();
 }
+
+MRE_PHASE_FN void solve_constraints(ModelP M, Sm& s, int l) { solve_constraints_impl<false>(M, s, l); }
+MRE_PHASE_FN void solve_constraints_pyramidal(ModelP M, Sm& s, int l) { solve_constraints_impl<true>(M, s, l); }
 
 #endif  // !MRE_NEWTON
 

@@ -560,6 +560,7 @@ def compile_scene(scene: dict = None) -> Dict[str, np.ndarray]:
     A["opt_timestep"] = np.array([o["timestep"]])
     A["opt_gravity"] = np.asarray(o["gravity"], dtype=np.float64)
     A["opt_impratio"] = np.array([o["impratio"]])
+    A["opt_cone"] = np.array([{"pyramidal": 0, "elliptic": 1}[o.get("cone", "elliptic")]], np.int32)  # mjtCone
     A["opt_tolerance"] = np.array([o["tolerance"]])
     A["opt_iterations"] = np.array([o["iterations"]], np.int32)
     A["opt_solver"] = np.array([{"PGS": 0, "Newton": 2}[o.get("solver", "PGS")]], np.int32)  # mjtSolver

@@ -387,9 +387,10 @@ def other_task_scene(task: str, cfg: Optional[Dict] = None, embed: bool = True, 
     the attachment body when the task has none, four cube slots); False gives the task's own body tree
     (used by the oracle cross-check of the embedding and by tools/emit_mjcf.py).
 
-    Without the 2F-85 nothing sets ``cone`` / ``impratio``: MuJoCo's defaults there are pyramidal / 1.
-    The kernels implement elliptic cones only, so push / lasa run ``cone=elliptic impratio=1`` (stated
-    deviation).
+    Without the 2F-85 nothing sets ``cone`` / ``impratio``: MuJoCo's defaults apply there, pyramidal / 1, and
+    that is what push / lasa run here (``cfg["cone"] = "elliptic"`` selects the other cone; rounds 1-2 ran these
+    tasks with it, tests/test_other_tasks.py measures what that cost).  The kernels and the oracle implement
+    both (csrc/mre_solver.h: assemble_constraints).
     """
     cfg = cfg or {}
     motor = cfg.get("motor_ctrlrange", [87.0, 87.0, 87.0, 87.0, 12.0, 12.0, 12.0])
@@ -457,7 +458,8 @@ def other_task_scene(task: str, cfg: Optional[Dict] = None, embed: bool = True, 
         option=dict(
             timestep=float(cfg.get("physics_dt", default_dt)),
             gravity=tuple(cfg.get("gravity", (0.0, 0.0, -9.8))),
-            integrator="implicitfast", cone="elliptic", impratio=10.0 if has_gripper else 1.0,
+            integrator="implicitfast", cone=str(cfg.get("cone", "elliptic" if has_gripper else "pyramidal")),
+            impratio=10.0 if has_gripper else 1.0,   # base: inherited from 2f85.xml; push / lasa: MuJoCo's defaults
             solver=str(cfg.get("solver", "Newton")),   # MuJoCo's default: these tasks set no solver either
             iterations=100, tolerance=1e-8, ls_iterations=50, ls_tolerance=0.01,
         ),

@@ -27,7 +27,9 @@
 #define GEOM_BOX 1
 #define EQ_CONNECT 0
 #define EQ_JOINT 1
-enum { EFC_EQ = 0, EFC_LIMIT = 1, EFC_CONTACT = 2 };
+enum { EFC_EQ = 0, EFC_LIMIT = 1, EFC_CONTACT = 2, EFC_PYRAMID = 3 };
+/* limit rows and the rows of a pyramidal contact are scalar and one-sided (force >= 0) */
+#define EFC_ONESIDED(t) ((t) == EFC_LIMIT || (t) == EFC_PYRAMID)
 
 struct mro_model {
   int nbody, nv, nq, nM, ngeom, nsite, npair, neq, nprop;
@@ -62,6 +64,7 @@ struct mro_model {
   double act_gain[MRO_NU], act_bias[MRO_NU][3], act_forcerange[MRO_NU][2];
   int act_forcelimited[MRO_NU];
   double timestep, gravity[3], impratio, tolerance, ls_tolerance;
+  int cone; /* mjtCone: 0 pyramidal, 1 elliptic */
   int iterations, solver, ls_iterations; /* solver: 0 = PGS, 2 = Newton (mjtSolver) */
   int arm_dof[7], eef_site, tcp_site, prop_bodyid[MRO_MAXPROP];
   double home_qpos[7];
@@ -309,9 +312,10 @@ mro_model* mro_model_load(const void* blob, size_t nbytes) {
   LD1(impratio, "opt_impratio"); LD1(tolerance, "opt_tolerance");
   LI1(iterations, "opt_iterations");
   /* optional entries (older blobs: PGS, MuJoCo's line-search defaults) */
-  m->solver = 0; m->ls_iterations = 50; m->ls_tolerance = 0.01;
+  m->solver = 0; m->ls_iterations = 50; m->ls_tolerance = 0.01; m->cone = 1;
   { blob_entry e;
     if (blob_find(b, "opt_solver", &e)) blob_i(b, "opt_solver", &m->solver, 1);
+    if (blob_find(b, "opt_cone", &e)) blob_i(b, "opt_cone", &m->cone, 1);
     if (blob_find(b, "opt_ls_iterations", &e)) blob_i(b, "opt_ls_iterations", &m->ls_iterations, 1);
     if (blob_find(b, "opt_ls_tolerance", &e)) blob_d(b, "opt_ls_tolerance", &m->ls_tolerance, 1);
     for (int a = 0; a < MRO_NU; a++) m->act_gain[a] = 1.0;
@@ -408,6 +412,11 @@ double mro_solver_cost(const mro_data* d) { return d->solver_cost; }
 int mro_solver_iters(const mro_data* d) { return d->solver_iters; }
 int mro_ncon(const mro_data* d) { return d->ncon; }
 int mro_nefc(const mro_data* d) { return d->nefc; }
+int mro_ncon_active(const mro_data* d) {   /* contacts with constraint rows (three, or four with pyramidal cones) */
+  int n = 0;
+  for (int c = 0; c < d->ncon; c++) n += d->contact[c].efc_address >= 0;
+  return n;
+}
 int mro_nl(const mro_data* d) { return d->nl; }
 int mro_limit_mask(const mro_data* d) {
   int mask = 0;
@@ -940,7 +949,8 @@ static void make_constraint(const mro_model* m, mro_data* d) {
     }
   }
   d->nl = d->nefc - d->ne;
-  /* contacts (mj_instantiateContact, elliptic cones, condim 3).  Optional capacity emulation of
+  /* contacts (mj_instantiateContact, condim 3: three rows of an elliptic cone, or the four edges
+   * normal +- friction * tangent of a pyramidal one).  Optional capacity emulation of
    * the device kernels (mro_set_caps): the first ncon_cap ACTIVE contacts are candidates; the list
    * is cut at the first contact that would exceed the row / robot-row / cube-cube capacities. */
   d->overflow = 0;
@@ -953,17 +963,32 @@ static void make_constraint(const mro_model* m, mro_data* d) {
       if (d->ncon_cap > 0 && nact >= d->ncon_cap) { d->overflow = 1; stop = 1; continue; }
       int rob = (con->body1 > 0 && m->body_propid[con->body1] < 0) || (con->body2 > 0 && m->body_propid[con->body2] < 0);
       int two = m->body_propid[con->body1] >= 0 && m->body_propid[con->body2] >= 0;
-      if ((d->nefc_cap > 0 && d->nefc + 3 > d->nefc_cap) || (d->nrrow_cap > 0 && rob && rrows + 3 > d->nrrow_cap) ||
-          (d->npp_cap > 0 && two && npp >= d->npp_cap) || d->nefc + 3 > MRO_MAXEFC) {
+      int nrow = m->cone == 0 ? 4 : 3;
+      if ((d->nefc_cap > 0 && d->nefc + nrow > d->nefc_cap) || (d->nrrow_cap > 0 && rob && rrows + nrow > d->nrrow_cap) ||
+          (d->npp_cap > 0 && two && npp >= d->npp_cap) || d->nefc + nrow > MRO_MAXEFC) {
         d->overflow = 1; stop = 1; continue;
       }
       nact++;
-      if (rob) rrows += 3;
+      if (rob) rrows += nrow;
       if (two) npp++;
       jac_point(m, d, con->body1, con->pos, jp1, NULL);
       jac_point(m, d, con->body2, con->pos, jp2, NULL);
       double da = d->body_invweight0[con->body1][0] + d->body_invweight0[con->body2][0];
       con->efc_address = d->nefc;
+      if (m->cone == 0) {
+        /* pyramidal: rows (n + mu_k t_k), (n - mu_k t_k) for k = 1, 2; every row carries the contact's
+         * distance and margin; diagApprox = tran * (1 + mu_k^2) */
+        for (int r = 0; r < 4; r++) {
+          int k = 1 + r / 2;
+          double sg = (r & 1) ? -1.0 : 1.0, mu = con->friction[k - 1], ax[3];
+          for (int a = 0; a < 3; a++) ax[a] = con->frame[a] + sg * mu * con->frame[3 * k + a];
+          for (int i = 0; i < nv; i++)
+            J[i] = ax[0] * (jp2[i] - jp1[i]) + ax[1] * (jp2[nv + i] - jp1[nv + i]) +
+                   ax[2] * (jp2[2 * nv + i] - jp1[2 * nv + i]);
+          add_row(d, EFC_PYRAMID, c, J, nv, con->dist, con->includemargin, da * (1.0 + mu * mu));
+        }
+        continue;
+      }
       for (int r = 0; r < 3; r++) {
         const double* ax = con->frame + 3 * r;
         for (int i = 0; i < nv; i++)
@@ -1012,6 +1037,10 @@ static void make_impedance(const mro_model* m, mro_data* d) {
     } else if (type == EFC_LIMIT) {
       solref = m->jnt_solref[id]; solimp = m->jnt_solimp[id];
       pos = d->efc_pos[i];
+    } else if (type == EFC_PYRAMID) {
+      solref = d->contact[id].solref; solimp = d->contact[id].solimp;
+      dim = 4;
+      pos = d->efc_pos[i];
     } else {
       solref = d->contact[id].solref; solimp = d->contact[id].solimp;
       dim = 3;
@@ -1034,6 +1063,15 @@ static void make_impedance(const mro_model* m, mro_data* d) {
       d->efc_KBIP[i + j][1] = B;
       d->efc_KBIP[i + j][2] = imp;
       d->efc_KBIP[i + j][3] = 0;
+    }
+    if (type == EFC_PYRAMID) {
+      /* pyramidal: one R for the four edges, Rpy = 2 mu^2 R0 with mu = friction[0] / sqrt(impratio) */
+      mro_contact_t* con = &d->contact[id];
+      double ir = m->impratio > MINVAL ? m->impratio : MINVAL;
+      con->mu = con->friction[0] / sqrt(ir);
+      double Rpy = 2.0 * con->mu * con->mu * d->efc_R[i];
+      if (Rpy < MINVAL) Rpy = MINVAL;
+      for (int j = 0; j < 4; j++) d->efc_R[i + j] = Rpy;
     }
     if (type == EFC_CONTACT) {
       /* elliptic friction rows: R1 = R0/impratio; mu of regularised cone */
@@ -1265,7 +1303,7 @@ static double constraint_update_full(const mro_model* m, mro_data* d, const doub
       i++;
       continue;
     }
-    if (type == EFC_LIMIT) {
+    if (EFC_ONESIDED(type)) {
       if (jar[i] < 0) {
         force[i] = -d->efc_D[i] * jar[i];
         cost += 0.5 * d->efc_D[i] * jar[i] * jar[i];
@@ -1336,7 +1374,7 @@ static void sol_pgs(const mro_model* m, mro_data* d, int maxiter, double toleran
       }
       if (dim == 1) {
         f[i] -= res[0] / AR[(size_t)i * MRO_MAXEFC + i];
-        if (type == EFC_LIMIT && f[i] < 0) f[i] = 0;
+        if (EFC_ONESIDED(type) && f[i] < 0) f[i] = 0;
       } else {
         const mro_contact_t* con = &d->contact[d->efc_id[i]];
         double At[9];
@@ -1561,7 +1599,7 @@ static void newton_ls_eval(const mro_model* m, mro_data* d, const newton_ctx* c,
     int type = d->efc_type[i];
     const double* q = c->quad[i];
     if (type == EFC_EQ) { q0 += q[0]; q1 += q[1]; q2 += q[2]; i++; continue; }
-    if (type == EFC_LIMIT) {
+    if (EFC_ONESIDED(type)) {
       if (c->jar[i] + alpha * c->jv[i] < 0) { q0 += q[0]; q1 += q[1]; q2 += q[2]; }
       i++;
       continue;

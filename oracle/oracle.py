@@ -65,6 +65,7 @@ def lib() -> C.CDLL:
         L.mro_get.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int)]
         L.mro_ncon.argtypes = [C.c_void_p]
         L.mro_nefc.argtypes = [C.c_void_p]
+        L.mro_ncon_active.argtypes = [C.c_void_p]
         L.mro_nl.argtypes = [C.c_void_p]
         L.mro_limit_mask.argtypes = [C.c_void_p]
         L.mro_contact.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double)]
@@ -189,7 +190,7 @@ class Env:
     def census(self) -> int:
         """Constraint census of the current position: active contacts + 64 * (bit b - 1: the hinge
         of body b has an active limit row)."""
-        return (self.nefc - 7 - self.nl) // 3 + 64 * lib().mro_limit_mask(self.ptr)
+        return lib().mro_ncon_active(self.ptr) + 64 * lib().mro_limit_mask(self.ptr)
 
     @property
     def solver_iters(self):

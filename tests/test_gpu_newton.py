@@ -278,3 +278,33 @@ def test_robot_self_collision_is_opt_in_and_matches_the_oracle():
     print(f"self-collision: arm + fingers max |dq| vs oracle after {T} steps {worst:.2e}; status {np.unique(phys.status()).tolist()}")
     assert (phys.status() & 6 == 0).all()
     assert worst < TOL
+
+
+@pytest.mark.parametrize("solver", ["Newton", "PGS"])
+def test_pyramidal_cones_on_the_scene_with_the_most_contact_structure(solver):
+    """opt.cone = pyramidal (MuJoCo's default; the reference's PushEnv / LasaDrawEnv run it, tests/test_gpu_other_tasks.py)
+    on the rearrangement scene, whose contacts exercise every block shape of both solvers: cube-table, cube-cube,
+    finger-cube, arm-cube, finger-ground.  The oracle builds MuJoCo's four edge rows per contact; the kernels evaluate
+    the same pyramid on the contact's three rows.  32 envs x 500 steps of the bench's full-range torque law."""
+    from mujoco_robot_environments_amd.model import compile as MC
+    from oracle import oracle as O
+    A = MC.compile_scene()
+    A["opt_cone"][:] = 0
+    cm = (A, MC.to_blob(A))
+    om = O.Model(cm[1])
+    N = 32
+    gq, oq, nprops, phys, gcen, ocen = _rollout_both(cm, om, N=N, T=100, flags=0, scale=1.0, seed=5, z_extra=0.0005,
+                                                     yaw=True, solver=solver, census=True)
+    under, switched, unexplained, cmax = _divergence_report(f"pyramidal {solver} bench law", gq, oq, nprops, gcen, ocen)
+    assert np.isfinite(gq).all() and (phys.status() == 0).all()
+    if solver == "Newton":
+        assert not unexplained and cmax < TOL and len(under) + len(switched) == N and len(under) >= N - 2
+    else:
+        # (PGS is cut at 100 sweeps: the finger linkage's soft rows are not converged, DESIGN.md section 7)
+        err = np.abs(gq - oq)
+        for i in range(N):
+            err[:, i, 15 + 7 * int(nprops[i]):] = 0
+        clean = [i for i in range(N) if not np.any(gcen[:, i] != ocen[:, i])]
+        assert len(clean) >= N - 2
+        assert err[:, clean, :7].max() < 1e-4 and np.median(err[:, clean, 15:].max(axis=(0, 2))) < 2e-5
+    phys.close()

@@ -155,7 +155,7 @@ def test_push_friction_quirk_and_the_forwarded_gradient():
             dec[(ff, xc)] = (e.arr("qvel")[16] + 0.5) / 0.05
     g = 9.8
     for key, mu in (((False, 0.2), 1.0), ((False, 0.9), 1.0), ((True, 0.2), 0.4), ((True, 0.9), 0.8)):
-        assert 0.9 * mu * g < dec[key] < 1.01 * mu * g, (key, dec[key])
+        assert 0.9 * mu * g < dec[key] < 1.05 * mu * g, (key, dec)   # (pyramidal cones, along a tangent axis: 0.98 .. 1.03)
 
 
 def test_configs_of_the_other_tasks():
@@ -203,3 +203,55 @@ def test_emitted_mjcf_of_the_other_tasks(task):
                 if ((masks[a][0] & masks[b][1]) or (masks[b][0] & masks[a][1])) and not (static[a] and static[b]))
     explicit = len(root.find("contact")) if root.find("contact") is not None else 0   # robot self-collision pairs
     assert ncoll + explicit == int(A["npair"][0]), (ncoll, explicit, int(A["npair"][0]))
+
+
+def test_oracle_pyramidal_cone_rest_diamond_and_what_the_elliptic_stand_in_cost():
+    """PushEnv / LasaDrawEnv set neither `cone` nor `impratio`: the reference's MuJoCo runs them with pyramidal cones
+    (four one-sided edge rows n +- mu t_k per contact, R = 2 mu^2 R0 on each, diagApprox = tran (1 + mu^2)).  The
+    oracle builds those rows; three known answers: (1) a resting block sinks exactly as deep as with an elliptic cone
+    (MuJoCo scales the edges' R for that); (2) sliding friction is a diamond -- mu g along the contact frame's
+    tangent axes, about mu g / sqrt(2) along their diagonal -- where an elliptic cone brakes both alike; (3) what
+    rounds 1-2 paid for running these tasks with elliptic cones: 3 mm of block travel over an 11 cm push."""
+    rest, dec = {}, {}
+    for cone in ("elliptic", "pyramidal"):
+        for solver in ("Newton", "PGS"):
+            A = MC.compile_scene(spec.other_task_scene("push", dict(cone=cone, solver=solver)))
+            assert int(A["opt_cone"][0]) == (0 if cone == "pyramidal" else 1)
+            M = O.Model(MC.to_blob(A))
+            for name, vel in (("axis", (-0.5, 0.0)), ("diag", (-0.5 / np.sqrt(2), -0.5 / np.sqrt(2)))):
+                e = O.Env(M, 1, np.full((4, 3), 0.025))
+                e.reset()
+                e.arr("qpos")[:7] = A["home_qpos"]
+                e.arr("qpos")[15:22] = [0.5, 0.3, 0.425, 1, 0, 0, 0]
+                e.freeze_robot(True)
+                e.forward()
+                e.step(300)
+                assert e.nefc - 7 - e.nl == (16 if cone == "pyramidal" else 12)   # four corner contacts
+                rest[(cone, solver)] = e.arr("qpos")[17] - 0.425
+                e.arr("qvel")[15:17] = vel
+                e.forward()
+                e.step(30)
+                v = e.arr("qvel")[15:17]
+                dec[(cone, solver, name)] = (0.5 - np.hypot(*v)) / 0.03 / 9.8
+                assert abs(v[0] * vel[1] - v[1] * vel[0]) < 2e-2 * 0.5 * np.hypot(*v)   # braked along its motion
+    for solver in ("Newton", "PGS"):
+        assert abs(rest[("pyramidal", solver)] - rest[("elliptic", solver)]) < 5e-7, rest
+        assert -1.2e-4 < rest[("pyramidal", solver)] < -1.0e-4
+        assert 0.93 < dec[("pyramidal", solver, "axis")] < 1.02, dec
+        assert 0.78 < dec[("pyramidal", solver, "diag")] < 0.88, dec
+        assert abs(dec[("elliptic", solver, "diag")] / dec[("elliptic", solver, "axis")] - 1.0) < 0.08, dec
+    # (3) the push of test_push_embedding_equals_the_arm_only_model under both cones
+    traj = {}
+    for cone in ("elliptic", "pyramidal"):
+        A, M, e = _oracle("push", dict(cone=cone))
+        p = O.make_osc()
+        pa = int(A["body_qposadr"][A["prop_bodyid"][0]])
+        out = []
+        for k in range(300):
+            p.target_pos[:] = [0.2 + 0.0006 * k, 0.0, 0.53]
+            p.target_quat[:] = [0, 0, 1, 0]
+            e.run_controller(p, 0.0, 1, 5)
+            out.append(e.arr("qpos")[pa:pa + 3].copy())
+        traj[cone] = np.array(out)
+    gap = np.abs(traj["elliptic"] - traj["pyramidal"]).max(axis=0)
+    assert traj["pyramidal"][-1][0] > 0.40 and 5e-4 < gap[0] < 6e-3, gap
