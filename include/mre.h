@@ -230,7 +230,11 @@ int mre_set_fallback(mre_env*, int mode);
  * selects it at mre_create; the reference leaves MuJoCo's default, Newton
  * (tasks/rearrangement.py:77-80 sets timestep / gravity / nconmax / njmax only), BASELINE.json's
  * north_star prescribes PGS.  Both are built; mre_set_solver switches a live handle (the state,
- * warm start included, carries over). mre_get_solver returns the current value. */
+ * warm start included, carries over). mre_get_solver returns the current value.
+ *
+ * Friction cone (mjOption.cone): the blob's `opt_cone`, 0 = pyramidal (MuJoCo's default: the reference's PushEnv /
+ * LasaDrawEnv models, which set neither cone nor impratio), 1 = elliptic (the rearrangement and base scenes inherit it
+ * from the 2F-85's model).  Blobs without the entry are elliptic.  Both cones are built into both solvers. */
 /* Stream ordering with the caller's own stream: device buffers handed to the library (controls,
  * control sequences, trace buffers) are consumed on the handle's stream (mre_stream); when another
  * stream produced them, mre_wait_stream(h, that_stream) makes every later launch of the handle wait
