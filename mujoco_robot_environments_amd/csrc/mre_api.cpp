@@ -28,7 +28,8 @@ extern "C" void mre_launch_restore_rows(const uint8_t* sel, int env0, int N, flo
                                         const float* sv_qvel, float* qacc_ws, const float* sv_qacc_ws, float* qfine,
                                         const float* sv_qfine, float* ctrl, const float* sv_ctrl, int* nstep,
                                         const int* sv_nstep, uint32_t* status, const uint32_t* sv_status,
-                                        uint8_t* converged, const uint8_t* sv_converged, hipStream_t stream);
+                                        uint8_t* converged, const uint8_t* sv_converged, uint8_t* pending,
+                                        hipStream_t stream);
 extern "C" void mre_launch_pose_search(const SearchArgs* args, hipStream_t stream);
 extern "C" void mre_launch_sort_select(const SortArgs* args, hipStream_t stream);
 extern "C" void mre_launch_reset(const DevModel* M, int N, float* qpos, float* qvel, float* qacc_ws, float* qfine,
@@ -99,7 +100,10 @@ struct mre_env {
   float* contacts = nullptr;     // device [N][1 + 3 * CONTACT_EXPORT] (detect launches), allocated on first use
   int* settle_steps = nullptr;   // device [N]
   int* launch_info = nullptr;    // device [N][4]
-  int* h_launch_info = nullptr;  // pinned host mirror
+  int* h_launch_info = nullptr;  // pinned host mirror: two buffers of [N][4] (a group's two launches in flight)
+  int* h_info_last = nullptr;    // the buffer (one of the two, per group region) that holds each env's latest record
+  uint8_t* d_pending = nullptr;  // device [N]: env overflowed the compact kernel, waits for its re-run (StepArgs::pending)
+  uint8_t* h_large_stage = nullptr;  // pinned [2][N]: staging of the d_large uploads, per ring slot
   std::vector<uint8_t> h_large, h_rerun;
   int n_large = 0;
   long long* d_env_ids = nullptr; // device copy of env_ids (pose search), null = offset + index
@@ -110,23 +114,30 @@ struct mre_env {
   int last_settle_max = 0;
   long long n_reruns = 0, n_promotions = 0, n_demotions = 0;
   // ---- pipelined env groups (launch_step): the envs are cut into contiguous groups, each with its own stream
-  // pair; a stepping call enqueues every group's launch and returns, and a group's launch info is read -- and its
-  // fallback decisions taken -- only when the NEXT launch of that group is issued (or at the next call that
-  // touches the state: drain()).  The tail of one group's launch (its slowest envs) then overlaps the other
-  // group's next launch instead of leaving the GPU idle.
+  // pair; a stepping call enqueues every group's launch and returns.  The tail of one group's launch (its slowest
+  // envs) then overlaps the other groups' next launches instead of leaving the GPU idle.
+  // A group's launch info is read -- and its fallback decisions taken -- ONE LAUNCH LATE: launch t + 1 of a group is
+  // enqueued behind launch t without the host in between (reading t's info first put the read-back copy, the host's
+  // wake-up and the enqueue, 100 - 200 us, between every two launches of a chain whose launches last 800 us: the
+  // kernel trace of the Newton bench), and t's info is processed when launch t + 2 is issued (or at the next call
+  // that touches the state: drain()).  An env that overflows the compact kernel in launch t is therefore skipped by
+  // launch t + 1 on the device (StepArgs::pending) and re-run for BOTH launches on the large kernel.
   struct Group {
     int lo = 0, n = 0;
     hipStream_t st = nullptr, st2 = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_info = nullptr;
-    bool pending = false;
-    StepArgs args;   // of the pending launch (a re-run uses them)
-    hipEvent_t p0 = nullptr, p1 = nullptr;   // profiling bracket of the pending launch
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    struct Out {           // a launch whose info has not been processed yet
+      StepArgs args;       // (a re-run uses them)
+      hipEvent_t ev_info = nullptr;
+    } out[2];              // ring: out[head] is the older one
+    int head = 0, nout = 0;
+    hipEvent_t p0 = nullptr, p1 = nullptr;   // profiling bracket of the launch being enqueued
   };
   std::vector<Group> groups;
   int* grp_order = nullptr;     // device [N]: per group, its envs slowest first
   int* h_grp_order = nullptr;   // pinned staging
   hipEvent_t ev_main = nullptr; // orders the group streams after the handle's stream
-  float* seq_copy[2] = {nullptr, nullptr};  // own copies of the last two ctrl_seq arguments (re-runs read them later)
+  float* seq_copy[3] = {nullptr, nullptr, nullptr};  // own copies of the last three ctrl_seq arguments (re-runs read them later)
   size_t seq_cap = 0;
   unsigned seq_calls = 0;
   double dbg_wait_s = 0, dbg_call_s = 0; long dbg_calls = 0;   // MRE_DEBUG_TIMING
@@ -174,29 +185,36 @@ static int profile_events(mre_env* e, hipEvent_t* e0, hipEvent_t* e1) {
   return MRE_OK;
 }
 
-// Read the launch info of a group's pending launch and act on it (see launch_step): promotions / demotions,
-// dispatch order of the group's next launch, re-run of the envs that overflowed the compact kernel.
-static int finish_group(mre_env* e, mre_env::Group& G) {
-  if (!G.pending) return MRE_OK;
+// Read the launch info of a group's OLDEST outstanding launch and act on it (see launch_step): promotions /
+// demotions, dispatch order of the group's next launch, re-run of the envs that overflowed the compact kernel --
+// for that launch and for the younger outstanding one, which skipped them.
+static int process_oldest(mre_env* e, mre_env::Group& G) {
+  if (G.nout == 0) return MRE_OK;
+  const int slot = G.head;
+  mre_env::Group::Out& O = G.out[slot];
   {
     const auto w0 = std::chrono::steady_clock::now();
-    HIPCHK(hipEventSynchronize(G.ev_info));
+    HIPCHK(hipEventSynchronize(O.ev_info));
     e->dbg_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
   }
-  G.pending = false;
+  const int* const info = e->h_launch_info + (size_t)slot * 4 * (size_t)e->N;
+  int* const order_stage = e->h_grp_order + (size_t)slot * (size_t)e->N;
   int nrerun = 0;
   bool changed = false;
   int kmax = 0;
   for (int i = G.lo; i < G.lo + G.n; i++) {
-    const int* li = e->h_launch_info + 4 * (size_t)i;
+    const int* li = info + 4 * (size_t)i;
     e->h_rerun[i] = 0;
-    if (li[0] < 0) continue;
+    if (li[0] < 0) continue;   // not part of the launch, or skipped while it waited for a re-run
     const int hw_ncon = li[1] & 0xFFFF, hw_nefc = li[2], hw_nrrow = li[3] & 0xFFFF, hw_npp = li[3] >> 16;
     if ((li[1] >> 16) > kmax) kmax = li[1] >> 16;
-    if (!e->h_large[i]) {
-      if (li[0] > 0) {
-        e->h_rerun[i] = 1; e->h_large[i] = 1; nrerun++; changed = true; e->n_large++; e->n_promotions++;
-      } else if (!e->compact_only && (8 * hw_ncon > 7 * NCON_MAX || 8 * hw_nefc > 7 * NEFC_MAX ||
+    if (li[0] == 1) {
+      // overflowed the COMPACT kernel (whatever the host's flag says by now: a promotion decided one launch ago
+      // takes effect one launch later)
+      e->h_rerun[i] = 1; nrerun++;
+      if (!e->h_large[i]) { e->h_large[i] = 1; changed = true; e->n_large++; e->n_promotions++; }
+    } else if (!e->h_large[i]) {
+      if (!e->compact_only && (8 * hw_ncon > 7 * NCON_MAX || 8 * hw_nefc > 7 * NEFC_MAX ||
                                       8 * hw_nrrow > 7 * NRROW_MAX || 8 * hw_npp > 7 * NPP_MAX)) {
         e->h_large[i] = 1; changed = true; e->n_large++; e->n_promotions++;
       }
@@ -205,34 +223,47 @@ static int finish_group(mre_env* e, mre_env::Group& G) {
       e->h_large[i] = 0; changed = true; e->n_large--; e->n_demotions++;
     }
   }
+  // (the uploads below are enqueued BEHIND the younger outstanding launch and take effect with the launch after it;
+  //  their pinned staging areas are per ring slot: a slot is rewritten two launches later, after the event of a launch
+  //  that follows the upload in stream order has been waited for)
   if (kmax > 0) {   // longest processing time first within the group (counting sort, stable)
     int count[258] = {0};
     auto bucket = [&](int i) {
-      const int* li = e->h_launch_info + 4 * (size_t)i;
+      const int* li = info + 4 * (size_t)i;
       return (int)((long long)(li[0] < 0 ? 0 : (li[1] >> 16)) * 255 / kmax);
     };
     for (int i = G.lo; i < G.lo + G.n; i++) count[255 - bucket(i) + 1]++;
     for (int k = 1; k <= 256; k++) count[k] += count[k - 1];
-    for (int i = G.lo; i < G.lo + G.n; i++) e->h_grp_order[G.lo + count[255 - bucket(i)]++] = i;
-    HIPCHK(hipMemcpyAsync(e->grp_order + G.lo, e->h_grp_order + G.lo, (size_t)G.n * 4, hipMemcpyHostToDevice, G.st));
+    for (int i = G.lo; i < G.lo + G.n; i++) order_stage[G.lo + count[255 - bucket(i)]++] = i;
+    HIPCHK(hipMemcpyAsync(e->grp_order + G.lo, order_stage + G.lo, (size_t)G.n * 4, hipMemcpyHostToDevice, G.st));
   }
   if (nrerun > 0) {
     HIPCHK(hipMemcpyAsync(e->mask_r + G.lo, e->h_rerun.data() + G.lo, (size_t)G.n, hipMemcpyHostToDevice, G.st));
     mre_launch_restore_rows(e->mask_r, G.lo, G.n, e->qpos, e->sv_qpos, e->qvel, e->sv_qvel, e->qacc_ws, e->sv_qacc_ws,
                             e->qfine, e->sv_qfine, e->ctrl, e->sv_ctrl, e->nstep, e->sv_nstep, e->status, e->sv_status,
-                            e->converged, e->sv_converged, G.st);
-    StepArgs ar = G.args;
-    ar.env_mask = e->mask_r; ar.launch_info = nullptr; ar.large = nullptr; ar.sv_qpos = nullptr;
-    launch_large(e, ar, G.st);
-    HIPCHK(hipGetLastError());
+                            e->converged, e->sv_converged, e->d_pending, G.st);
+    // the launch that overflowed, then the younger outstanding launch (which left these envs alone)
+    for (int k = 0; k < G.nout; k++) {
+      StepArgs ar = G.out[(slot + k) & 1].args;
+      ar.env_mask = e->mask_r; ar.launch_info = nullptr; ar.large = nullptr; ar.sv_qpos = nullptr; ar.pending = nullptr;
+      launch_large(e, ar, G.st);
+      HIPCHK(hipGetLastError());
+    }
     e->n_reruns += nrerun;
   }
   if (changed) {
-    HIPCHK(hipMemcpyAsync(e->d_large + G.lo, e->h_large.data() + G.lo, (size_t)G.n, hipMemcpyHostToDevice, G.st));
-    HIPCHK(hipStreamSynchronize(G.st));   // (the staged bytes must outlive the upload)
-  } else if (nrerun > 0) {
-    HIPCHK(hipStreamSynchronize(G.st));
+    uint8_t* stage = e->h_large_stage + (size_t)slot * (size_t)e->N;
+    memcpy(stage + G.lo, e->h_large.data() + G.lo, (size_t)G.n);
+    HIPCHK(hipMemcpyAsync(e->d_large + G.lo, stage + G.lo, (size_t)G.n, hipMemcpyHostToDevice, G.st));
   }
+  if (nrerun > 0) HIPCHK(hipStreamSynchronize(G.st));   // (h_rerun is pageable: the staged bytes must outlive the upload)
+  // the latest record of every env of the group (mre_get_launch_info)
+  for (int i = G.lo; i < G.lo + G.n; i++) {
+    const int* li = info + 4 * (size_t)i;
+    if (li[0] != -2) memcpy(e->h_info_last + 4 * (size_t)i, li, 16);
+  }
+  G.head ^= 1;
+  G.nout--;
   return MRE_OK;
 }
 
@@ -244,12 +275,14 @@ static int drain(mre_env* e, bool api_call = false) {
     e->calls_since_drain = 0;
   }
   bool any = false;
-  for (auto& G : e->groups) any = any || G.pending;
+  for (auto& G : e->groups) any = any || G.nout > 0;
   if (!any) return MRE_OK;
   HIPCHK(hipSetDevice(e->device));
   for (auto& G : e->groups) {
-    int rc = finish_group(e, G);
-    if (rc) return rc;
+    while (G.nout > 0) {
+      int rc = process_oldest(e, G);
+      if (rc) return rc;
+    }
     HIPCHK(hipStreamSynchronize(G.st));
   }
   return MRE_OK;
@@ -267,15 +300,18 @@ static void guard_args(mre_env* e, StepArgs& a) {
 // One group's part of a stepping call: finish its previous launch, enqueue the new one, do not wait.
 static int launch_group_enqueue(mre_env* e, mre_env::Group& G, const StepArgs& a_full);
 static int launch_group(mre_env* e, mre_env::Group& G, const StepArgs& a_full) {
-  int rc = finish_group(e, G);
-  if (rc) return rc;
-  rc = launch_group_enqueue(e, G, a_full);
+  // at most one launch stays unprocessed behind the one enqueued here
+  while (G.nout >= 2) {
+    int rc = process_oldest(e, G);
+    if (rc) return rc;
+  }
+  int rc = launch_group_enqueue(e, G, a_full);
   if (rc) {
     // something failed after part of the launch was enqueued: nothing may stay in flight behind an event that was
-    // never recorded (a later drain() would skip this group and race its kernels)
+    // never recorded (a later drain() would wait for it)
     (void)hipStreamSynchronize(G.st);
     (void)hipStreamSynchronize(G.st2);
-    G.pending = false;
+    G.nout = 0; G.head = 0;
   }
   return rc;
 }
@@ -288,6 +324,8 @@ static int launch_group_enqueue(mre_env* e, mre_env::Group& G, const StepArgs& a
   HIPCHK(hipStreamWaitEvent(G.st, e->ev_main, 0));
   if (G.p0) HIPCHK(hipEventRecord(G.p0, G.st));
   guard_args(e, a);
+  a.pending = e->d_pending;
+  const int slot = (G.head + G.nout) & 1;
   StepArgs ac = a;
   ac.want_large = 0;
   bool run_large = false;
@@ -305,11 +343,11 @@ static int launch_group_enqueue(mre_env* e, mre_env::Group& G, const StepArgs& a
   HIPCHK(hipGetLastError());
   if (run_large) HIPCHK(hipStreamWaitEvent(G.st, G.ev_join, 0));
   if (G.p1) HIPCHK(hipEventRecord(G.p1, G.st));
-  HIPCHK(hipMemcpyAsync(e->h_launch_info + 4 * (size_t)G.lo, e->launch_info + 4 * (size_t)G.lo, (size_t)G.n * 16,
-                        hipMemcpyDeviceToHost, G.st));
-  HIPCHK(hipEventRecord(G.ev_info, G.st));
-  G.args = a;
-  G.pending = true;
+  HIPCHK(hipMemcpyAsync(e->h_launch_info + (size_t)slot * 4 * (size_t)e->N + 4 * (size_t)G.lo,
+                        e->launch_info + 4 * (size_t)G.lo, (size_t)G.n * 16, hipMemcpyDeviceToHost, G.st));
+  HIPCHK(hipEventRecord(G.out[slot].ev_info, G.st));
+  G.out[slot].args = a;
+  G.nout++;
   return MRE_OK;
 }
 
@@ -331,7 +369,7 @@ static int launch_step(mre_env* e, const StepArgs& a, bool settle = false, bool 
       for (size_t left = ng; left > 0;) {
         size_t pick = ng;
         for (size_t g = 0; g < ng && pick == ng; g++)
-          if (!done[g] && (!e->groups[g].pending || hipEventQuery(e->groups[g].ev_info) == hipSuccess)) pick = g;
+          if (!done[g] && (e->groups[g].nout < 2 || hipEventQuery(e->groups[g].out[e->groups[g].head].ev_info) == hipSuccess)) pick = g;
         (void)hipGetLastError();   // (hipErrorNotReady of a query is not an error)
         if (pick == ng) {          // none ready: wait for the first outstanding one
           for (size_t g = 0; g < ng && pick == ng; g++) if (!done[g]) pick = g;
@@ -383,6 +421,7 @@ static int launch_step(mre_env* e, const StepArgs& a, bool settle = false, bool 
     if (run_large) HIPCHK(hipStreamWaitEvent(e->stream, e->ev_join, 0));
     HIPCHK(hipMemcpyAsync(e->h_launch_info, e->launch_info, N * 16, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
+    memcpy(e->h_info_last, e->h_launch_info, N * 16);
     int nrerun = 0;
     bool changed = false;
     for (size_t i = 0; i < N; i++) {
@@ -433,7 +472,7 @@ static int launch_step(mre_env* e, const StepArgs& a, bool settle = false, bool 
       HIPCHK(hipMemcpyAsync(e->mask_r, e->h_rerun.data(), N, hipMemcpyHostToDevice, e->stream));
       mre_launch_restore_rows(e->mask_r, 0, e->N, e->qpos, e->sv_qpos, e->qvel, e->sv_qvel, e->qacc_ws, e->sv_qacc_ws,
                               e->qfine, e->sv_qfine, e->ctrl, e->sv_ctrl, e->nstep, e->sv_nstep, e->status,
-                              e->sv_status, e->converged, e->sv_converged, e->stream);
+                              e->sv_status, e->converged, e->sv_converged, nullptr, e->stream);
       StepArgs ar = a;
       ar.env_mask = e->mask_r; ar.launch_info = nullptr;
       launch_large(e, ar, e->stream);
@@ -690,7 +729,12 @@ static int create_buffers(mre_env* e, int num_envs, int device_id) {
   HIPCHK(hipMalloc(&e->sv_qacc_ws, N * NVP * 4)); HIPCHK(hipMalloc(&e->sv_ctrl, N * NU * 4));
   HIPCHK(hipMalloc(&e->sv_status, N * 4)); HIPCHK(hipMalloc(&e->launch_info, N * 16));
   HIPCHK(hipMalloc(&e->sv_converged, N));
-  HIPCHK(hipHostMalloc((void**)&e->h_launch_info, N * 16, hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void**)&e->h_launch_info, 2 * N * 16, hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void**)&e->h_info_last, N * 16, hipHostMallocDefault));
+  memset(e->h_info_last, 0xFF, N * 16);   // -1: no launch yet
+  HIPCHK(hipHostMalloc((void**)&e->h_large_stage, 2 * N, hipHostMallocDefault));
+  HIPCHK(hipMalloc(&e->d_pending, N));
+  HIPCHK(hipMemsetAsync(e->d_pending, 0, N, e->stream));
   HIPCHK(hipMemsetAsync(e->d_large, 0, N, e->stream));
   e->h_large.assign(N, 0); e->h_rerun.assign(N, 0);
   {
@@ -702,7 +746,7 @@ static int create_buffers(mre_env* e, int num_envs, int device_id) {
     if (ng > 8) ng = 8;
     while (ng > 1 && num_envs < min_envs * ng) ng--;
     HIPCHK(hipMalloc(&e->grp_order, N * 4));
-    HIPCHK(hipHostMalloc((void**)&e->h_grp_order, N * 4, hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void**)&e->h_grp_order, 2 * N * 4, hipHostMallocDefault));   // staging, per ring slot
     for (int i = 0; i < num_envs; i++) e->h_grp_order[i] = i;
     HIPCHK(hipMemcpy(e->grp_order, e->h_grp_order, N * 4, hipMemcpyHostToDevice));
     HIPCHK(hipEventCreateWithFlags(&e->ev_main, hipEventDisableTiming));
@@ -728,7 +772,8 @@ static int create_buffers(mre_env* e, int num_envs, int device_id) {
       HIPCHK(hipStreamCreateWithPriority(&G.st2, hipStreamNonBlocking, pr));
       HIPCHK(hipEventCreateWithFlags(&G.ev_fork, hipEventDisableTiming));
       HIPCHK(hipEventCreateWithFlags(&G.ev_join, hipEventDisableTiming));
-      HIPCHK(hipEventCreateWithFlags(&G.ev_info, hipEventDisableTiming));
+      HIPCHK(hipEventCreateWithFlags(&G.out[0].ev_info, hipEventDisableTiming));
+      HIPCHK(hipEventCreateWithFlags(&G.out[1].ev_info, hipEventDisableTiming));
     }
   }
   if (const char* fb = getenv("MRE_NO_FALLBACK")) e->fallback = atoi(fb) == 0;  // profiling knob only
@@ -804,7 +849,7 @@ extern "C" int mre_destroy(mre_env* e) {
     if (G.st2) { (void)hipStreamSynchronize(G.st2); (void)hipStreamDestroy(G.st2); }
     if (G.ev_fork) (void)hipEventDestroy(G.ev_fork);
     if (G.ev_join) (void)hipEventDestroy(G.ev_join);
-    if (G.ev_info) (void)hipEventDestroy(G.ev_info);
+    for (auto& O : G.out) if (O.ev_info) (void)hipEventDestroy(O.ev_info);
   }
   if (e->ev_main) (void)hipEventDestroy(e->ev_main);
   if (e->grp_order) (void)hipFree(e->grp_order);
@@ -821,6 +866,9 @@ extern "C" int mre_destroy(mre_env* e) {
                   e->ps_pick};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (e->h_launch_info) (void)hipHostFree(e->h_launch_info);
+  if (e->h_info_last) (void)hipHostFree(e->h_info_last);
+  if (e->h_large_stage) (void)hipHostFree(e->h_large_stage);
+  if (e->d_pending) (void)hipFree(e->d_pending);
   if (e->h_auto_order) (void)hipHostFree(e->h_auto_order);
   for (auto& pr : e->events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   if (e->ev_order) (void)hipEventDestroy(e->ev_order);
@@ -1241,14 +1289,15 @@ extern "C" int mre_rollout(mre_env* e, const float* ctrl_seq, int nticks, int co
   a.sites = nullptr;  // (as in mre_step)
   if (e->groups.size() > 1 && nticks > 0) {
     // a pipelined launch may be re-run (capacity fallback) after this call has returned: it reads the controls
-    // from the handle's own copy (two buffers: the copy of call k is needed until call k + 1 has been issued)
+    // from the handle's own copy (three buffers: a launch's info is processed when the second launch after it is
+    // issued, so the copy of call k is needed until call k + 2 has been issued)
     const size_t n = (size_t)nticks * (size_t)e->N * NU;
     if (n > e->seq_cap) {
       DRAIN_PENDING(e);
       for (float*& p : e->seq_copy) { if (p) HIPCHK(hipFree(p)); p = nullptr; HIPCHK(hipMalloc(&p, n * 4)); }
       e->seq_cap = n;
     }
-    float* dst = e->seq_copy[e->seq_calls++ & 1u];
+    float* dst = e->seq_copy[e->seq_calls++ % 3u];
     HIPCHK(hipMemcpyAsync(dst, ctrl_seq, n * 4, hipMemcpyDeviceToDevice, e->stream));
     a.ctrl_seq = dst;
   }
@@ -1731,7 +1780,7 @@ extern "C" int mre_get_launch_info(mre_env* e, int32_t* info) {
   DRAIN(e);
   HIPCHK(hipSetDevice(e->device));
   HIPCHK(hipStreamSynchronize(e->stream));
-  return copy_out(e, info, e->h_launch_info, (size_t)e->N * 16);
+  return copy_out(e, info, e->h_info_last, (size_t)e->N * 16);
 }
 
 extern "C" int mre_set_env_ids(mre_env* e, const long long* ids) {

@@ -191,9 +191,15 @@ struct StepArgs {
   int* sv_nstep;
   uint32_t* sv_status;
   uint8_t* sv_converged;
-  int* launch_info;          // [N][4] or null: {overflowed in this launch, max ncon | the env's own duration
-                             //  in this launch (s_memtime ticks >> 10) << 16, max nefc, max robot rows | max cube-cube
-                             //  contacts << 16} over the launch's steps
+  int* launch_info;          // [N][4] or null: {overflow in this launch: 1 on the compact kernel (the host re-runs the
+                             //  env), 2 on the large one; -1: not part of the launch; -2: skipped, see `pending`,
+                             //  max ncon | the env's own duration in this launch (s_memtime ticks >> 10) << 16,
+                             //  max nefc, max robot rows | max cube-cube contacts << 16} over the launch's steps
+  // The host reads a launch's info one launch late (the next launch of the group is already enqueued by then).  An env
+  // that overflows the compact kernel raises its `pending` byte; the launches that follow leave such an env alone
+  // (state rows and save area untouched) until the host has put it back and re-run every launch it missed on the
+  // large kernel (k_restore_rows clears the byte).  null: no such protocol (synchronous launches, re-runs).
+  uint8_t* pending;          // [N] or null
 };
 
 // Rejection sampling of a cube pose (k_pose_search): PropPlacer.__call__'s per-prop loop

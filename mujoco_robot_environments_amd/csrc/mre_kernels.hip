@@ -1245,6 +1245,11 @@ MRE_DEV void step_body(const StepArgs& a, Sm& s) {
     if (a.launch_info != nullptr && l < 4) a.launch_info[(size_t)env * 4 + l] = -1;
     return;
   }
+  if (a.pending != nullptr && a.pending[env] != 0) {
+    // overflowed the compact kernel in an earlier launch whose info the host has not read yet: wait for the re-run
+    if (a.launch_info != nullptr && l < 4) a.launch_info[(size_t)env * 4 + l] = l == 0 ? -2 : -1;
+    return;
+  }
   ModelP M = (ModelP)a.M;
 
   // ---- load state (one coalesced row per array); with a save area, the rows as they were before this launch are
@@ -1492,8 +1497,16 @@ MRE_DEV void step_body(const StepArgs& a, Sm& s) {
   if (l == 0 && a.launch_info != nullptr) {
     int* li = a.launch_info + (size_t)env * 4;
     const unsigned long long dt = (__builtin_amdgcn_s_memtime() - launch_t0) >> 10;
-    li[0] = s.overflow; li[1] = hw_ncon | ((int)(dt < 0x7FFFull ? dt : 0x7FFFull) << 16); li[2] = hw_nefc; li[3] = hw_nrrow | (hw_npp << 16);
+#ifdef MRE_LARGE_CAPS
+    li[0] = s.overflow ? 2 : 0;
+#else
+    li[0] = s.overflow ? 1 : 0;
+#endif
+    li[1] = hw_ncon | ((int)(dt < 0x7FFFull ? dt : 0x7FFFull) << 16); li[2] = hw_nefc; li[3] = hw_nrrow | (hw_npp << 16);
   }
+#ifndef MRE_LARGE_CAPS
+  if (l == 0 && a.pending != nullptr && s.overflow) a.pending[env] = 1;
+#endif
   if (l == 0 && a.status != nullptr) {
     unsigned st = 0;
     for (int k = 0; k < NQ; k++) if (!isfinite(s.qpos[k])) st |= 2u;
@@ -1750,9 +1763,10 @@ __global__ __launch_bounds__(64) void k_restore_rows(const uint8_t* sel, int env
                                                      const float* sv_qacc_ws, float* qfine, const float* sv_qfine,
                                                      float* ctrl, const float* sv_ctrl, int* nstep, const int* sv_nstep,
                                                      uint32_t* status, const uint32_t* sv_status, uint8_t* converged,
-                                                     const uint8_t* sv_converged) {
+                                                     const uint8_t* sv_converged, uint8_t* pending) {
   const int env = env0 + blockIdx.x, l = threadIdx.x;
   if ((int)blockIdx.x >= N || sel[env] == 0) return;
+  if (l == 0 && pending != nullptr) pending[env] = 0;
   if (l < NQP) qpos[(size_t)env * NQP + l] = sv_qpos[(size_t)env * NQP + l];
   if (l < NVP) {
     qvel[(size_t)env * NVP + l] = sv_qvel[(size_t)env * NVP + l];
@@ -1769,10 +1783,11 @@ extern "C" void mre_launch_restore_rows(const uint8_t* sel, int env0, int N, flo
                                         const float* sv_qvel, float* qacc_ws, const float* sv_qacc_ws, float* qfine,
                                         const float* sv_qfine, float* ctrl, const float* sv_ctrl, int* nstep,
                                         const int* sv_nstep, uint32_t* status, const uint32_t* sv_status,
-                                        uint8_t* converged, const uint8_t* sv_converged, hipStream_t stream) {
+                                        uint8_t* converged, const uint8_t* sv_converged, uint8_t* pending,
+                                        hipStream_t stream) {
   hipLaunchKernelGGL(mre::k_restore_rows, dim3(N), dim3(64), 0, stream, sel, env0, N, qpos, sv_qpos, qvel, sv_qvel,
                      qacc_ws, sv_qacc_ws, qfine, sv_qfine, ctrl, sv_ctrl, nstep, sv_nstep, status, sv_status, converged,
-                     sv_converged);
+                     sv_converged, pending);
 }
 
 extern "C" void mre_launch_pose_search(const mre::SearchArgs* args, hipStream_t stream) {

@@ -235,8 +235,9 @@ def test_fallback_reproduces_the_large_kernel_bit_for_bit(compiled_model, solver
 @pytest.mark.parametrize("solver", ["PGS", "Newton"])
 def test_pipelined_env_groups_equal_the_synchronous_path(compiled_model, solver, monkeypatch):
     """The stepping calls cut the batch into env groups on separate streams and return before the launches have
-    finished; a group's launch info is read -- and an overflowing env re-run from its saved rows -- only when the
-    group's next launch is issued or the state is touched.  Same grasp-on-the-table scenario as above (promotions
+    finished; a group's launch info is read -- and an overflowing env re-run from its saved rows, for that launch and
+    for the one enqueued behind it, which skipped the env on the device -- only when the group's next launch but one is
+    issued or the state is touched.  Same grasp-on-the-table scenario as above (promotions
     and re-runs mid-phase), then 30 ticks of per-tick control sequences, one call per tick without a sync in
     between: state, status and fallback counters must equal the single-group (synchronous) handle bit for bit."""
     import torch
@@ -270,7 +271,9 @@ def test_pipelined_env_groups_equal_the_synchronous_path(compiled_model, solver,
                        phys.fallback_stats(), phys.solver_stats().copy())
         phys.close()
     assert out[1][4]["promotions"] > 0 and out[1][4]["reruns"] > 0, out[1][4]
-    assert out[1][4] == out[3][4], (out[1][4], out[3][4])
+    # (the groups read a launch's info one launch late: a promotion takes effect a launch later than on the synchronous
+    #  handle, so more envs overflow the compact kernel before they are moved -- and are re-run, for two launches)
+    assert out[3][4]["promotions"] > 0 and out[3][4]["reruns"] >= out[1][4]["reruns"], (out[1][4], out[3][4])
     for k in (0, 1, 2, 3, 5):
         assert np.array_equal(out[1][k], out[3][k]), k
 
