@@ -94,8 +94,9 @@ int mre_reset(mre_env*, const uint8_t* mask);
 int mre_place_props(mre_env*, const uint8_t* mask, uint64_t seed, const float* ws_min,
                     const float* ws_max, int max_attempts, int settle_steps);
 int mre_get_settle_steps(mre_env*, int32_t* steps);
-/* Per-env record of the last stepping launch, info [N][4] int32: {overflowed the compact capacities (-1: the
- * env was not part of the launch), max contacts | the env's own duration << 16 (clock ticks >> 10; the key of
+/* Per-env record of the last stepping launch, info [N][4] int32: {1: overflowed the compact capacities (the library
+ * has re-run the env on the large kernel by the time this returns), 2: overflowed the large ones (MRE_ST_OVERFLOW),
+ * 0: neither, -1: the env was not part of the launch, max contacts | the env's own duration << 16 (clock ticks >> 10; the key of
  * the longest-first dispatch of the next launch), max constraint rows, max robot rows | max cube-cube
  * contacts << 16} over the launch's steps.  Diagnostics; nothing in the reference corresponds to it. */
 int mre_get_launch_info(mre_env*, int32_t* info);
