@@ -149,22 +149,18 @@ def test_resting_contact_parity(compiled_model, oracle_model):
 
 CUBE_POS = np.array([15 + 7 * p + k for p in range(4) for k in range(3)])
 CUBE_QUAT = np.array([15 + 7 * p + 3 + k for p in range(4) for k in range(4)])
-CUBE_QUAT_TOL = 1e-3
+CUBE_QUAT_TOL = 5e-4
 
 
-def _assert_regimes(err, grip_frac=0.9, grip_max=5e-3):
-    """Tolerances per regime (fp32 device vs fp64 oracle), max over the rollout:
-      * arm joints and cube positions: |dq| < 1e-4 for every env (north-star bar);
-      * cube quaternion components: < 1e-3.  Resting cubes creep in yaw by ~1e-3 rad/s because
-        PGS stops at its 100-sweep cap before the friction rows converge (the oracle shows the
-        same creep, tests/test_oracle_kat.py); the creep rate is set by rounding-level residuals,
-        so fp32 and fp64 drift apart slowly in orientation while positions agree;
-      * the 8 passive/driven finger-linkage joints: < 1e-4 for >= 90 % of the envs and
-        < 5e-3 always.  The linkage couplers rest exactly AT their joint limit
-        (range [-1.57, 0], q ~ 0), so a limit row can switch on one step earlier or
-        later in fp32 than in fp64 when a crossing lands within the accumulated
-        rounding error (~2e-6) of zero; MuJoCo's limit model is discontinuous there
-        (aref jumps by B*vel), which perturbs the few-gram links by up to ~1e-3 rad."""
+def _assert_regimes(err, grip_max=1e-4):
+    """Tolerances per regime (fp32 device vs fp64 oracle, PGS), max over the rollout:
+      * arm joints, cube positions and the 8 finger-linkage joints: |dq| < 1e-4 for every env (north-star bar;
+        measured 4.5e-7 / 2.1e-5 / 1.3e-7 -- rounds 1-2 allowed the linkage 5e-3 in 10 % of the envs: its state is
+        now carried in double-float form, DESIGN.md section 7);
+      * cube quaternion components: < 5e-4 (measured 1.6e-4).  Resting cubes creep in yaw by ~1e-3 rad/s because
+        PGS stops at its 100-sweep cap before the friction rows converge (the oracle shows the same creep,
+        tests/test_oracle_kat.py); the creep rate is set by rounding-level residuals, so fp32 and fp64 drift apart
+        slowly in orientation while positions agree."""
     arm = err[:, :, :7].max()
     cpos = err[:, :, CUBE_POS].max()
     cquat = err[:, :, CUBE_QUAT].max()
@@ -173,7 +169,7 @@ def _assert_regimes(err, grip_frac=0.9, grip_max=5e-3):
     print(f"regimes: arm {arm:.2e} cube pos {cpos:.2e} cube quat {cquat:.2e} grip<{QPOS_TOL} for {frac:.0%} of envs, "
           f"grip max {grip_env.max():.2e}")
     assert arm < QPOS_TOL and cpos < QPOS_TOL and cquat < CUBE_QUAT_TOL
-    assert frac >= grip_frac and grip_env.max() < grip_max
+    assert grip_env.max() < grip_max
 
 
 def _osc_setup(compiled_model, oracle_model, N, seed=5):
@@ -253,47 +249,59 @@ def test_osc_run_controller_parity(compiled_model, oracle_model):
     _assert_regimes(err)
 
 
+def _bar_report(name, gq, oq, nprops, gcen, ocen):
+    from tests.test_gpu_newton import _divergence_report
+    under, switched, unexplained, cmax = _divergence_report(name, gq, oq, nprops, gcen, ocen)
+    err = np.abs(gq - oq)
+    for i in range(err.shape[1]):
+        err[:, i, 15 + 7 * int(nprops[i]):] = 0
+    clean = [i for i in range(err.shape[1]) if not np.any(gcen[:, i] != ocen[:, i])]
+    arm_env, grip_env = err[:, :, :7].max(axis=(0, 2)), err[:, :, 7:15].max(axis=(0, 2))
+    cube_clean = err[:, clean][:, :, 15:].max()
+    print("   per env: arm median %.2e max %.2e; finger linkage median %.2e 90%% %.2e max %.2e; cubes (envs without a census switch) max %.2e"
+          % (np.median(arm_env), arm_env.max(), np.median(grip_env), np.quantile(grip_env, 0.9), grip_env.max(), cube_clean))
+    return under, switched, unexplained, cmax, arm_env, grip_env, cube_clean
+
+
 def test_long_rollout_parity_1000_steps(compiled_model, oracle_model):
-    """BASELINE.json north_star bar: max|qpos - qpos_ref| < 1e-4 over 1000 env-steps.
-    64 envs x 1000 steps (200 ticks), cubes resting on the table, arm under gravity
-    compensation + 10 % random torques, random gripper commands (SURVEY 8(d) 'gentler
-    variant'; full-range torques slam the joint limits and are covered by the bench's
-    health counters).  Tolerances per regime as in _assert_regimes."""
-    gq, oq, nprops, phys = _rollout_both(compiled_model, oracle_model, N=64, T=200, flags=0, scale=0.1,
-                                         seed=21, z_extra=0.0005, gravity_comp=True, yaw=True)
-    err = _report("1000-step rollout", gq, oq, nprops)
-    arm_env = err[:, :, :7].max(axis=(0, 2))
-    cube_env = err[:, :, 15:].max(axis=(0, 2))
-    print("per-env arm err  : median %.2e  max %.2e" % (np.median(arm_env), arm_env.max()))
-    print("per-env cube err : median %.2e  max %.2e" % (np.median(cube_env), cube_env.max()))
+    """BASELINE.json north_star bar with north_star's solver (PGS, cut at 100 sweeps): max|qpos - qpos_ref| < 1e-4
+    over 1000 env-steps on ALL 43 coordinates.  64 envs, cubes resting on the table, arm under gravity compensation
+    + 10 % random torques, random gripper commands -- the workload of the Newton test
+    (tests/test_gpu_newton.py::test_newton_long_rollout_1000_steps_all_coordinates), same rules: an env may leave
+    the bar only after its constraint census differed from the oracle's.  Measured: 63 / 64 under the bar (one exit
+    after a census switch), 3.3e-5 among the rest; rounds 1-2 allowed the finger linkage 5e-2 here (measured 1.3e-2):
+    what changed is the robot's state in double-float form and the finger bias forces in fp64,
+    which the PGS builds share with the Newton ones."""
+    N = 64
+    gq, oq, nprops, phys, gcen, ocen = _rollout_both(compiled_model, oracle_model, N=N, T=200, flags=0, scale=0.1,
+                                                     seed=11, z_extra=0.0005, gravity_comp=True, yaw=True,
+                                                     solver="PGS", census=True)
+    under, switched, unexplained, cmax, arm_env, grip_env, cube_clean = _bar_report("PGS 1000 steps", gq, oq, nprops, gcen, ocen)
     assert (phys.status() == 0).all()
-    # north-star bar on the coordinates that define the task state
-    assert err[:, :, :7].max() < QPOS_TOL and err[:, :, CUBE_POS].max() < QPOS_TOL
-    assert err[:, :, CUBE_QUAT].max() < CUBE_QUAT_TOL
-    # finger linkage under a command that is re-drawn every 5 ms (never the case in the
-    # reference, whose MinMax command switches twice per pick/place): the four-bar is closed by
-    # soft equality rows that PGS leaves unconverged at its 100-sweep cap, and its couplers sit on
-    # their joint limit, so fp32 and fp64 drift apart by ~1e-3 rad in the few-gram follower links
-    # (gradual) and by up to ~3e-2 rad for a few hundred steps after a limit row switches one step
-    # apart (sudden).  The arm and the cubes are not affected (bounds above).
-    grip_env = err[:, :, 7:15].max(axis=(0, 2))
-    print("per-env finger-linkage err: median %.2e  90%% %.2e  max %.2e" %
-          (np.median(grip_env), np.quantile(grip_env, 0.9), grip_env.max()))
-    assert np.median(grip_env) < 1e-3 and grip_env.max() < 5e-2
+    assert not unexplained, unexplained
+    assert cmax < QPOS_TOL
+    assert len(under) + len(switched) == N and len(under) >= N - 2
+    assert arm_env.max() < 2e-5 and cube_clean < 5e-5
 
 
 def test_full_range_random_torques_stay_close(compiled_model, oracle_model):
-    """BASELINE configs[1] action law at full scale (tau ~ U(+-87 / +-12) Nm, no gravity
-    compensation): the arm is thrown into its joint limits within ~0.1 s, so trajectories are only
-    compared statistically over 500 steps -- most envs still agree to 1e-4, none blows up."""
-    gq, oq, nprops, phys = _rollout_both(compiled_model, oracle_model, N=32, T=100, flags=0, scale=1.0,
-                                         seed=33, z_extra=0.0005, yaw=True)
-    err = _report("full-range torques, 500 steps", gq, oq, nprops)
-    arm_env = err[:, :, :7].max(axis=(0, 2))
-    print("per-env arm err: median %.2e  90%% %.2e  max %.2e" % (np.median(arm_env), np.quantile(arm_env, 0.9), arm_env.max()))
+    """BASELINE configs[1]'s own action law (tau ~ U(+-87 / +-12) N m re-drawn every tick, gripper command U(0, 255))
+    with PGS over 1000 steps, 64 envs: the arm is thrown against its joint limits, onto the table and into the cubes.
+    PGS stops at its 100-sweep cap before the soft rows that close the finger four-bars have converged (by
+    construction: mean_solver_iters = 100), so where the device's float32 sweeps and the oracle's float64 sweeps stand
+    after 100 of them differs in the last bits of the finger forces -- no polish applies to an iterate that is not the
+    optimum.  Measured: 60 / 64 envs under 1e-4 on all 43 coordinates (one exit after a census switch, three finger
+    exits of 8e-4 .. 7e-3 rad without one), arm 4e-5 and cubes 1.1e-5 in the envs without a census switch; the
+    Newton path holds the bar in 64 / 64 (tests/test_gpu_newton.py)."""
+    N = 64
+    gq, oq, nprops, phys, gcen, ocen = _rollout_both(compiled_model, oracle_model, N=N, T=200, flags=0, scale=1.0,
+                                                     seed=5, z_extra=0.0005, yaw=True, solver="PGS", census=True)
+    under, switched, unexplained, cmax, arm_env, grip_env, cube_clean = _bar_report("PGS bench law", gq, oq, nprops, gcen, ocen)
     assert np.isfinite(gq).all() and (phys.status() & 2 == 0).all()
-    assert np.median(arm_env) < QPOS_TOL
-    assert err[:, :, CUBE_POS].max() < 1e-3
+    assert len(under) >= N - 8 and len(unexplained) <= 5, (len(under), unexplained)
+    assert cmax < 5e-3                                  # (the finger exits; every other coordinate below)
+    assert np.median(arm_env) < 1e-5 and np.median(grip_env) < 1e-5
+    assert cube_clean < 5e-5
 
 
 def test_scripted_pick_phases_match_oracle(compiled_model, oracle_model):
