@@ -1,5 +1,6 @@
-"""Generates tests/golden/oracle_rollout_v2.npz from THIS repo's fp64 CPU oracle (one rollout per
-solver: PGS as BASELINE.json prescribes, Newton as the reference's MuJoCo runs).
+"""Generates tests/golden/oracle_rollout_v2.npz (elliptic cones, the rearrangement scene's own) and
+oracle_rollout_pyramidal_v1.npz (the same scenario with MuJoCo's default pyramidal cones) from THIS repo's fp64 CPU
+oracle (one rollout per solver: PGS as BASELINE.json prescribes, Newton as the reference's MuJoCo runs).
 
 The reference cannot produce vectors here (MuJoCo / dm_control / mujoco_controllers are
 absent), so the fixture pins the oracle against regressions and gives
@@ -29,8 +30,10 @@ def scenario():
     return ids, nprops, sizes, yaws, acts
 
 
-def run(solver="PGS"):
+def run(solver="PGS", cone="elliptic"):
     A = MC.compile_scene()
+    if cone == "pyramidal":   # MuJoCo's default cone on the same scene (oracle_rollout_pyramidal_v1.npz)
+        A["opt_cone"][:] = 0
     m = O.Model(MC.to_blob(A))
     ids, nprops, sizes, yaws, acts = scenario()
     q0 = np.zeros((N, 43))
@@ -56,6 +59,11 @@ def run(solver="PGS"):
 if __name__ == "__main__":
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle_rollout_v2.npz")
     r, rn = run("PGS"), run("Newton")
+    r["qpos_newton"], r["qvel_newton"] = rn["qpos"], rn["qvel"]
+    np.savez_compressed(out, **r)
+    print("wrote", out)
+    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle_rollout_pyramidal_v1.npz")
+    r, rn = run("PGS", "pyramidal"), run("Newton", "pyramidal")
     r["qpos_newton"], r["qvel_newton"] = rn["qpos"], rn["qvel"]
     np.savez_compressed(out, **r)
     print("wrote", out)
