@@ -192,16 +192,19 @@ def test_dispatch_order_does_not_change_results(compiled_model):
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
 
 
-@pytest.mark.parametrize("solver", ["PGS", "Newton"])
-def test_fallback_reproduces_the_large_kernel_bit_for_bit(compiled_model, solver):
+@pytest.mark.parametrize("solver,cone", [("PGS", "elliptic"), ("Newton", "elliptic"), ("PGS", "pyramidal"), ("Newton", "pyramidal")])
+def test_fallback_reproduces_the_large_kernel_bit_for_bit(compiled_model, solver, cone):
     """Closing the gripper on a cube with the pads pressed onto the table (pick height 1 cm too low:
     pad-table plus pad-cube contacts) overflows the compact capacities.  Running the envs
     compact-first with re-runs (the default) must give exactly the bits of running every env on the
     large kernel from the start: both kernels execute the same arithmetic, and a re-run starts from
-    the saved pre-launch rows."""
+    the saved pre-launch rows.  (cone = pyramidal: the same scenario through the pyramidal instantiations of the
+    solver phases, compact and large.)"""
     import bench
     from mujoco_robot_environments_amd import demo_logic
-    A, _ = compiled_model
+    A = dict(compiled_model[0])
+    if cone == "pyramidal":
+        A["opt_cone"] = np.zeros(1, np.int32)
     N = 64
     out = {}
     for mode in (1, 2):
@@ -226,7 +229,10 @@ def test_fallback_reproduces_the_large_kernel_bit_for_bit(compiled_model, solver
             phys.run_controller(50, 5)
         out[mode] = (phys.qpos().copy(), phys.qvel().copy(), phys.status().copy(), phys.fallback_stats())
         phys.close()
-    assert out[1][3]["promotions"] > 0, out[1][3]          # the scenario does exercise the fallback
+    if cone == "elliptic" or solver == "Newton":
+        assert out[1][3]["promotions"] > 0, out[1][3]      # the scenario does exercise the fallback
+    # (PGS with pyramidal cones: the softer grasp stays below the promotion thresholds; the comparison is then the
+    #  compact kernel against the large one on the same envs)
     assert out[2][3]["promotions"] == 0 and out[2][3]["reruns"] == 0
     assert np.array_equal(out[1][0], out[2][0]) and np.array_equal(out[1][1], out[2][1])
     assert np.array_equal(out[1][2], out[2][2])
