@@ -40,6 +40,7 @@ extern "C" {
 #define MRE_NV 39
 #define MRE_NU 8       /* 7 arm motors + fingers_actuator */
 #define MRE_NQ_PAD 44  /* row stride of qpos arrays */
+#define MRE_TRACE_W 48 /* row of the parity trace (mre_set_trace) */
 #define MRE_NV_PAD 40  /* row stride of qvel / qacc arrays */
 #define MRE_MAX_PROPS 4
 
@@ -159,7 +160,9 @@ int mre_step(mre_env*, int nsubsteps, unsigned flags);
  * control_steps physics steps per tick (BASELINE config 2: random actions). */
 int mre_rollout(mre_env*, const float* ctrl_seq, int nticks, int control_steps, unsigned flags);
 /* optional trajectory capture for parity tests: qpos of the first `nenv` envs
- * after every physics step -> out[step][nenv][MRE_NQ_PAD] (device or host).
+ * after every physics step -> out[step][nenv][MRE_TRACE_W] (device): columns 0..42 qpos, 43 the constraint census
+ * the step's solve saw (active contacts + 64 * bit mask of the joints at a limit), 44 a 22-bit hash of the geom pairs
+ * those contacts belong to (a contact that opens while another closes leaves the count unchanged), 45..47 zero.
  * Pass NULL to disable. Applies to subsequent mre_step / mre_rollout / mre_run_controller. */
 int mre_set_trace(mre_env*, float* out, int nenv, int max_steps);
 

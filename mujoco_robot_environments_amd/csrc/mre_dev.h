@@ -15,6 +15,7 @@ constexpr int NV = 39;
 constexpr int NRV = 15;    // robot dofs (ids 0..14), cube p owns dofs 15+6p..
 constexpr int NQ = 43;
 constexpr int NQP = 44;    // padded qpos row
+constexpr int TRACE_W = 48; // row of the parity trace: qpos[43], constraint census, contact-set hash, pad (MRE_TRACE_W)
 constexpr int NVP = 40;    // padded qvel row
 constexpr int NU = 8;
 constexpr int QFINE = 32;  // row of low-order state words: robot joint angles [0:15], velocities [16:31] (StepArgs::qfine)
@@ -172,7 +173,7 @@ struct StepArgs {
   uint32_t* status;          // [N]
   int* nstep;                // [N] or null: physics steps taken since the last reset (physics.data.time / timestep)
   int* stats;                // [N][4]
-  float* trace;              // [max_steps][trace_nenv][NQP] or null
+  float* trace;              // [max_steps][trace_nenv][TRACE_W] or null
   int trace_nenv, trace_max, trace_base;
   const uint8_t* env_mask;   // [N] or null: envs with 0 are skipped by this launch
   const int* env_order;      // [N] or null: workgroup b steps env env_order[b] (heavy-first dispatch)

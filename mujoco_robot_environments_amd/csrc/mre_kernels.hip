@@ -1410,16 +1410,27 @@ MRE_DEV void step_body(const StepArgs& a, Sm& s) {
       settled = mv < 1e-3f && ma < 1e-2f && step + 1 > a.min_settle_steps;
     }
     if (a.trace != nullptr && env < a.trace_nenv && (a.trace_base + step) < a.trace_max) {
-      // the pad element of the row carries the step's constraint census (an integer < 2^24, exact
+      // column 43 of the row carries the step's constraint census (an integer < 2^24, exact
       // in fp32): active contacts + 64 * (bit b - 1 set: the joint of robot body b is at a limit)
-      if (l < NQP) {
+      if (l < TRACE_W) {
         float v = l < NQ ? s.qpos[l] : 0.f;
         if (l == NQ && constrained) {
           int mask = 0;
           for (int k = 0; k < s.nl; k++) mask |= 1 << ((s.lim_info[k] & 0xFF) - 1);
           v = (float)(s.ncon + 64 * mask);
         }
-        a.trace[((size_t)(a.trace_base + step) * a.trace_nenv + env) * NQP + l] = v;
+        if (l == NQ + 1 && constrained) {
+          // which pairs the active contacts belong to (22 bits: sum of squared pair keys; a contact that opens
+          // while another one closes leaves the count above unchanged)
+          unsigned h = 0u;
+          for (int c = 0; c < s.ncon; c++) {
+            const int pr = s.con_pair[c];
+            const unsigned key = (unsigned)(M->pair_g1[pr] * 32 + M->pair_g2[pr] + 1);
+            h = (h + key * key) & 0x3FFFFFu;
+          }
+          v = (float)h;
+        }
+        a.trace[((size_t)(a.trace_base + step) * a.trace_nenv + env) * TRACE_W + l] = v;
       }
     }
     if (settled) break;

@@ -18,6 +18,7 @@ _HEADERS = ["mre_dev.h", "mre_math.h", "mre_collide.h", "mre_solver.h", "mre_new
 _LIB: Optional[C.CDLL] = None
 
 MRE_NQ, MRE_NV, MRE_NU, MRE_NQ_PAD, MRE_NV_PAD, MRE_MAX_PROPS = 43, 39, 8, 44, 40, 4
+MRE_TRACE_W = 48   # row of the parity trace (mre_set_trace)
 
 EXPORTS = [
     "mre_create", "mre_destroy", "mre_last_error", "mre_num_envs", "mre_stream", "mre_sync",

@@ -19,7 +19,7 @@ import numpy as np
 import torch
 
 from . import lib as _lib
-from .lib import MRE_NQ, MRE_NQ_PAD, MRE_NU, MRE_NV, MRE_NV_PAD, MRE_MAX_PROPS, check
+from .lib import MRE_NQ, MRE_NQ_PAD, MRE_NU, MRE_NV, MRE_NV_PAD, MRE_MAX_PROPS, MRE_TRACE_W, check
 from .model import compile as _compile
 
 FLAG_NO_CONSTRAINTS = 1
@@ -251,7 +251,7 @@ class BatchedPhysics:
             self._trace = None
             check(_lib.lib().mre_set_trace(self._h, None, 0, 0), "mre_set_trace")
             return None
-        self._trace = torch.zeros((max_steps, nenv, MRE_NQ_PAD), dtype=torch.float32,
+        self._trace = torch.zeros((max_steps, nenv, MRE_TRACE_W), dtype=torch.float32,
                                   device=self.device)
         self._after_torch()  # the zero fill runs on torch's stream
         check(_lib.lib().mre_set_trace(self._h, self._trace.data_ptr(), nenv, max_steps),

@@ -412,6 +412,15 @@ double mro_solver_cost(const mro_data* d) { return d->solver_cost; }
 int mro_solver_iters(const mro_data* d) { return d->solver_iters; }
 int mro_ncon(const mro_data* d) { return d->ncon; }
 int mro_nefc(const mro_data* d) { return d->nefc; }
+int mro_contact_set_hash(const mro_data* d) {   /* 22 bits: which pairs the active contacts belong to (device: trace column 44) */
+  unsigned h = 0;
+  for (int c = 0; c < d->ncon; c++) {
+    if (d->contact[c].efc_address < 0) continue;
+    unsigned key = (unsigned)(d->contact[c].geom1 * 32 + d->contact[c].geom2 + 1);
+    h = (h + key * key) & 0x3FFFFFu;
+  }
+  return (int)h;
+}
 int mro_ncon_active(const mro_data* d) {   /* contacts with constraint rows (three, or four with pyramidal cones) */
   int n = 0;
   for (int c = 0; c < d->ncon; c++) n += d->contact[c].efc_address >= 0;

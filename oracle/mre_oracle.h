@@ -83,7 +83,8 @@ double mro_solver_cost(const mro_data*);  /* Newton: primal cost at exit */
 double* mro_get(mro_data*, const char* name, int* n);
 int mro_ncon(const mro_data*);
 int mro_nefc(const mro_data*);
-int mro_ncon_active(const mro_data*);   /* contacts with constraint rows */
+int mro_ncon_active(const mro_data*);
+int mro_contact_set_hash(const mro_data*);   /* contacts with constraint rows */
 int mro_nl(const mro_data*);   /* active joint-limit rows */
 int mro_limit_mask(const mro_data*);  /* bit b - 1: the hinge of body b has an active limit row */
 /* contact i: out[0:3]=pos, [3:12]=frame, [12]=dist, [13]=geom1, [14]=geom2 */

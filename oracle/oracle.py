@@ -66,6 +66,7 @@ def lib() -> C.CDLL:
         L.mro_ncon.argtypes = [C.c_void_p]
         L.mro_nefc.argtypes = [C.c_void_p]
         L.mro_ncon_active.argtypes = [C.c_void_p]
+        L.mro_contact_set_hash.argtypes = [C.c_void_p]
         L.mro_nl.argtypes = [C.c_void_p]
         L.mro_limit_mask.argtypes = [C.c_void_p]
         L.mro_contact.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double)]
@@ -191,6 +192,11 @@ class Env:
         """Constraint census of the current position: active contacts + 64 * (bit b - 1: the hinge
         of body b has an active limit row)."""
         return lib().mro_ncon_active(self.ptr) + 64 * lib().mro_limit_mask(self.ptr)
+
+    @property
+    def contact_set_hash(self) -> int:
+        """22-bit hash of the geom pairs of the active contacts (the device traces the same number)."""
+        return lib().mro_contact_set_hash(self.ptr)
 
     @property
     def solver_iters(self):

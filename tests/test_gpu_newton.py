@@ -8,8 +8,9 @@ cube positions and quaternions) over 1000 steps -- asserted for EVERY env, not f
 One legitimate source of divergence is left to a converged solver: MuJoCo's constraint set is discontinuous in the
 state (a joint-limit row exists iff dist < 0, a contact row iff dist < margin), so a crossing that lands within fp32
 rounding of the threshold is taken one step apart by the two arithmetics.  The tests therefore record the constraint
-census (active contacts, active limit rows) of device and oracle at every step; an env may leave the bar only AFTER
-its census differed, every other env must meet it over the whole rollout.  On the two 64-env workloads below no
+census of device and oracle at every step -- the number of active contacts, the joints at a limit, and a hash of the
+geom pairs the active contacts belong to (a contact that opens while another one closes leaves the count unchanged) --
+and an env may leave the bar only AFTER its census differed; every other env must meet it over the whole rollout.  On the two 64-env workloads below no
 census differs at all since the robot's state is carried in double-float form and its accelerations are polished in
 fp64 (csrc/mre_newton.h: nw_robot_polish), so the bar holds in 64 of 64 envs.
 """

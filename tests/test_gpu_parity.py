@@ -30,7 +30,8 @@ def _rollout_both(compiled_model, oracle_model, N, T, flags, scale, seed=0, no_c
                   control_steps=5, z_extra=0.0, gravity_comp=False, yaw=False, solver=None, census=False,
                   fp32_state=False):
     """census=True also returns, per step and env, the constraint census the solve of that step saw
-    (active contacts + 64 * bit mask of the joints at a limit), device and oracle.
+    (active contacts + 64 * bit mask of the joints at a limit, and in the high word a 22-bit hash of the geom pairs
+    those contacts belong to), device and oracle.
     fp32_state=True also returns the qpos trace of a SECOND fp64 oracle run whose state (qpos, qvel,
     warm start) is rounded to float32 after every step -- all arithmetic still fp64: the part of the
     device-vs-oracle gap that any implementation holding its state in fp32 has."""
@@ -71,7 +72,7 @@ def _rollout_both(compiled_model, oracle_model, N, T, flags, scale, seed=0, no_c
     phys.sync()
     tr = trace.cpu().numpy()
     gq = tr[:, :, :43]
-    gcen = tr[:, :, 43].astype(np.int64)
+    gcen = tr[:, :, 43].astype(np.int64) + (tr[:, :, 44].astype(np.int64) << 32)
     oq = np.zeros_like(gq, dtype=np.float64)
     ocen = np.zeros(gq.shape[:2], np.int64)
     acts32 = acts.astype(np.float32).astype(np.float64)  # the device sees fp32 controls
@@ -79,7 +80,7 @@ def _rollout_both(compiled_model, oracle_model, N, T, flags, scale, seed=0, no_c
         for t in range(T):
             e.arr("ctrl")[:] = acts32[t, i]
             for k in range(control_steps):
-                ocen[t * control_steps + k, i] = e.census   # the rows the coming solve will see
+                ocen[t * control_steps + k, i] = e.census + (e.contact_set_hash << 32)   # the rows the coming solve will see
                 e.step(1)
                 oq[t * control_steps + k, i] = e.arr("qpos")[:43]
     if fp32_state:
