@@ -134,6 +134,28 @@ def test_newton_reaches_the_optimum_of_converged_pgs_grasp(compiled_model, oracl
     assert dq.max() < 1e-6
 
 
+def test_pyramidal_cones_primal_and_dual_solver_agree(compiled_model):
+    """Pyramidal cones (MuJoCo's default; four one-sided edge rows per contact with R = 2 mu^2 R0): Newton minimises
+    the primal cost over qacc, PGS the dual over the edge forces.  Run to convergence both reach the same
+    accelerations -- cubes dropped onto the table and one stacked on another, step by step -- which ties the
+    regulariser scaling, the edge Jacobians and the one-sided cost of the two implementations to each other."""
+    from mujoco_robot_environments_amd.model import compile as MC
+    from oracle import oracle as O
+    A = dict(compiled_model[0])
+    A["opt_cone"] = np.zeros(1, np.int32)
+    om = O.Model(MC.to_blob(A))
+    a, b = _pair(om, 3, z_extra=0.002)
+    for e in (a, b):
+        q = e.arr("qpos")
+        q[22:25] = q[15:18] + [0.004, 0.003, 0.0335]   # cube 1 dropped onto cube 0, slightly offset
+        e.forward()
+    worst = _step_both(a, b, 150)
+    dq = np.abs(a.arr("qpos") - b.arr("qpos")).max()
+    assert a.nefc - 7 - a.nl >= 16 and (a.nefc - 7 - a.nl) % 4 == 0   # edge rows, four per contact
+    print("pyramidal: max |dqacc|", worst, "|dqpos|", dq, "rows", a.nefc)
+    assert worst < 1e-4 and dq < 1e-6
+
+
 def test_newton_iteration_counts(oracle_model):
     """Warm-started Newton needs a handful of iterations per step (MuJoCo's typical 1-3); the PGS the
     north_star prescribes runs into its 100-sweep cap on the same steps."""
