@@ -1,6 +1,6 @@
 """Error growth of ONE env of a parity rollout (GPU diagnostic): per 25 steps the max |dq| of arm / fingers / cubes and
 the constraint census (contacts + 64 * limit mask) of device and oracle.
-    python tests/diagnostics/env_trace.py bench|gentle ENV [ENV ...]"""
+    python tests/diagnostics/env_trace.py bench|gentle ENV [ENV ...]      (MRE_TRACE_SOLVER=PGS: the PGS path)"""
 import os
 import sys
 
@@ -20,7 +20,7 @@ def main():
     om = O.Model(blob)
     kw = dict(scale=1.0, seed=5) if law == "bench" else dict(scale=0.1, seed=11, gravity_comp=True)
     gq, oq, nprops, phys, gcen, ocen = _rollout_both((A, blob), om, N=64, T=200, flags=0, z_extra=0.0005, yaw=True,
-                                                     solver="Newton", census=True, **kw)
+                                                     solver=os.environ.get("MRE_TRACE_SOLVER", "Newton"), census=True, **kw)
     err = np.abs(gq - oq)
     cnt, con = phys.contacts()
     names = A["_names"]["geoms"]
@@ -33,7 +33,7 @@ def main():
             sl = slice(t, t + 25)
             print(f"  steps {t:4d}-{t + 24:4d}  arm {err[sl, i, :7].max():.2e}  fingers {err[sl, i, 7:15].max():.2e} "
                   f"(dof {7 + int(err[sl, i, 7:15].max(axis=0).argmax())})  cubes {err[sl, i, 15:n].max():.2e}  census dev "
-                  f"{sorted(set(gcen[sl, i].tolist()))} oracle {sorted(set(ocen[sl, i].tolist()))}  q_fingers "
+                  f"{sorted(set((gcen[sl, i] & 0xFFFFFFFF).tolist()))} oracle {sorted(set((ocen[sl, i] & 0xFFFFFFFF).tolist()))}  q_fingers "
                   f"{np.round(oq[t, i, 7:15], 3).tolist()}")
 
 
