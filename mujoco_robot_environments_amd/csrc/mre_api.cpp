@@ -372,7 +372,8 @@ static int launch_step(mre_env* e, const StepArgs& a, bool settle = false, bool 
       for (size_t left = ng; left > 0;) {
         size_t pick = ng;
         for (size_t g = 0; g < ng && pick == ng; g++)
-          if (!done[g] && (e->groups[g].nout < 2 || hipEventQuery(e->groups[g].out[e->groups[g].head].ev_info) == hipSuccess)) pick = g;
+          if (!done[g] && (e->groups[g].nout <= (a.nsteps <= 50 ? 1 : 0) ||   // (launch_group's `keep`: nothing to wait for)
+                           hipEventQuery(e->groups[g].out[e->groups[g].head].ev_info) == hipSuccess)) pick = g;
         (void)hipGetLastError();   // (hipErrorNotReady of a query is not an error)
         if (pick == ng) {          // none ready: wait for the first outstanding one
           for (size_t g = 0; g < ng && pick == ng; g++) if (!done[g]) pick = g;
