@@ -964,7 +964,9 @@ static void make_constraint(const mro_model* m, mro_data* d) {
    * is cut at the first contact that would exceed the row / robot-row / cube-cube capacities. */
   d->overflow = 0;
   {
-    int nact = 0, rrows = d->nefc, npp = 0, stop = 0;
+    /* (the capacities are the DEVICE's, which keeps three rows per contact under either cone: dev_rows / rrows count
+     *  those, the MRO_MAXEFC check the rows built here) */
+    int nact = 0, rrows = d->nefc, dev_rows = d->nefc, npp = 0, stop = 0;
     for (int c = 0; c < d->ncon; c++) {
       mro_contact_t* con = &d->contact[c];
       con->efc_address = -1;
@@ -973,12 +975,13 @@ static void make_constraint(const mro_model* m, mro_data* d) {
       int rob = (con->body1 > 0 && m->body_propid[con->body1] < 0) || (con->body2 > 0 && m->body_propid[con->body2] < 0);
       int two = m->body_propid[con->body1] >= 0 && m->body_propid[con->body2] >= 0;
       int nrow = m->cone == 0 ? 4 : 3;
-      if ((d->nefc_cap > 0 && d->nefc + nrow > d->nefc_cap) || (d->nrrow_cap > 0 && rob && rrows + nrow > d->nrrow_cap) ||
+      if ((d->nefc_cap > 0 && dev_rows + 3 > d->nefc_cap) || (d->nrrow_cap > 0 && rob && rrows + 3 > d->nrrow_cap) ||
           (d->npp_cap > 0 && two && npp >= d->npp_cap) || d->nefc + nrow > MRO_MAXEFC) {
         d->overflow = 1; stop = 1; continue;
       }
       nact++;
-      if (rob) rrows += nrow;
+      dev_rows += 3;
+      if (rob) rrows += 3;
       if (two) npp++;
       jac_point(m, d, con->body1, con->pos, jp1, NULL);
       jac_point(m, d, con->body2, con->pos, jp2, NULL);
