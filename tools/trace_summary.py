@@ -1,0 +1,50 @@
+"""What bounds a bench tick: per env group (= HIP stream) the launch durations and the gaps between consecutive
+launches, and how many of the groups' launches are in flight at a time -- from a rocprofv3 kernel trace.
+
+  rocprofv3 --kernel-trace --output-format csv -d gpurun_out/ktrace -- python bench.py --solver Newton --no-cpu-baseline
+  python tools/trace_summary.py gpurun_out/ktrace k_step_newton [warmup_launches_per_group=20]
+
+A launch "starts" when its first workgroup gets a slot: with every slot of the GPU taken, the gap between two launches
+of one group is the wait for a slot, not host latency (the host enqueues a group's next launch before the running one
+has ended: csrc/mre_api.cpp, launch_group)."""
+import collections
+import csv
+import glob
+import os
+import sys
+
+import numpy as np
+
+d, kern = sys.argv[1], sys.argv[2]
+warm = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+f = sorted(glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True))[0]
+rows = list(csv.DictReader(open(f)))
+by = collections.defaultdict(list)
+for r in rows:
+    if r["Kernel_Name"].startswith("mre::" + kern + "("):
+        by[r["Stream_Id"]].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+for k in by:
+    by[k] = sorted(by[k])[warm:]
+t0 = min(s for v in by.values() for s, e in v)
+t1 = max(e for v in by.values() for s, e in v)
+n = min(len(v) for v in by.values())
+print(f"{kern}: {len(by)} streams x {n} timed launches; span {(t1 - t0) / 1e6:.1f} ms = {(t1 - t0) / 1e6 / n:.3f} ms per tick")
+for st, v in sorted(by.items()):
+    dur = np.array([e - s for s, e in v]) / 1e3
+    gap = np.array([v[i + 1][0] - v[i][1] for i in range(len(v) - 1)]) / 1e3
+    print(f"  stream {st}: launch us mean {dur.mean():.0f} p10 {np.percentile(dur, 10):.0f} p90 {np.percentile(dur, 90):.0f} | "
+          f"end -> next start us mean {gap.mean():.0f} median {np.median(gap):.0f} p90 {np.percentile(gap, 90):.0f}")
+ev = []
+for v in by.values():
+    for s, e in v:
+        ev += [(s, 1), (e, -1)]
+ev.sort()
+cur, last, acc = 0, ev[0][0], collections.Counter()
+for t, dl in ev:
+    acc[cur] += t - last
+    last = t
+    cur += dl
+tot = sum(acc.values())
+print("  launches in flight (share of the span):", {k: round(v / tot, 3) for k, v in sorted(acc.items())})
+others = collections.Counter(r["Kernel_Name"].split("(")[0] for r in rows if not r["Kernel_Name"].startswith("mre::" + kern + "("))
+print("  other kernels in the trace:", dict(others.most_common(6)))
