@@ -98,6 +98,30 @@ def test_newton_bench_action_law_1000_steps(compiled_model, oracle_model):
     assert len(under) >= N - 4                             # (census switches: none measured; a few would be legitimate)
 
 
+@pytest.mark.parametrize("solver", ["Newton", "PGS"])
+def test_config0_single_env_four_props_1000_random_action_steps(compiled_model, oracle_model, solver):
+    """BASELINE.json configs[0] -- the reference's own CPU-runnable case: ONE RearrangementEnv,
+    four props (the worst case), 1000 env-steps, the full-range action law re-drawn every 5 steps -- here as a batch of
+    one on the device against the oracle, three seeds.  Newton: every run whose census never differed holds the bar
+    on all 43 coordinates; PGS: arm and cubes do."""
+    held = 0
+    for seed in (1, 2, 3):
+        gq, oq, nprops, phys, gcen, ocen = _rollout_both(compiled_model, oracle_model, N=1, T=200, flags=0, scale=1.0,
+                                                         seed=seed, z_extra=0.0005, yaw=True, solver=solver, census=True,
+                                                         nprops_fixed=4)
+        assert int(nprops[0]) == 4 and (phys.status() == 0).all() and np.isfinite(gq).all()
+        under, switched, unexplained, cmax = _divergence_report(f"configs[0] {solver} seed {seed}", gq, oq, nprops, gcen, ocen)
+        err = np.abs(gq - oq)
+        if solver == "Newton":
+            assert not unexplained, unexplained
+            assert cmax < TOL
+        elif not switched:
+            assert err[:, 0, :7].max() < TOL and err[:, 0, 15:].max() < TOL, (err[:, 0, :7].max(), err[:, 0, 15:].max())
+        held += len(under)
+        phys.close()
+    assert held >= 2
+
+
 def test_newton_run_controller_parity(compiled_model, oracle_model):
     """RobotArm.run_controller (models/robot_arm.py:61-94) with the Newton solver: in-kernel OSC + MinMax,
     16 envs x 400 ticks (the 2 s of a scripted phase), half of them towards a reachable pre-pick pose, half towards a

@@ -28,7 +28,7 @@ def _oracle_envs(oracle_model, nprops, sizes):
 
 def _rollout_both(compiled_model, oracle_model, N, T, flags, scale, seed=0, no_constraints=False,
                   control_steps=5, z_extra=0.0, gravity_comp=False, yaw=False, solver=None, census=False,
-                  fp32_state=False):
+                  fp32_state=False, nprops_fixed=None):
     """census=True also returns, per step and env, the constraint census the solve of that step saw
     (active contacts + 64 * bit mask of the joints at a limit, and in the high word a 22-bit hash of the geom pairs
     those contacts belong to), device and oracle.
@@ -40,6 +40,8 @@ def _rollout_both(compiled_model, oracle_model, N, T, flags, scale, seed=0, no_c
     A, _ = compiled_model
     ids = np.arange(N)
     nprops, sizes = rng.prop_params(seed, ids)
+    if nprops_fixed is not None:
+        nprops = np.full(N, nprops_fixed, nprops.dtype)
     acts = rng.random_actions(seed, ids, np.arange(T), scale=scale)
     # gravity compensation offset keeps the arm in its workspace for the gentle variant
     envs = _oracle_envs(oracle_model, nprops, sizes)
