@@ -758,6 +758,8 @@ MRE_DEV void solve_constraints_impl(ModelP M, Sm& s, int l) {
       s.frc[i] = f0; s.frc[i + 1] = f1; s.frc[i + 2] = f2;
     }
   }
+  // (elliptic cones: pyr_f carries the low-order words of the forces of robot contacts, see the block step)
+  if (!pyr) for (int i = l; i < 4 * s.ncon; i += 64) s.pyr_f[i] = 0.f;
   MRE_SYNC();
   // ---- a = M^-1 J' f, w = J' f for the warm start (lane = dof in the solver layout)
   float a = 0.f, w = 0.f;
@@ -811,7 +813,8 @@ MRE_DEV void solve_constraints_impl(ModelP M, Sm& s, int l) {
   // body-frame arrays and region R1, which nothing reads between the controller and the next
   // position stage.  Entry (step, island):
   //   x = offset of the island's first Jacobian row | offset of the block record << 16
-  //   y = row0 | nrows << 8 | on << 10 | contact << 11 | primary << 12 | partner lane << 13 | coupled << 19
+  //   y = row0 | nrows << 8 | on << 10 | contact << 11 | primary << 12 | partner lane << 13 | coupled << 19 |
+  //       robot contact << 20
   static_assert(offsetof(Sm, xpos) % 8 == 0 &&
                 offsetof(Sm, cdof) - offsetof(Sm, xpos) >= sizeof(uint2) * (TAB_OFF + 1) + sizeof(float) * TAB_ZEROS,
                 "operand table must fit in the body-frame arrays + region R1");
@@ -841,7 +844,8 @@ MRE_DEV void solve_constraints_impl(ModelP M, Sm& s, int l) {
     uint2 ent;
     ent.x = joff | (roff << 16);
     ent.y = (unsigned)row0 | ((unsigned)nr << 8) | ((unsigned)on << 10) | ((unsigned)is3 << 11) |
-            ((unsigned)(on && is == bk.primary) << 12) | ((unsigned)partner << 13) | ((unsigned)coupled << 19);
+            ((unsigned)(on && is == bk.primary) << 12) | ((unsigned)partner << 13) | ((unsigned)coupled << 19) |
+            ((unsigned)(is3 && rs != BLK_NONE) << 20);   // bit 20: a contact with a robot part (fp64 block update)
     tab[e] = ent;
   }
   if (l == 63) {
@@ -928,6 +932,8 @@ MRE_DEV void solve_constraints_impl(ModelP M, Sm& s, int l) {
         if ((w1 & 0x80000u) != 0u) { p0 += x0; p1 += x1; p2 += x2; }
       }
       float d0 = 0.f, d1 = 0.f, d2 = 0.f, change = 0.f;
+      float nh0 = 0.f, nh1 = 0.f, nh2 = 0.f;   // the new forces as stored (set by the fp64 branch only)
+      const bool rob3 = !pyr && (w1 & 0x100000u) != 0u;
       if (on) {
         const float A00 = q2.y, A01 = q2.z, A02 = q2.w, A11 = q3.x, A12 = q3.y, A22 = q3.z;
         const float A10 = A01, A20 = A02, A21 = A12;
@@ -985,6 +991,81 @@ MRE_DEV void solve_constraints_impl(ModelP M, Sm& s, int l) {
           edge1(e0, fr); edge1(e1, -fr); edge2(e2, fr); edge2(e3, -fr);
           d0 = ((e0 + e1) + (e2 + e3)) - f0; d1 = fr * (e0 - e1) - f1; d2 = fr * (e2 - e3) - f2;
           if (leader) { fe[0] = e0; fe[1] = e1; fe[2] = e2; fe[3] = e3; }
+        } else if (rob3) {
+          // A contact that touches the robot: the same update in fp64 on the same float32 operands, the force kept
+          // as a float32 pair (frc + its low-order word in pyr_f, which elliptic cones leave free).
+          // Why: PGS stops at its sweep cap, not at the optimum, so the iterate itself has to be reproduced.  A float32
+          // force of 100 N moves in steps of 8e-6 N; through M^-1 J' that is 1e-3 rad/s^2 on the few-gram finger links
+          // the arm carries, every sweep, and no later stage can take it back.  CPU study (the fp64 oracle running
+          // this matrix-free sweep with float32 roundings, tests/diagnostics/pgs_precision_study.py): everything float32
+          // leaves the 1e-4 bar in the envs the device left it in (21, 33, 34 of the 64-env bench law); with the force,
+          // residual and update of ROBOT CONTACT rows in double -- accumulators, Jacobians, M^-1 J', diagonal blocks and
+          // every other row still float32 -- 64 of 64 stay within 3e-5 (scalar rows alone in double: no change).
+          const int cix = (row0 - nscalar) / 3;
+          float* const flo = &s.pyr_f[4 * cix];
+          const double F0 = (double)f0 + (double)flo[0], F1 = (double)f1 + (double)flo[1], F2 = (double)f2 + (double)flo[2];
+          const double a00 = A00, a01 = A01, a02 = A02, a11 = A11, a12 = A12, a22 = A22;
+          const double e0 = (double)p0 + (double)r0.x * F0 + (double)r0.y, e1 = (double)p1 + (double)r1.x * F1 + (double)r1.y,
+                       e2 = (double)p2 + (double)r2.x * F2 + (double)r2.y;
+          const double fr = q3.w;
+          double n0 = F0, n1 = F1, n2 = F2;
+          if (n0 < (double)kMinVal) {
+            n0 -= e0 / a00;
+            if (n0 < 0.0) n0 = 0.0;
+            n1 = n2 = 0.0;
+          } else {
+            const double v0 = a00 * n0 + a01 * n1 + a02 * n2, v1 = a01 * n0 + a11 * n1 + a12 * n2,
+                         v2 = a02 * n0 + a12 * n1 + a22 * n2;
+            const double denom = n0 * v0 + n1 * v1 + n2 * v2;
+            if (denom >= (double)kMinVal) {
+              double x = -(n0 * e0 + n1 * e1 + n2 * e2) / denom;
+              if (n0 + x * n0 < 0.0) x = -1.0;
+              n0 += x * F0; n1 += x * F1; n2 += x * F2;
+            }
+          }
+          const double bc0 = e1 - a11 * F1 - a12 * F2 + a01 * (n0 - F0), bc1 = e2 - a12 * F1 - a22 * F2 + a02 * (n0 - F0);
+          if (n0 < (double)kMinVal) {
+            n1 = n2 = 0.0;
+          } else {
+            // mju_QCQP2 (d0 = d1 = fr, r = n0)
+            const double b1 = bc0 * fr, b2 = bc1 * fr, fr2 = fr * fr;
+            const double Q11 = a11 * fr2, Q22 = a22 * fr2, Q12 = a12 * fr2;
+            double la = 0.0, u1 = 0.0, u2 = 0.0;
+            bool ok = true;
+            for (int it = 0; it < 20; it++) {
+              const double det = (Q11 + la) * (Q22 + la) - Q12 * Q12;
+              if (det < 1e-10) { ok = false; break; }
+              const double di = 1.0 / det;
+              const double P11 = (Q22 + la) * di, P22 = (Q11 + la) * di, P12 = -Q12 * di;
+              u1 = -P11 * b1 - P12 * b2;
+              u2 = -P12 * b1 - P22 * b2;
+              const double val = u1 * u1 + u2 * u2 - n0 * n0;
+              if (val < 1e-10) break;
+              const double deriv = -2.0 * (P11 * u1 * u1 + 2.0 * P12 * u1 * u2 + P22 * u2 * u2);
+              const double delta = -val / deriv;
+              if (delta < 1e-10) break;
+              la += delta;
+            }
+            if (!ok) { n1 = n2 = 0.0; }
+            else {
+              n1 = u1 * fr; n2 = u2 * fr;
+              if (la != 0.0) {
+                // back onto the cone: v *= sqrt(n0^2 / sum (v_i / mu)^2)
+                const double ss = u1 * u1 + u2 * u2;
+                const double sc = sqrt(n0 * n0 / (ss > (double)kMinVal ? ss : (double)kMinVal));
+                n1 *= sc; n2 *= sc;
+              }
+            }
+          }
+          double D0 = n0 - F0, D1 = n1 - F1, D2 = n2 - F2;
+          const double Ad0 = a00 * D0 + a01 * D1 + a02 * D2, Ad1 = a01 * D0 + a11 * D1 + a12 * D2,
+                       Ad2 = a02 * D0 + a12 * D1 + a22 * D2;
+          double ch = 0.5 * (D0 * Ad0 + D1 * Ad1 + D2 * Ad2) + D0 * e0 + D1 * e1 + D2 * e2;
+          if (ch > 1e-10) { D0 = D1 = D2 = 0.0; ch = 0.0; n0 = F0; n1 = F1; n2 = F2; }
+          change = (float)ch;
+          d0 = (float)D0; d1 = (float)D1; d2 = (float)D2;
+          nh0 = (float)n0; nh1 = (float)n1; nh2 = (float)n2;
+          if (leader) { flo[0] = (float)(n0 - (double)nh0); flo[1] = (float)(n1 - (double)nh1); flo[2] = (float)(n2 - (double)nh2); }
         } else {
           const float fr = q3.w;
           float n0 = f0, n1 = f1, n2 = f2;
@@ -1026,9 +1107,9 @@ MRE_DEV void solve_constraints_impl(ModelP M, Sm& s, int l) {
         }
         if ((w1 & 0x1000u) != 0u) impr -= change;
         if (leader) {
-          s.frc[row0] = f0 + d0;
-          if (h1) s.frc[row0 + 1] = f1 + d1;
-          if (h2) s.frc[row0 + 2] = f2 + d2;
+          s.frc[row0] = rob3 ? nh0 : f0 + d0;
+          if (h1) s.frc[row0 + 1] = rob3 ? nh1 : f1 + d1;
+          if (h2) s.frc[row0 + 2] = rob3 ? nh2 : f2 + d2;
         }
       }
       // a += B'd, w += J'd (cube lanes: B = J / M_dof; lanes of an idle island keep d = 0, and

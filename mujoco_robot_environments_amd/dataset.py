@@ -475,6 +475,11 @@ class BatchedEpisodeLogger:
 
     def reset(self, ts) -> None:
         self._meta = self.env.get_camera_metadata()   # calibration_metadata on the FIRST step (:88-95)
+        # an env whose reset() failed (PropPlacer found no pose: the reference's reset() raises and the loop drops the
+        # episode, transporter_network_data_generation.py:137-139) logs nothing
+        failed = getattr(self.env, "placement_failed", None)
+        if failed is not None:
+            self.mask = self.mask & ~np.asarray(failed, bool)
         for i in np.nonzero(self.mask)[0]:
             self._steps[i] = [{"observation": self._obs(ts, i), "action": None, "reward": 0.0, "discount": 0.0,
                                "is_first": True, "is_last": False, "is_terminal": False}]

@@ -151,6 +151,8 @@ class BatchedRearrangementEnv:
         self.mode = None
         self.eef_home_pose = None
         self.last_converged = np.ones(self.num_envs, bool)
+        self.placement_failed = np.zeros(self.num_envs, bool)   # reset(): PropPlacer found no pose for a cube
+        self.not_settled = np.zeros(self.num_envs, bool)
         self.failed_phase = np.full(self.num_envs, "", dtype=object)
 
     # ------------------------------------------------------------------ misc
@@ -233,12 +235,19 @@ class BatchedRearrangementEnv:
             self._physics.set_env_id_offset(int(self.env_ids[0]))
         # PropPlacer: contact-based rejection sampling, then settle with the robot frozen; every env
         # stops by itself (>= 0.3 s, <= 2 s, max|qvel| < 1e-3 and max|qacc| < 1e-2) inside the kernel
-        try:
-            self._physics.place_props(self.seed + 104729 * self._reset_count, ws.min_pose, ws.max_pose,
-                                      settle_steps=300)
-        except Exception as e:  # reference: RuntimeError(_REJECTION_SAMPLING_FAILED)
-            raise RuntimeError("Failed to find a non-colliding pose for some props") from e
+        self._physics.place_props(self.seed + 104729 * self._reset_count, ws.min_pose, ws.max_pose,
+                                  settle_steps=300)
         self._reset_count += 1
+        # mre_place_props flags the envs whose rejection sampling ran out of attempts (MRE_ST_PLACEMENT_FAILED) or whose
+        # cubes never came to rest (MRE_ST_NOT_SETTLED) and returns MRE_OK.  The reference raises
+        # RuntimeError(_REJECTION_SAMPLING_FAILED) out of reset() (prop_initializer.py:230-233) and the data-generation loop
+        # drops the episode: a batch of one raises likewise, a batch carries the mask so that sort_colours() and
+        # BatchedEpisodeLogger leave those envs out.
+        st = self._physics.status()
+        self.placement_failed = (st & 16) != 0
+        self.not_settled = (st & 8) != 0
+        if self.num_envs == 1 and self.placement_failed[0]:
+            raise RuntimeError("Failed to find a non-colliding pose for some props")
         steps = int(np.abs(self._physics.settle_steps()).max())
         cp = self._cfg.robots.arm.controller_config.controller_params
         mm = self._cfg.robots.end_effector.controller_config.controller
@@ -464,7 +473,7 @@ class BatchedRearrangementEnv:
                 return True, self.prop_pick_env(i, prop_id, info), self.prop_place_env(i, prop_id, lo, hi, info)
         return False, None, None
 
-    def sort_colours(self):
+    def sort_colours(self, peek: bool = False):
         """Batched sort_colours on the device (mre_sort_colours: selection, prop_pick and the
         prop_place rejection loop of tasks/rearrangement.py:700-751 run per env in one launch pair):
         (in_progress[N], pick_pose[N,7], place_pose[N,7]); envs with nothing left to do (or whose place
@@ -474,10 +483,11 @@ class BatchedRearrangementEnv:
             self._zones = np.concatenate([lo[..., :2], hi[..., :2]], axis=2)
         which, pick, place, att = self._physics.sort_colours(self.seed, self._place_counts, self._zones,
                                                              demo_logic.MAX_PLACE_ATTEMPTS, demo_logic.PLACE_CLEARANCE)
-        prog = (which >= 0) & (att > 0)
-        failed = (which >= 0) & (att < 0)
-        self._place_counts[prog] += 1
-        self.failed_phase[failed] = "Failed to find collision free place pose."
+        prog = (which >= 0) & (att > 0) & ~self.placement_failed
+        failed = (which >= 0) & (att < 0) & ~self.placement_failed
+        if not peek:   # (peek: only asks which envs still have a cube to move; consumes no place draws)
+            self._place_counts[prog] += 1
+            self.failed_phase[failed] = "Failed to find collision free place pose."
         idle = ~prog
         home = np.atleast_2d(self.eef_home_pose)
         pick[idle, :3] = place[idle, :3] = home[idle] if len(home) == self.num_envs else home[0]

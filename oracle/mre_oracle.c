@@ -79,6 +79,7 @@ typedef struct {
 struct mro_data {
   /* per-env model parameters */
   int nprops, freeze_robot, no_constraints, ncon_cap, nefc_cap, nrrow_cap, npp_cap, overflow;
+  int pgs_emu;   /* diagnostic (mro_set_pgs_emulation): device-like matrix-free PGS, see sol_pgs_emu */
   int round32;   /* diagnostic (mro_set_round32): intermediate arrays rounded to float32, see mre_oracle.h */
   /* diagnostic (mro_set_emulation): a device-like error on the solver's output and the device's cure for it */
   double emu_rel_arm, emu_abs_finger, emu_abs_bias;
@@ -393,6 +394,7 @@ void mro_data_free(mro_data* d) {
 }
 void mro_set_freeze_robot(mro_data* d, int f) { d->freeze_robot = f; }
 void mro_set_round32(mro_data* d, int mask) { d->round32 = mask; }
+void mro_set_pgs_emulation(mro_data* d, int mask) { d->pgs_emu = mask; }
 void mro_set_emulation(mro_data* d, double rel_arm, double abs_finger, int polish, unsigned long long seed) {
   d->emu_rel_arm = rel_arm; d->emu_abs_finger = abs_finger; d->emu_polish = polish;
   d->emu_rng = seed * 0x9E3779B97F4A7C15ull + 0x1234567ull;
@@ -1448,6 +1450,142 @@ static void sol_pgs(const mro_model* m, mro_data* d, int maxiter, double toleran
   }
 }
 
+
+/* Diagnostic (tests/diagnostics/pgs_precision_study.py; never used by a parity test's reference run):
+ * mj_solPGS as the DEVICE runs it -- matrix-free on the running accumulator a = M^-1 J' f, residual of a row
+ * = J_i . a + R_i f_i + b_i -- with float32 roundings where the device rounds (products, partial sums, forces,
+ * block arithmetic), and selected quantities kept in double to find what a float32 PGS has to carry in fp64
+ * to reproduce the fp64 iterates.  Elliptic cones only.  Mask bits:
+ *   1  on (everything float32)
+ *   2  finger dofs (7..14): accumulator a, column of B = M^-1 J', products J a in double
+ *   4  arm dofs (0..6): the same
+ *   8  rows with a robot part: force, residual and block update in double, diagonal block in double
+ *  16  B rounded to float32 even on the protected dofs
+ *  32  final accelerations re-evaluated as M^-1 J' f in double from the final forces
+ *  64  cube dofs: accumulator / B / products in double
+ * 128  rows WITHOUT a robot part: force, residual and block update in double */
+static inline double r32(double x) { return (double)(float)x; }
+static void sol_pgs_emu(const mro_model* m, mro_data* d, int maxiter, double tolerance, double* a_out) {
+  const int n = d->nefc, nv = m->nv, mask = d->pgs_emu;
+  double* f = d->efc_force;
+  static __thread double Bm[MRO_MAXEFC][MRO_MAXV];
+  double a[MRO_MAXV];
+  int prot[MRO_MAXV], rrow[MRO_MAXEFC];
+  for (int k = 0; k < nv; k++) prot[k] = (k < 7) ? (mask & 4) != 0 : (k < 15 ? (mask & 2) != 0 : (mask & 64) != 0);
+  for (int i = 0; i < n; i++) {
+    rrow[i] = 0;
+    for (int k = 0; k < 15; k++) if (d->efc_J[i][k] != 0.0) rrow[i] = 1;
+    for (int k = 0; k < nv; k++) Bm[i][k] = (prot[k] && !(mask & 16)) ? d->efc_B[i][k] : r32(d->efc_B[i][k]);
+  }
+  /* a contact's three rows share the protection of its normal row */
+  for (int i = 0; i < n; i++) if (d->efc_type[i] == EFC_CONTACT) { rrow[i + 1] = rrow[i + 2] = rrow[i]; i += 2; }
+/* 256 / 512: bit 8 applies to scalar robot rows only / to robot contact rows only; 1024: protected rows keep only the
+ * STORED force in double: residual, diagonal block and the update d = f_new - f_old are rounded to float32 */
+#define ROWP(i) (rrow[i] ? ((mask & 8) != 0 && !((mask & 256) && d->efc_type[i] == EFC_CONTACT) && !((mask & 512) && d->efc_type[i] != EFC_CONTACT)) : (mask & 128) != 0)
+  for (int i = 0; i < n; i++) if (!ROWP(i) || (mask & 4096)) f[i] = r32(f[i]);   /* 4096: every starting force is a float32 */
+  /* a = sum B f for the starting forces */
+  for (int k = 0; k < nv; k++) {
+    double s = 0;
+    for (int i = 0; i < n; i++) { double t = Bm[i][k] * f[i]; s = prot[k] ? s + t : r32(s + r32(t)); }
+    a[k] = s;
+  }
+  double scale = 1.0 / (d->meaninertia * (d->nv_active > 1 ? d->nv_active : 1));
+  d->solver_iters = 0;
+  for (int iter = 0; iter < maxiter; iter++) {
+    double improvement = 0;
+    for (int i = 0; i < n;) {
+      int type = d->efc_type[i];
+      int dim = (type == EFC_CONTACT) ? 3 : 1;
+      const int rp = ROWP(i);
+      double res[3], old[3], At[9];
+      for (int r = 0; r < dim; r++)
+        for (int c = 0; c < dim; c++) {
+          double s = 0;
+          for (int k = 0; k < nv; k++) s += d->efc_J[i + r][k] * Bm[i + c][k];
+          if (r == c) s += d->efc_R[i + r];
+          At[3 * r + c] = (rp && !(mask & (1024 | 2048))) ? s : r32(s);   /* 2048: the diagonal block is a float32 input */
+        }
+      for (int j = 0; j < dim; j++) {
+        double s64 = 0, s32 = 0;
+        for (int k = 0; k < nv; k++) {
+          if (d->efc_J[i + j][k] == 0.0) continue;
+          double t = d->efc_J[i + j][k] * a[k];
+          if (prot[k]) s64 += t; else s32 = r32(s32 + r32(t));
+        }
+        double s = s64 + s32 + d->efc_R[i + j] * f[i + j] + d->efc_b[i + j];
+        res[j] = (rp && !(mask & 1024)) ? s : r32(s);
+        old[j] = f[i + j];
+      }
+      if (dim == 1) {
+        f[i] -= res[0] / At[0];
+        if (EFC_ONESIDED(type) && f[i] < 0) f[i] = 0;
+      } else {
+        const mro_contact_t* con = &d->contact[d->efc_id[i]];
+        if (f[i] < MINVAL) {
+          f[i] -= res[0] / At[0];
+          if (f[i] < 0) f[i] = 0;
+          f[i + 1] = f[i + 2] = 0;
+        } else {
+          double v[3] = {f[i], f[i + 1], f[i + 2]}, v1[3];
+          m3mulv(v1, At, v);
+          double denom = v3dot(v, v1);
+          if (denom >= MINVAL) {
+            double x = -v3dot(v, res) / denom;
+            if (f[i] + x * v[0] < 0) x = -f[i] / v[0];
+            for (int j = 0; j < 3; j++) f[i + j] += x * v[j];
+          }
+        }
+        double Ac[4] = {At[4], At[5], At[7], At[8]}, bc[2];
+        for (int j = 0; j < 2; j++) {
+          bc[j] = res[1 + j];
+          for (int k = 0; k < 2; k++) bc[j] -= Ac[2 * j + k] * old[1 + k];
+          bc[j] += At[3 * (j + 1)] * (f[i] - old[0]);
+        }
+        if (f[i] < MINVAL) {
+          f[i + 1] = f[i + 2] = 0;
+        } else {
+          double v[2];
+          int active = qcqp2(v, Ac, bc, con->friction, f[i]);
+          if (active) {
+            double s = (v[0] / con->friction[0]) * (v[0] / con->friction[0]) +
+                       (v[1] / con->friction[1]) * (v[1] / con->friction[1]);
+            s = sqrt(f[i] * f[i] / (s > MINVAL ? s : MINVAL));
+            v[0] *= s; v[1] *= s;
+          }
+          f[i + 1] = v[0]; f[i + 2] = v[1];
+        }
+      }
+      if (!rp) for (int j = 0; j < dim; j++) f[i + j] = r32(f[i + j]);
+      double delta[3], change = 0;
+      for (int j = 0; j < dim; j++) delta[j] = f[i + j] - old[j];
+      if (rp && (mask & 1024)) for (int j = 0; j < dim; j++) { delta[j] = r32(delta[j]); f[i + j] = old[j] + delta[j]; }
+      for (int j = 0; j < dim; j++) {
+        double s = 0;
+        for (int k = 0; k < dim; k++) s += At[3 * j + k] * delta[k];
+        change += delta[j] * (0.5 * s + res[j]);
+      }
+      if (change > 1e-10) {
+        for (int j = 0; j < dim; j++) { f[i + j] = old[j]; delta[j] = 0; }
+        change = 0;
+      }
+      improvement -= change;
+      for (int j = 0; j < dim; j++) {
+        if (delta[j] == 0.0) continue;
+        for (int k = 0; k < nv; k++) {
+          if (Bm[i + j][k] == 0.0) continue;
+          double t = Bm[i + j][k] * delta[j];
+          a[k] = prot[k] ? a[k] + t : r32(a[k] + r32(t));
+        }
+      }
+      i += dim;
+    }
+    d->solver_iters = iter + 1;
+    if (improvement * scale < tolerance) break;
+  }
+#undef ROWP
+  memcpy(a_out, a, sizeof(double) * nv);
+}
+
 /* ---------------------------------------------------------------- mj_mulM */
 static void mul_m(const mro_model* m, const mro_data* d, double* res, const double* vec) {
   int nv = m->nv;
@@ -1770,7 +1908,10 @@ static void fwd_constraint(const mro_model* m, mro_data* d) {
     cost += d->efc_force[i] * (0.5 * s + d->efc_b[i]);
   }
   if (cost > 0) memset(d->efc_force, 0, sizeof(double) * n);
-  sol_pgs(m, d, maxiter, tolerance);
+  double a_emu[MRO_MAXV];
+  const int emu = (d->pgs_emu & 1) && m->cone != 0;
+  if (emu) sol_pgs_emu(m, d, maxiter, tolerance, a_emu);
+  else sol_pgs(m, d, maxiter, tolerance);
   /* dual -> primal */
   for (int k = 0; k < nv; k++) d->qfrc_constraint[k] = 0;
   for (int i = 0; i < n; i++)
@@ -1779,6 +1920,9 @@ static void fwd_constraint(const mro_model* m, mro_data* d) {
   memcpy(tmp, d->qfrc_constraint, sizeof(double) * nv);
   solve_ld(m, d->qLD, d->qLDiagInv, tmp);
   for (int k = 0; k < nv; k++) d->qacc[k] = d->qacc_smooth[k] + tmp[k];
+  if (emu && !(d->pgs_emu & 32)) {   /* the device's output: the running accumulator, J' f summed in its precision */
+    for (int k = 0; k < nv; k++) d->qacc[k] = d->qacc_smooth[k] + a_emu[k];
+  }
 }
 
 /* ----------------------------------------------- mj_implicit (implicitfast) */

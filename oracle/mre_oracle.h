@@ -57,6 +57,9 @@ void mro_set_freeze_robot(mro_data*, int freeze);
  * produced -- 1 efc_J, 2 efc_aref, 4 qM, 8 qfrc_smooth + qacc_smooth, 16 qacc + qfrc_constraint (solver output),
  * 32 the implicit integrator's acceleration, 64 efc_pos, 128 efc_R / efc_D, 256 qfrc_bias.  0 = the plain fp64 oracle. */
 void mro_set_round32(mro_data*, int mask);
+/* Diagnostic (tests/diagnostics/pgs_precision_study.py): PGS run matrix-free with float32 roundings like the
+ * device's, selected quantities kept in double (mask bits: mre_oracle.c, sol_pgs_emu).  0 = mj_solPGS on the explicit AR. */
+void mro_set_pgs_emulation(mro_data*, int mask);
 /* Diagnostic: after every solve the converged qacc gets a Gaussian error (relative `rel_arm` on the 7 arm dofs,
  * absolute `abs_finger` rad/s^2 on the 8 finger dofs) and is then, optionally, polished by exact Newton steps on a
  * block of dofs with the others held (polish 1: finger dofs, 2: all robot dofs) -- mre_oracle.c:

@@ -51,6 +51,7 @@ def lib() -> C.CDLL:
         L.mro_solver_iters.argtypes = [C.c_void_p]
         L.mro_set_no_constraints.argtypes = [C.c_void_p, C.c_int]
         L.mro_set_round32.argtypes = [C.c_void_p, C.c_int]
+        L.mro_set_pgs_emulation.argtypes = [C.c_void_p, C.c_int]
         L.mro_set_emulation.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_ulonglong]
         L.mro_set_bias_noise.argtypes = [C.c_void_p, C.c_double]
         L.mro_set_caps.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
@@ -134,6 +135,10 @@ class Env:
 
     def freeze_robot(self, flag: bool):
         lib().mro_set_freeze_robot(self.ptr, int(flag))
+
+    def pgs_emulation(self, mask: int):
+        """Diagnostic: device-like float32 PGS (mro_set_pgs_emulation)."""
+        lib().mro_set_pgs_emulation(self.ptr, int(mask))
 
     def round32(self, mask: int):
         """Diagnostic: round intermediate arrays to float32 (bit mask, oracle/mre_oracle.h)."""

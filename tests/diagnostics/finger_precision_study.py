@@ -28,7 +28,7 @@ TOL = 1e-4
 FING = slice(7, 15)
 
 
-def run(om, law, N, mode, sigma=0.0, T=200, cs=5, rmask=0, emu=None):
+def run(om, law, N, mode, sigma=0.0, T=200, cs=5, rmask=0, emu=None, solver="Newton", hook=None):
     scale, seed, gcomp = law
     ids = np.arange(N)
     nprops, sizes = rng.prop_params(seed, ids)
@@ -50,7 +50,9 @@ def run(om, law, N, mode, sigma=0.0, T=200, cs=5, rmask=0, emu=None):
 
     def one(i):
         e = O.Env(om, int(nprops[i]), sizes[i])
-        e.set_solver("Newton")
+        e.set_solver(solver)
+        if hook is not None:
+            hook(e)
         # parked slots as the device's reset leaves them are irrelevant to the active coordinates
         e.arr("qpos")[:43] = q0[i]
         e.round32(rmask)

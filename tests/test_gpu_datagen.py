@@ -297,3 +297,63 @@ print("ok")
     out = subprocess.run([sys.executable, "-c", code], env=envv, capture_output=True, text=True, timeout=900, cwd=root)
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
     assert out.stdout.strip().endswith("ok")
+
+
+def test_full_episode_256_envs_shards_match_the_loop(tmp_path):
+    """configs[4] as the reference RUNS it: the whole episode, not one pair of it -- reset, then up to
+    ``dataset.max_steps`` (config/dataset/default.yaml:3 = 10) rounds of sort_colours -> step(pick) -> step(place)
+    (transporter_network_data_generation.py:112-136), camera on, episodes of the first 16 envs written as shards.
+    256 envs, OSC gains of ``config.apply_tuned_osc_gains`` (with osc.yaml's own gains the loop does not finish: the
+    grasp holds in a third of the picks; profiles/r04a_datagen_full_refgains.log).  Asserted: the
+    number of envs still in progress never increases from pair to pair, nearly every env ends sorted, and the shards
+    hold exactly the episodes and steps the loop produced (one reset step + two steps per pair the env acted in)."""
+    from mujoco_robot_environments_amd import dataset as D
+    from mujoco_robot_environments_amd.config import apply_tuned_osc_gains
+    from mujoco_robot_environments_amd.tasks.rearrangement import BatchedRearrangementEnv, colour_separator_task_config
+    N, LOG = 256, 16
+    cfg = colour_separator_task_config()
+    apply_tuned_osc_gains(cfg)
+    env = BatchedRearrangementEnv(cfg=cfg, num_envs=N, seed=7, solver="Newton", render=True)
+    ts = env.reset()
+    assert not env.placement_failed.any()
+    cam = "overhead_camera/overhead_camera"
+    w = D.EpisodeWriter(str(tmp_path), "colour_splitter", env.overhead_camera_height, env.overhead_camera_width,
+                        max_episodes_per_file=cfg.dataset.max_episodes_per_file)
+    mask = np.arange(N) < LOG
+    log = D.BatchedEpisodeLogger(env, w, mask)
+    log.reset(ts)
+    alive = np.ones(N, bool)
+    acted = np.zeros(N, np.int64)
+    counts = []
+    for pair in range(cfg.dataset.max_steps):
+        in_progress, pick, place = env.sort_colours()
+        active = in_progress & alive
+        counts.append(int(in_progress.sum()))
+        if not active.any():
+            break
+        env.last_converged[:] = True
+        for pose in (pick, place):
+            a = {"pose": pose, "pixel_coords": env.world_2_pixel(cam, pose[:, :3]), "gripper_rot": 0.0}
+            ts = env.step(a)
+            log.step(a, ts, active)
+        acted += active
+        alive &= env.last_converged
+    log.flush()
+    info = w.close()
+    done = ~env.sort_colours(peek=True)[0]
+    print(f"full episode, {N} envs: in progress per pair {counts}; sorted at the end {int(done.sum())}/{N}; "
+          f"episodes with every phase converged {int(alive.sum())}/{N}; pairs acted per env: median {int(np.median(acted))} max {int(acted.max())}")
+    assert (env.physics.status() & 6 == 0).all() and np.isfinite(env.physics.qpos()).all()
+    assert all(b <= a for a, b in zip(counts, counts[1:])), counts          # in-progress never increases
+    assert counts[0] >= N - 8 and done.sum() >= 0.9 * N                     # the loop does its job
+    # shards = what the loop produced
+    assert sum(int(x) for x in info["splits"][0]["shardLengths"]) == LOG
+    eps = list(D.read_episodes(str(tmp_path)))
+    assert len(eps) == LOG
+    for i, e in enumerate(eps):
+        T = 1 + 2 * int(acted[i])
+        s = e["steps"]
+        assert s["reward"].shape == (T,), (i, s["reward"].shape, T)
+        assert s["is_first"].tolist() == [True] + [False] * (T - 1) and s["is_last"].tolist() == [False] * (T - 1) + [True]
+        assert s["observation"]["overhead_camera/rgb"].shape == (T, 480, 640, 3)
+    env.close()

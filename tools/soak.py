@@ -21,6 +21,8 @@ for c0 in range(0, nticks, CH):
     phys.sync()
     st = phys.status(); qp = phys.qpos(); ss = phys.solver_stats()
     z = qp[:, 15:43].reshape(N, 4, 7)[:, :, 2]
+    nprops = rng.prop_params(0, ids)[0]
+    inuse = np.arange(4)[None, :] < nprops[:, None]        # (the unused cube slots are parked far below the floor)
     print(f"tick {c0 + CH}: {time.time() - t0:.1f} s, nan {int(((st & 2) != 0).sum())}, overflow {int(((st & 4) != 0).sum())}, finite {bool(np.isfinite(qp).all())}, "
           f"mean ncon {ss[:, 0].mean():.1f} max {ss[:, 0].max()}, max nefc {ss[:, 1].max()}, iters mean {ss[:, 2].mean():.2f} max {ss[:, 2].max()}, "
-          f"cubes below the table top {int((z < 0.39).sum())}, |qvel| max {np.abs(phys.qvel()).max():.1f}, fallback {phys.fallback_stats()}", flush=True)
+          f"cubes in use below the table top {int(((z < 0.39) & inuse).sum())}, |qvel| max {np.abs(phys.qvel()).max():.1f}, fallback {phys.fallback_stats()}", flush=True)

@@ -10,8 +10,7 @@ usage: [BENCH_STEPS=200 BENCH_WARMUP=20] python tools/summarize_profiles.py TAG 
   FETCH_DIR / WRITE_DIR / SQ_DIR / FLOP_DIR : the separate --pmc passes (never combined with traces
   other than --kernel-trace); FLOP_DIR (SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F32/F64) may be "-"; MFMA_DIR (environment:
   the SQ_INSTS_VALU_MFMA_MOPS_F32 pass) is optional.
-Writes profiles/TAG_kernel_stats.csv, TAG_pmc_{fetch,write,sq}.csv (k_step rows only) and
-TAG_pmc_summary.json (per-launch means; FETCH_SIZE / WRITE_SIZE are KiB on gfx950).
+Writes profiles/TAG_kernel_stats.csv and TAG_pmc_summary.json (per-launch means; FETCH_SIZE / WRITE_SIZE are KiB on gfx950).
 """
 import csv
 import glob
@@ -77,10 +76,8 @@ def main():
         if not rows:
             print(f"no rows of {KERNEL} in {path}")
             continue
-        with open(os.path.join(out, f"{tag}_pmc_{name}{sfx}.csv"), "w", newline="") as f:
-            w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
-            w.writeheader()
-            w.writerows(rows)
+        # (the per-dispatch rows stay under gpurun_out/: only the per-launch means below are read afterwards, and two
+        #  generations of raw CSVs were 29 MB of every snapshot pushed to the GPU box)
         acc = defaultdict(list)
         dur = {}
         for r in rows:
