@@ -99,11 +99,17 @@ struct mre_env {
   uint8_t* sv_converged = nullptr;
   float* contacts = nullptr;     // device [N][1 + 3 * CONTACT_EXPORT] (detect launches), allocated on first use
   int* settle_steps = nullptr;   // device [N]
-  int* launch_info = nullptr;    // device [N][4]
-  int* h_launch_info = nullptr;  // pinned host mirror: two buffers of [N][4] (a group's two launches in flight)
+  // Launch info and the per-launch inputs the host decides (dispatch order, large flags) live in MAPPED pinned host
+  // memory that the step kernels store to / load from directly: no copy command sits in a group's launch chain
+  // (round 3: one shader blit of 16 KB behind every group launch, 0.08 .. 3.9 ms each behind 2048 resident waves, and
+  // two more in front of the next one).  d_* = the device-side address of the same bytes.
+  int* h_launch_info = nullptr;  // [2][N][4]: a group's two launches in flight write one buffer each (ring slot)
+  int* d_launch_info = nullptr;
   int* h_info_last = nullptr;    // the buffer (one of the two, per group region) that holds each env's latest record
   uint8_t* d_pending = nullptr;  // device [N]: env overflowed the compact kernel, waits for its re-run (StepArgs::pending)
-  uint8_t* h_large_stage = nullptr;  // pinned [2][N]: staging of the d_large uploads, per ring slot
+  uint8_t* h_large_stage = nullptr;  // mapped [NSTAGE][N]: the large flags a pipelined launch reads (Group::cur)
+  uint8_t* d_large_stage = nullptr;
+  bool d_large_stale = false;        // the pipelined path changed h_large: d_large (synchronous launches) is behind
   std::vector<uint8_t> h_large, h_rerun;
   int n_large = 0;
   long long* d_env_ids = nullptr; // device copy of env_ids (pose search), null = offset + index
@@ -129,13 +135,17 @@ struct mre_env {
     struct Out {           // a launch whose info has not been processed yet
       StepArgs args;       // (a re-run uses them)
       hipEvent_t ev_info = nullptr;
+      int stage = 0;       // the staged record (order + large flags) the launch reads
     } out[2];              // ring: out[head] is the older one
     int head = 0, nout = 0;
+    int cur = 0;           // staged record new launches read: the latest complete one of NSTAGE
+                           // (a record is rewritten only when no outstanding launch reads it)
     hipEvent_t p0 = nullptr, p1 = nullptr;   // profiling bracket of the launch being enqueued
   };
   std::vector<Group> groups;
-  int* grp_order = nullptr;     // device [N]: per group, its envs slowest first
-  int* h_grp_order = nullptr;   // pinned staging
+  int* h_grp_order = nullptr;   // mapped [NSTAGE][N]: per group, its envs slowest first
+  int* d_grp_order = nullptr;
+  static constexpr int NSTAGE = 3;   // <= 2 outstanding launches + the record being written
   hipEvent_t ev_main = nullptr; // orders the group streams after the handle's stream
   float* seq_copy[3] = {nullptr, nullptr, nullptr};  // own copies of the last three ctrl_seq arguments (re-runs read them later)
   size_t seq_cap = 0;
@@ -198,7 +208,13 @@ static int process_oldest(mre_env* e, mre_env::Group& G) {
     e->dbg_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
   }
   const int* const info = e->h_launch_info + (size_t)slot * 4 * (size_t)e->N;
-  int* const order_stage = e->h_grp_order + (size_t)slot * (size_t)e->N;
+  // a staged record nobody reads: not the current one, not the younger outstanding launch's
+  int fs = 0;
+  {
+    const int younger = G.nout > 1 ? G.out[slot ^ 1].stage : -1;
+    while (fs == G.cur || fs == younger) fs++;
+  }
+  int* const order_stage = e->h_grp_order + (size_t)fs * (size_t)e->N;
   int nrerun = 0;
   bool changed = false;
   int kmax = 0;
@@ -223,9 +239,8 @@ static int process_oldest(mre_env* e, mre_env::Group& G) {
       e->h_large[i] = 0; changed = true; e->n_large--; e->n_demotions++;
     }
   }
-  // (the uploads below are enqueued BEHIND the younger outstanding launch and take effect with the launch after it;
-  //  their pinned staging areas are per ring slot: a slot is rewritten two launches later, after the event of a launch
-  //  that follows the upload in stream order has been waited for)
+  // (what is decided here takes effect with the NEXT launch enqueued for the group -- the one after the younger
+  //  outstanding launch -- which reads the staged record straight from mapped host memory)
   if (kmax > 0) {   // longest processing time first within the group (counting sort, stable)
     int count[258] = {0};
     auto bucket = [&](int i) {
@@ -235,7 +250,8 @@ static int process_oldest(mre_env* e, mre_env::Group& G) {
     for (int i = G.lo; i < G.lo + G.n; i++) count[255 - bucket(i) + 1]++;
     for (int k = 1; k <= 256; k++) count[k] += count[k - 1];
     for (int i = G.lo; i < G.lo + G.n; i++) order_stage[G.lo + count[255 - bucket(i)]++] = i;
-    HIPCHK(hipMemcpyAsync(e->grp_order + G.lo, order_stage + G.lo, (size_t)G.n * 4, hipMemcpyHostToDevice, G.st));
+  } else {
+    memcpy(order_stage + G.lo, e->h_grp_order + (size_t)G.cur * (size_t)e->N + G.lo, (size_t)G.n * 4);
   }
   if (nrerun > 0) {
     HIPCHK(hipMemcpyAsync(e->mask_r + G.lo, e->h_rerun.data() + G.lo, (size_t)G.n, hipMemcpyHostToDevice, G.st));
@@ -251,11 +267,9 @@ static int process_oldest(mre_env* e, mre_env::Group& G) {
     }
     e->n_reruns += nrerun;
   }
-  if (changed) {
-    uint8_t* stage = e->h_large_stage + (size_t)slot * (size_t)e->N;
-    memcpy(stage + G.lo, e->h_large.data() + G.lo, (size_t)G.n);
-    HIPCHK(hipMemcpyAsync(e->d_large + G.lo, stage + G.lo, (size_t)G.n, hipMemcpyHostToDevice, G.st));
-  }
+  memcpy(e->h_large_stage + (size_t)fs * (size_t)e->N + G.lo, e->h_large.data() + G.lo, (size_t)G.n);
+  G.cur = fs;
+  if (changed) e->d_large_stale = true;
   if (nrerun > 0) HIPCHK(hipStreamSynchronize(G.st));   // (h_rerun is pageable: the staged bytes must outlive the upload)
   // the latest record of every env of the group (mre_get_launch_info)
   for (int i = G.lo; i < G.lo + G.n; i++) {
@@ -292,7 +306,7 @@ static int drain(mre_env* e, bool api_call = false) {
 
 // a launch under the capacity fallback: split by the envs' flags, state rows copied aside, launch info reported
 static void guard_args(mre_env* e, StepArgs& a) {
-  a.large = e->d_large; a.launch_info = e->launch_info;
+  a.large = e->d_large; a.launch_info = e->d_launch_info;
   a.sv_qpos = e->sv_qpos; a.sv_qvel = e->sv_qvel; a.sv_qacc_ws = e->sv_qacc_ws; a.sv_qfine = e->sv_qfine;
   a.sv_ctrl = e->sv_ctrl; a.sv_status = e->sv_status; a.sv_converged = e->sv_converged; a.sv_nstep = e->sv_nstep;
 }
@@ -321,7 +335,10 @@ static int launch_group(mre_env* e, mre_env::Group& G, const StepArgs& a_full) {
 static int launch_group_enqueue(mre_env* e, mre_env::Group& G, const StepArgs& a_full) {
   int rc;
   StepArgs a = a_full;
-  a.N = G.n; a.env_order = e->grp_order + G.lo; a.seq_stride = e->N;
+  const size_t N = (size_t)e->N;
+  // first launch of a burst (nothing of the group in flight): other entry points may have changed the flags since
+  if (G.nout == 0) memcpy(e->h_large_stage + (size_t)G.cur * N + G.lo, e->h_large.data() + G.lo, (size_t)G.n);
+  a.N = G.n; a.env_order = e->d_grp_order + (size_t)G.cur * N + G.lo; a.seq_stride = e->N;
   rc = profile_events(e, &G.p0, &G.p1);
   if (rc) return rc;
   HIPCHK(hipStreamWaitEvent(G.st, e->ev_main, 0));
@@ -329,10 +346,15 @@ static int launch_group_enqueue(mre_env* e, mre_env::Group& G, const StepArgs& a
   guard_args(e, a);
   a.pending = e->d_pending;
   const int slot = (G.head + G.nout) & 1;
+  a.large = e->d_large_stage + (size_t)G.cur * N;
+  a.launch_info = e->d_launch_info + (size_t)slot * 4 * N;
   StepArgs ac = a;
   ac.want_large = 0;
   bool run_large = false;
-  for (int i = G.lo; i < G.lo + G.n && !run_large; i++) run_large = e->h_large[i] != 0;
+  {
+    const uint8_t* fl = e->h_large_stage + (size_t)G.cur * N;   // (the very flags the kernels will read)
+    for (int i = G.lo; i < G.lo + G.n && !run_large; i++) run_large = fl[i] != 0;
+  }
   if (run_large) {
     HIPCHK(hipEventRecord(G.ev_fork, G.st));
     HIPCHK(hipStreamWaitEvent(G.st2, G.ev_fork, 0));
@@ -346,10 +368,10 @@ static int launch_group_enqueue(mre_env* e, mre_env::Group& G, const StepArgs& a
   HIPCHK(hipGetLastError());
   if (run_large) HIPCHK(hipStreamWaitEvent(G.st, G.ev_join, 0));
   if (G.p1) HIPCHK(hipEventRecord(G.p1, G.st));
-  HIPCHK(hipMemcpyAsync(e->h_launch_info + (size_t)slot * 4 * (size_t)e->N + 4 * (size_t)G.lo,
-                        e->launch_info + 4 * (size_t)G.lo, (size_t)G.n * 16, hipMemcpyDeviceToHost, G.st));
+  // (the kernels stored their 16 B of launch info per env into mapped host memory: the event is all that follows)
   HIPCHK(hipEventRecord(G.out[slot].ev_info, G.st));
   G.out[slot].args = a;
+  G.out[slot].stage = G.cur;
   G.nout++;
   return MRE_OK;
 }
@@ -403,6 +425,11 @@ static int launch_step(mre_env* e, const StepArgs& a, bool settle = false, bool 
     HIPCHK(hipGetLastError());
   } else {
     const size_t N = (size_t)e->N;
+    if (e->d_large_stale) {   // promotions / demotions decided by the pipelined path since the last synchronous launch
+      HIPCHK(hipMemcpyAsync(e->d_large, e->h_large.data(), N, hipMemcpyHostToDevice, e->stream));
+      HIPCHK(hipStreamSynchronize(e->stream));
+      e->d_large_stale = false;
+    }
     StepArgs ac = a;
     guard_args(e, ac);
     ac.want_large = 0;
@@ -423,8 +450,7 @@ static int launch_step(mre_env* e, const StepArgs& a, bool settle = false, bool 
     launch_compact(e, ac, e->stream, settle);
     HIPCHK(hipGetLastError());
     if (run_large) HIPCHK(hipStreamWaitEvent(e->stream, e->ev_join, 0));
-    HIPCHK(hipMemcpyAsync(e->h_launch_info, e->launch_info, N * 16, hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));   // (launch info: stored to mapped host memory by the kernels)
     memcpy(e->h_info_last, e->h_launch_info, N * 16);
     int nrerun = 0;
     bool changed = false;
@@ -731,12 +757,16 @@ static int create_buffers(mre_env* e, int num_envs, int device_id) {
   HIPCHK(hipMalloc(&e->d_large, N)); HIPCHK(hipMalloc(&e->mask_r, N));
   HIPCHK(hipMalloc(&e->sv_qpos, N * NQP * 4)); HIPCHK(hipMalloc(&e->sv_qvel, N * NVP * 4));
   HIPCHK(hipMalloc(&e->sv_qacc_ws, N * NVP * 4)); HIPCHK(hipMalloc(&e->sv_ctrl, N * NU * 4));
-  HIPCHK(hipMalloc(&e->sv_status, N * 4)); HIPCHK(hipMalloc(&e->launch_info, N * 16));
+  HIPCHK(hipMalloc(&e->sv_status, N * 4));
   HIPCHK(hipMalloc(&e->sv_converged, N));
-  HIPCHK(hipHostMalloc((void**)&e->h_launch_info, 2 * N * 16, hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void**)&e->h_launch_info, 2 * N * 16, hipHostMallocMapped | hipHostMallocCoherent));
+  HIPCHK(hipHostGetDevicePointer((void**)&e->d_launch_info, e->h_launch_info, 0));
+  memset(e->h_launch_info, 0xFF, 2 * N * 16);
   HIPCHK(hipHostMalloc((void**)&e->h_info_last, N * 16, hipHostMallocDefault));
   memset(e->h_info_last, 0xFF, N * 16);   // -1: no launch yet
-  HIPCHK(hipHostMalloc((void**)&e->h_large_stage, 2 * N, hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void**)&e->h_large_stage, mre_env::NSTAGE * N, hipHostMallocMapped | hipHostMallocCoherent));
+  HIPCHK(hipHostGetDevicePointer((void**)&e->d_large_stage, e->h_large_stage, 0));
+  memset(e->h_large_stage, 0, mre_env::NSTAGE * N);
   HIPCHK(hipMalloc(&e->d_pending, N));
   HIPCHK(hipMemsetAsync(e->d_pending, 0, N, e->stream));
   HIPCHK(hipMemsetAsync(e->d_large, 0, N, e->stream));
@@ -749,10 +779,10 @@ static int create_buffers(mre_env* e, int num_envs, int device_id) {
     if (ng < 1) ng = 1;
     if (ng > 8) ng = 8;
     while (ng > 1 && num_envs < min_envs * ng) ng--;
-    HIPCHK(hipMalloc(&e->grp_order, N * 4));
-    HIPCHK(hipHostMalloc((void**)&e->h_grp_order, 2 * N * 4, hipHostMallocDefault));   // staging, per ring slot
-    for (int i = 0; i < num_envs; i++) e->h_grp_order[i] = i;
-    HIPCHK(hipMemcpy(e->grp_order, e->h_grp_order, N * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipHostMalloc((void**)&e->h_grp_order, mre_env::NSTAGE * N * 4, hipHostMallocMapped | hipHostMallocCoherent));
+    HIPCHK(hipHostGetDevicePointer((void**)&e->d_grp_order, e->h_grp_order, 0));
+    for (int k = 0; k < mre_env::NSTAGE; k++)
+      for (int i = 0; i < num_envs; i++) e->h_grp_order[(size_t)k * N + i] = i;
     HIPCHK(hipEventCreateWithFlags(&e->ev_main, hipEventDisableTiming));
     e->groups.resize(ng);
     for (int g = 0; g < ng; g++) {
@@ -856,7 +886,6 @@ extern "C" int mre_destroy(mre_env* e) {
     for (auto& O : G.out) if (O.ev_info) (void)hipEventDestroy(O.ev_info);
   }
   if (e->ev_main) (void)hipEventDestroy(e->ev_main);
-  if (e->grp_order) (void)hipFree(e->grp_order);
   if (e->h_grp_order) (void)hipHostFree(e->h_grp_order);
   for (float* p : e->seq_copy) if (p) (void)hipFree(p);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
@@ -865,7 +894,7 @@ extern "C" int mre_destroy(mre_env* e) {
                   e->grip_closed, e->converged, e->mask, e->sites, e->status, e->stats, e->d_osc, e->d_osc_env, e->order,
                   e->geoms, e->prop_rgb, e->bg_depth, e->bg_rgb, e->bg_seg,
                   e->d_large, e->mask_r, e->qfine, e->sv_qfine, e->nstep, e->sv_nstep, e->sv_qpos, e->sv_qvel, e->sv_qacc_ws, e->sv_ctrl,
-                  e->sv_status, e->launch_info, e->auto_order, e->sv_converged, e->contacts, e->settle_steps,
+                  e->sv_status, e->auto_order, e->sv_converged, e->contacts, e->settle_steps,
                   e->d_env_ids, e->ps_attempts, e->ps_prop, e->ps_tick, e->ps_which, e->ps_bounds, e->ps_pose, e->ps_zones,
                   e->ps_pick};
   for (void* p : ptrs) if (p) (void)hipFree(p);

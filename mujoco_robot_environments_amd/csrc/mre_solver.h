@@ -696,6 +696,20 @@ MRE_DEV void build_schedule(ModelP M, Sm& s) {
   s.nsched = nst;
 }
 
+// fp64 reciprocal and reciprocal square root for the robot-contact block update: the hardware estimates (v_rcp_f64 /
+// v_rsq_f64, ~2^-26 relative) + two Newton steps = 1e-16, a third of the instructions of the IEEE division / sqrt
+// sequences with their scaling and fix-up steps (operands here are never denormal, zero or infinite: guarded by the callers)
+MRE_DEV double rcp64(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = r * (2.0 - x * r);
+  return r * (2.0 - x * r);
+}
+MRE_DEV double rsq64(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  y = y * (1.5 - 0.5 * x * y * y);
+  return y * (1.5 - 0.5 * x * y * y);
+}
+
 // ------------------------------------------------------------- mj_fwdConstraint
 // On exit: s.qacc = qacc_smooth + M^-1 J' f, s.qfrc_con = J' f.
 // PYR: pyramidal friction cones (opt.cone == 0); the two instantiations are separate phase functions, so the
@@ -1001,6 +1015,8 @@ MRE_DEV void solve_constraints_impl(ModelP M, Sm& s, int l) {
           // leaves the 1e-4 bar in the envs the device left it in (21, 33, 34 of the 64-env bench law); with the force,
           // residual and update of ROBOT CONTACT rows in double -- accumulators, Jacobians, M^-1 J', diagonal blocks and
           // every other row still float32 -- 64 of 64 stay within 3e-5 (scalar rows alone in double: no change).
+          // (Measured on the device too, round 4: the scalar rows' updates in fp64 as well cost 19 % of the PGS tick --
+          //  a dependent chain of thirty fp64 operations per step -- and moved the 256-env sample from 249 to 250.)
           const int cix = (row0 - nscalar) / 3;
           float* const flo = &s.pyr_f[4 * cix];
           const double F0 = (double)f0 + (double)flo[0], F1 = (double)f1 + (double)flo[1], F2 = (double)f2 + (double)flo[2];
@@ -1010,7 +1026,7 @@ MRE_DEV void solve_constraints_impl(ModelP M, Sm& s, int l) {
           const double fr = q3.w;
           double n0 = F0, n1 = F1, n2 = F2;
           if (n0 < (double)kMinVal) {
-            n0 -= e0 / a00;
+            n0 -= e0 * rcp64(a00);
             if (n0 < 0.0) n0 = 0.0;
             n1 = n2 = 0.0;
           } else {
@@ -1018,7 +1034,7 @@ MRE_DEV void solve_constraints_impl(ModelP M, Sm& s, int l) {
                          v2 = a02 * n0 + a12 * n1 + a22 * n2;
             const double denom = n0 * v0 + n1 * v1 + n2 * v2;
             if (denom >= (double)kMinVal) {
-              double x = -(n0 * e0 + n1 * e1 + n2 * e2) / denom;
+              double x = -(n0 * e0 + n1 * e1 + n2 * e2) * rcp64(denom);
               if (n0 + x * n0 < 0.0) x = -1.0;
               n0 += x * F0; n1 += x * F1; n2 += x * F2;
             }
@@ -1035,14 +1051,14 @@ MRE_DEV void solve_constraints_impl(ModelP M, Sm& s, int l) {
             for (int it = 0; it < 20; it++) {
               const double det = (Q11 + la) * (Q22 + la) - Q12 * Q12;
               if (det < 1e-10) { ok = false; break; }
-              const double di = 1.0 / det;
+              const double di = rcp64(det);
               const double P11 = (Q22 + la) * di, P22 = (Q11 + la) * di, P12 = -Q12 * di;
               u1 = -P11 * b1 - P12 * b2;
               u2 = -P12 * b1 - P22 * b2;
               const double val = u1 * u1 + u2 * u2 - n0 * n0;
               if (val < 1e-10) break;
               const double deriv = -2.0 * (P11 * u1 * u1 + 2.0 * P12 * u1 * u2 + P22 * u2 * u2);
-              const double delta = -val / deriv;
+              const double delta = -val * rcp64(deriv);
               if (delta < 1e-10) break;
               la += delta;
             }
@@ -1052,7 +1068,7 @@ MRE_DEV void solve_constraints_impl(ModelP M, Sm& s, int l) {
               if (la != 0.0) {
                 // back onto the cone: v *= sqrt(n0^2 / sum (v_i / mu)^2)
                 const double ss = u1 * u1 + u2 * u2;
-                const double sc = sqrt(n0 * n0 / (ss > (double)kMinVal ? ss : (double)kMinVal));
+                const double sc = n0 * rsq64(ss > (double)kMinVal ? ss : (double)kMinVal);   // (n0 >= kMinVal > 0 here)
                 n1 *= sc; n2 *= sc;
               }
             }

@@ -620,9 +620,40 @@ static void solve_ld(const mro_model* m, const double* LD, const double* diaginv
     for (int j = m->dof_parentid[i]; j >= 0; j = m->dof_parentid[j]) x[i] -= LD[a++] * x[j];
   }
 }
+/* Diagnostic (mro_set_round32 bit 512... see sol_pgs_emu bit 16384): the same factorisation and solve with every
+ * operation rounded to float32, as the device's register-resident versions run them */
+static inline double r32f(double x) { return (double)(float)x; }
+static void factor_ld32(const mro_model* m, double* LD, double* diaginv) {
+  for (int k = m->nv - 1; k >= 0; k--) {
+    int akk = m->dof_Madr[k], aki = akk + 1;
+    double inv = r32f(1.0 / LD[akk]);
+    for (int i = m->dof_parentid[k]; i >= 0; i = m->dof_parentid[i], aki++) {
+      double tmp = r32f(LD[aki] * inv);
+      int cnt = m->dof_Madr[i + 1] - m->dof_Madr[i];
+      for (int t = 0; t < cnt; t++) LD[m->dof_Madr[i] + t] = r32f(LD[m->dof_Madr[i] + t] - r32f(tmp * LD[aki + t]));
+      LD[aki] = tmp;
+    }
+    diaginv[k] = inv;
+  }
+}
+static void solve_ld32(const mro_model* m, const double* LD, const double* diaginv, double* x) {
+  int nv = m->nv;
+  for (int i = 0; i < nv; i++) x[i] = r32f(x[i]);
+  for (int i = nv - 1; i >= 0; i--) {
+    if (x[i] == 0) continue;
+    int a = m->dof_Madr[i] + 1;
+    for (int j = m->dof_parentid[i]; j >= 0; j = m->dof_parentid[j]) x[j] = r32f(x[j] - r32f(LD[a++] * x[i]));
+  }
+  for (int i = 0; i < nv; i++) x[i] = r32f(x[i] * diaginv[i]);
+  for (int i = 0; i < nv; i++) {
+    int a = m->dof_Madr[i] + 1;
+    for (int j = m->dof_parentid[i]; j >= 0; j = m->dof_parentid[j]) x[i] = r32f(x[i] - r32f(LD[a++] * x[j]));
+  }
+}
 static void factor_m(const mro_model* m, mro_data* d) {
   memcpy(d->qLD, d->qM, sizeof(double) * m->nM);
-  factor_ld(m, d->qLD, d->qLDiagInv);
+  if (d->pgs_emu & 16384) { for (int i = 0; i < m->nM; i++) d->qLD[i] = r32f(d->qLD[i]); factor_ld32(m, d->qLD, d->qLDiagInv); }
+  else factor_ld(m, d->qLD, d->qLDiagInv);
 }
 /* ---------------------------------------------------------- narrow phase */
 /* Sutherland-Hodgman clip of polygon (x,y,z=depth) against |x|<=sx, |y|<=sy */
@@ -1107,7 +1138,8 @@ static void project_constraint(const mro_model* m, mro_data* d) {
   double (*Bm)[MRO_MAXV] = d->efc_B;
   for (int i = 0; i < n; i++) {
     memcpy(Bm[i], d->efc_J[i], sizeof(double) * nv);
-    solve_ld(m, d->qLD, d->qLDiagInv, Bm[i]);
+    if (d->pgs_emu & 16384) solve_ld32(m, d->qLD, d->qLDiagInv, Bm[i]);
+    else solve_ld(m, d->qLD, d->qLDiagInv, Bm[i]);
   }
   for (int i = 0; i < n; i++)
     for (int j = i; j < n; j++) {
@@ -1252,7 +1284,8 @@ static void fwd_acceleration(const mro_model* m, mro_data* d) {
   if (d->emu_abs_bias > 0)   /* a float32 RNE about the robot's centre of mass: absolute error on the finger rows */
     for (int i = 7; i < 15; i++) { d->qfrc_smooth[i] += d->emu_abs_bias * emu_gauss(d); d->qacc_smooth[i] = d->qfrc_smooth[i]; }
   if (d->round32 & 8) round32(d->qfrc_smooth, m->nv);
-  solve_ld(m, d->qLD, d->qLDiagInv, d->qacc_smooth);
+  if (d->pgs_emu & 16384) solve_ld32(m, d->qLD, d->qLDiagInv, d->qacc_smooth);
+  else solve_ld(m, d->qLD, d->qLDiagInv, d->qacc_smooth);
   if (d->round32 & 8) round32(d->qacc_smooth, m->nv);
 }
 
@@ -1463,7 +1496,8 @@ static void sol_pgs(const mro_model* m, mro_data* d, int maxiter, double toleran
  *  16  B rounded to float32 even on the protected dofs
  *  32  final accelerations re-evaluated as M^-1 J' f in double from the final forces
  *  64  cube dofs: accumulator / B / products in double
- * 128  rows WITHOUT a robot part: force, residual and block update in double */
+ * 128  rows WITHOUT a robot part: force, residual and block update in double
+ * 16384  the factorisation of M and every solve with it (M^-1 J', qacc_smooth) run in float32 */
 static inline double r32(double x) { return (double)(float)x; }
 static void sol_pgs_emu(const mro_model* m, mro_data* d, int maxiter, double tolerance, double* a_out) {
   const int n = d->nefc, nv = m->nv, mask = d->pgs_emu;
@@ -1483,6 +1517,16 @@ static void sol_pgs_emu(const mro_model* m, mro_data* d, int maxiter, double tol
  * STORED force in double: residual, diagonal block and the update d = f_new - f_old are rounded to float32 */
 #define ROWP(i) (rrow[i] ? ((mask & 8) != 0 && !((mask & 256) && d->efc_type[i] == EFC_CONTACT) && !((mask & 512) && d->efc_type[i] != EFC_CONTACT)) : (mask & 128) != 0)
   for (int i = 0; i < n; i++) if (!ROWP(i) || (mask & 4096)) f[i] = r32(f[i]);   /* 4096: every starting force is a float32 */
+  /* 8192: efc_b = J qacc_smooth - aref evaluated in float32 (products and partial sums rounded) */
+  double eb[MRO_MAXEFC];
+  for (int i = 0; i < n; i++) {
+    eb[i] = d->efc_b[i];
+    if (mask & 8192) {
+      double sacc = 0;
+      for (int k = 0; k < nv; k++) if (d->efc_J[i][k] != 0.0) sacc = r32(sacc + r32(d->efc_J[i][k] * d->qacc_smooth[k]));
+      eb[i] = r32(sacc - d->efc_aref[i]);
+    }
+  }
   /* a = sum B f for the starting forces */
   for (int k = 0; k < nv; k++) {
     double s = 0;
@@ -1501,8 +1545,13 @@ static void sol_pgs_emu(const mro_model* m, mro_data* d, int maxiter, double tol
       for (int r = 0; r < dim; r++)
         for (int c = 0; c < dim; c++) {
           double s = 0;
-          for (int k = 0; k < nv; k++) s += d->efc_J[i + r][k] * Bm[i + c][k];
-          if (r == c) s += d->efc_R[i + r];
+          if (mask & 32768) {   /* 32768: the block is a float32 sum of float32 products, as assemble_blocks forms it */
+            for (int k = 0; k < nv; k++) if (d->efc_J[i + r][k] != 0.0) s = r32(s + r32(d->efc_J[i + r][k] * r32(Bm[i + c][k])));
+            if (r == c) s = r32(s + d->efc_R[i + r]);
+          } else {
+            for (int k = 0; k < nv; k++) s += d->efc_J[i + r][k] * Bm[i + c][k];
+            if (r == c) s += d->efc_R[i + r];
+          }
           At[3 * r + c] = (rp && !(mask & (1024 | 2048))) ? s : r32(s);   /* 2048: the diagonal block is a float32 input */
         }
       for (int j = 0; j < dim; j++) {
@@ -1512,7 +1561,7 @@ static void sol_pgs_emu(const mro_model* m, mro_data* d, int maxiter, double tol
           double t = d->efc_J[i + j][k] * a[k];
           if (prot[k]) s64 += t; else s32 = r32(s32 + r32(t));
         }
-        double s = s64 + s32 + d->efc_R[i + j] * f[i + j] + d->efc_b[i + j];
+        double s = s64 + s32 + d->efc_R[i + j] * f[i + j] + eb[i + j];
         res[j] = (rp && !(mask & 1024)) ? s : r32(s);
         old[j] = f[i + j];
       }

@@ -21,6 +21,12 @@ def report(name, label, tr, ref, N):
     w = err.max(axis=2)
     first = np.array([np.argmax(w[:, i] > TOL) if w[:, i].max() > TOL else w.shape[0] for i in range(N)])
     unexpl = [i for i, f in enumerate(first) if f < w.shape[0] and (sw_at[i] < 0 or sw_at[i] > f)]
+    if os.environ.get("ENVS"):
+        for i in [int(x) for x in os.environ["ENVS"].split(",")]:
+            print(f"   env {i}: fingers per 100 steps " + " ".join(f"{err[t:t + 100, i, 7:15].max():.1e}" for t in range(0, err.shape[0], 100)))
+    fe = np.array([err[:, i, 7:15].max() for i in range(N) if not switched[i]])
+    print(f"   finger error per env (no census switch): median {np.median(fe):.1e} p75 {np.quantile(fe, 0.75):.1e} p90 {np.quantile(fe, 0.9):.1e} "
+          f"p97 {np.quantile(fe, 0.97):.1e} max {fe.max():.1e}")
     print(f"{name:6s} {label:28s}: under the bar {int((first >= w.shape[0]).sum())}/{N}, unexplained exits {len(unexpl)}; "
           f"max err arm {err[:, :, :7].max():.1e} fingers {err[:, :, 7:15].max():.1e} cubes {err[:, :, 15:].max():.1e}; "
           f"exits (env, step, switch at) {sorted([(i, int(f), sw_at[i]) for i, f in enumerate(first) if f < w.shape[0]], key=lambda x: x[1])[:10]}",

@@ -269,12 +269,10 @@ def _bar_report(name, gq, oq, nprops, gcen, ocen):
 def test_long_rollout_parity_1000_steps(compiled_model, oracle_model):
     """BASELINE.json north_star bar with north_star's solver (PGS, cut at 100 sweeps): max|qpos - qpos_ref| < 1e-4
     over 1000 env-steps on ALL 43 coordinates.  64 envs, cubes resting on the table, arm under gravity compensation
-    + 10 % random torques, random gripper commands -- the workload of the Newton test
-    (tests/test_gpu_newton.py::test_newton_long_rollout_1000_steps_all_coordinates), same rules: an env may leave
-    the bar only after its constraint census differed from the oracle's.  Measured: 63 / 64 under the bar (one exit
-    after a census switch), 3.3e-5 among the rest; rounds 1-2 allowed the finger linkage 5e-2 here (measured 1.3e-2):
-    what changed is the robot's state in double-float form and the finger bias forces in fp64,
-    which the PGS builds share with the Newton ones."""
+    + 10 % random torques, random gripper commands -- the workload and the RULES of the Newton test
+    (tests/test_gpu_newton.py::test_newton_long_rollout_1000_steps_all_coordinates), verbatim: an env may leave the bar
+    only after its constraint census differed from the oracle's.  Measured (round 4): 63 / 64 under the bar, the one exit
+    after a census switch, 3.3e-5 among the rest."""
     N = 64
     gq, oq, nprops, phys, gcen, ocen = _rollout_both(compiled_model, oracle_model, N=N, T=200, flags=0, scale=0.1,
                                                      seed=11, z_extra=0.0005, gravity_comp=True, yaw=True,
@@ -290,19 +288,26 @@ def test_long_rollout_parity_1000_steps(compiled_model, oracle_model):
 def test_full_range_random_torques_stay_close(compiled_model, oracle_model):
     """BASELINE configs[1]'s own action law (tau ~ U(+-87 / +-12) N m re-drawn every tick, gripper command U(0, 255))
     with PGS over 1000 steps, 64 envs: the arm is thrown against its joint limits, onto the table and into the cubes.
-    PGS stops at its 100-sweep cap before the soft rows that close the finger four-bars have converged (by
-    construction: mean_solver_iters = 100), so where the device's float32 sweeps and the oracle's float64 sweeps stand
-    after 100 of them differs in the last bits of the finger forces -- no polish applies to an iterate that is not the
-    optimum.  Measured: 60 / 64 envs under 1e-4 on all 43 coordinates (one exit after a census switch, three finger
-    exits of 8e-4 .. 7e-3 rad without one), arm 4e-5 and cubes 1.1e-5 in the envs without a census switch; the
-    Newton path holds the bar in 64 / 64 (tests/test_gpu_newton.py)."""
+    PGS stops at its 100-sweep cap, not at the optimum (mean_solver_iters = 100), so the ITERATE has to be reproduced:
+    since round 4 the block update of every contact that touches the robot runs in fp64 on the device (force kept as a
+    float32 pair; csrc/mre_solver.h, CPU study tests/diagnostics/pgs_precision_study.py), which took this test from
+    60 / 64 with three finger exits of 8e-4 .. 7e-3 rad to 63 / 64 with ONE exit: env 34, one finger coordinate at
+    2.1 .. 2.8e-4 from step ~930 on, no census switch.  That env is a property of the oracle's own PGS trajectory, not of
+    the device: the fp64 oracle against itself amplifies a 1e-9 rad/s kick of the finger velocities at step 400 a
+    hundredfold more under PGS than the median env does (and 30 x more than under Newton), and the device's error in
+    that env grows by the same factor of ~3 per 100 steps from 3e-7 at step 500 (profiles/r04b_pgs_env34_trace.log,
+    profiles/r04b_pgs_amplification.log); the fp64 emulation of a float32 PGS with every intermediate array rounded once
+    ends at 3e-5 .. 8e-5 in the same env.  Asserted: the Newton tests' rules with room for that one env at 3x the
+    tolerance -- at most one exit without a census switch, every coordinate of every unswitched env below 3e-4 (round 3
+    accepted 5 such exits and 5e-3)."""
     N = 64
     gq, oq, nprops, phys, gcen, ocen = _rollout_both(compiled_model, oracle_model, N=N, T=200, flags=0, scale=1.0,
                                                      seed=5, z_extra=0.0005, yaw=True, solver="PGS", census=True)
     under, switched, unexplained, cmax, arm_env, grip_env, cube_clean = _bar_report("PGS bench law", gq, oq, nprops, gcen, ocen)
     assert np.isfinite(gq).all() and (phys.status() & 2 == 0).all()
-    assert len(under) >= N - 8 and len(unexplained) <= 5, (len(under), unexplained)
-    assert cmax < 5e-3                                  # (the finger exits; every other coordinate below)
+    assert len(unexplained) <= 1, unexplained
+    assert cmax < 3e-4
+    assert len(under) + len(switched) + len(unexplained) == N and len(under) >= N - 3
     assert np.median(arm_env) < 1e-5 and np.median(grip_env) < 1e-5
     assert cube_clean < 5e-5
 
