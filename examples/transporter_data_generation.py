@@ -93,7 +93,7 @@ def main():
                   f"(min {float(d.min()):.3f} m, max {float(d.max()):.3f} m) on {d.device}")
         failed_now = active & ~env.last_converged
         names, counts = np.unique(env.failed_phase[failed_now].astype(str), return_counts=True)
-        alive &= env.last_converged
+        alive &= env.last_converged | ~active   # (an idle env's no-op phases do not end an episode)
         nsim = 2 * 9000
         still = env.sort_colours(peek=True)[0]
         print(f"pair {step}: {int(in_progress.sum())} envs in progress, {int(active.sum())} of them acted; "

@@ -947,7 +947,11 @@ MRE_DEV void solve_constraints_impl(ModelP M, Sm& s, int l) {
       }
       float d0 = 0.f, d1 = 0.f, d2 = 0.f, change = 0.f;
       float nh0 = 0.f, nh1 = 0.f, nh2 = 0.f;   // the new forces as stored (set by the fp64 branch only)
+#ifdef MRE_PGS_F32   // (A/B builds, tools/build_variant.py: every block update in float32, as up to round 3)
+      const bool rob3 = false;
+#else
       const bool rob3 = !pyr && (w1 & 0x100000u) != 0u;
+#endif
       if (on) {
         const float A00 = q2.y, A01 = q2.z, A02 = q2.w, A11 = q3.x, A12 = q3.y, A22 = q3.z;
         const float A10 = A01, A20 = A02, A21 = A12;

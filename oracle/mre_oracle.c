@@ -15,6 +15,26 @@
  */
 #include "mre_oracle.h"
 
+/* FLOP counting build (flop_count.h; `make flops`): `double` is a counting class there and MRO_STAGE names the
+ * pipeline stage the counts go to.  In the plain C build MRO_STAGE is a no-op. */
+enum { FS_POSITION = 0, FS_CRB_FACTOR, FS_COLLISION, FS_MAKE_CONSTRAINT, FS_PROJECT, FS_VELOCITY, FS_ACTUATION_ACC,
+       FS_SOLVER, FS_INTEGRATE, FS_CONTROLLER, FS_OTHER, FS_COUNT };
+#ifdef MRO_COUNT_FLOPS
+extern "C" {
+__thread unsigned long long mro_flop_n[MRO_NSTAGE][2];
+__thread int mro_flop_stage = FS_OTHER;
+/* out[FS_COUNT][2]: operations counted since the last reset, per stage ([0] + - * /, [1] sqrt / trig / pow) */
+int mro_flops_read(unsigned long long* out, int reset) {
+  for (int k = 0; k < FS_COUNT; k++) { out[2 * k] = mro_flop_n[k][0]; out[2 * k + 1] = mro_flop_n[k][1]; }
+  if (reset) memset(mro_flop_n, 0, sizeof(mro_flop_n));
+  return FS_COUNT;
+}
+}
+#define MRO_STAGE(k) (mro_flop_stage = (k))
+#else
+#define MRO_STAGE(k) ((void)0)
+#endif
+
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -1153,19 +1173,26 @@ static void project_constraint(const mro_model* m, mro_data* d) {
 
 /* --------------------------------------------------------- position stage */
 static void fwd_position(const mro_model* m, mro_data* d) {
+  MRO_STAGE(FS_POSITION);
   kinematics(m, d);
   com_pos(m, d);
   tendon(m, d);
+  MRO_STAGE(FS_CRB_FACTOR);
   crb(m, d);
   if (d->round32 & 4) round32(d->qM, m->nM);
   factor_m(m, d);
+  MRO_STAGE(FS_COLLISION);
   collision(m, d);
+  MRO_STAGE(FS_MAKE_CONSTRAINT);
   make_constraint(m, d);
   if (d->round32 & 1) for (int i = 0; i < d->nefc; i++) round32(d->efc_J[i], m->nv);
   if (d->round32 & 64) round32(d->efc_pos, d->nefc);
   make_impedance(m, d);
   if (d->round32 & 128) { round32(d->efc_R, d->nefc); for (int i = 0; i < d->nefc; i++) d->efc_D[i] = 1.0 / d->efc_R[i]; }
-  project_constraint(m, d);
+  /* (AR = J M^-1 J' + R exists for the dual solvers only: mj_projectConstraint is skipped under Newton) */
+  MRO_STAGE(FS_PROJECT);
+  if ((d->solver_override >= 0 ? d->solver_override : m->solver) != 2) project_constraint(m, d);
+  MRO_STAGE(FS_OTHER);
 }
 
 /* --------------------------------------------------------- velocity stage */
@@ -2030,7 +2057,9 @@ static void integrate(const mro_model* m, mro_data* d) {
 
 static void step1(const mro_model* m, mro_data* d) {
   fwd_position(m, d);
+  MRO_STAGE(FS_VELOCITY);
   fwd_velocity(m, d);
+  MRO_STAGE(FS_OTHER);
 }
 /* Diagnostic (tests/diagnostics/finger_precision_study.py): what a float32 solver leaves behind, and the cure.
  * The converged qacc gets a relative error on the arm dofs and an absolute error on the finger dofs (Gaussian,
@@ -2106,18 +2135,25 @@ static void emulate_device_solver(const mro_model* m, mro_data* d) {
 
 void mro_set_bias_noise(mro_data* d, double abs_bias) { d->emu_abs_bias = abs_bias; if (!d->emu_rng) d->emu_rng = 0x2545F4914F6CDD1Dull; }
 static void step2(const mro_model* m, mro_data* d) {
+  MRO_STAGE(FS_ACTUATION_ACC);
   fwd_actuation(m, d);
   fwd_acceleration(m, d);
+  MRO_STAGE(FS_SOLVER);
   fwd_constraint(m, d);
+  MRO_STAGE(FS_INTEGRATE);
   if (d->emu_rel_arm > 0 || d->emu_abs_finger > 0 || d->emu_polish) emulate_device_solver(m, d);
   if (d->round32 & 16) { round32(d->qacc, m->nv); round32(d->qfrc_constraint, m->nv); }
   integrate(m, d);
+  MRO_STAGE(FS_OTHER);
 }
 void mro_forward(const mro_model* m, mro_data* d) {
   step1(m, d);
+  MRO_STAGE(FS_ACTUATION_ACC);
   fwd_actuation(m, d);
   fwd_acceleration(m, d);
+  MRO_STAGE(FS_SOLVER);
   fwd_constraint(m, d);
+  MRO_STAGE(FS_OTHER);
 }
 void mro_step(const mro_model* m, mro_data* d, int nstep) {
   for (int s = 0; s < nstep; s++) { step2(m, d); step1(m, d); }
@@ -2261,7 +2297,9 @@ int mro_run_controller(const mro_model* m, mro_data* d, const mro_osc* o, double
   int arm_converged = 0;
   for (int t = 0; t < nticks; t++) {
     double tau[7];
+    MRO_STAGE(FS_CONTROLLER);
     mro_osc_compute(m, d, o, tau);
+    MRO_STAGE(FS_OTHER);
     for (int a = 0; a < 7; a++) d->ctrl[a] = tau[a];
     d->ctrl[7] = grip_ctrl;
     mro_step(m, d, control_steps);

@@ -26,7 +26,30 @@ class OscParams(C.Structure):
                 ("target_angvel", C.c_double * 3), ("pinv_always", C.c_int)]
 
 
+FLOP_STAGES = ["position (kinematics, comPos, tendon)", "crb + factorM", "collision", "makeConstraint + impedance",
+               "projectConstraint (M^-1 J', AR: dual solvers only)", "velocity (comVel, passive, rne, reference)",
+               "actuation + acceleration", "solver", "integrate (implicitfast)", "controller (OSC)", "other"]
+
+
+def build_flops(force: bool = False) -> str:
+    """The operation-counting build of the same source (flop_count.h; loaded with MRE_ORACLE_LIB=<path>)."""
+    so = os.path.join(_HERE, "libmre_oracle_flops.so")
+    srcs = [os.path.join(_HERE, f) for f in ("mre_oracle.c", "mre_oracle.h", "flop_count.h")]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "libmre_oracle_flops.so"])
+    return so
+
+
+def flops_read(reset: bool = True) -> np.ndarray:
+    """[stage, 2] operations counted since the last reset (counting build only): column 0 = + - * /, 1 = sqrt / trig."""
+    out = (C.c_ulonglong * 64)()
+    n = lib().mro_flops_read(out, int(reset))
+    return np.array(out[:2 * n], np.float64).reshape(n, 2)
+
+
 def build(force: bool = False) -> str:
+    if os.environ.get("MRE_ORACLE_LIB"):     # (tools/count_flops.py: the counting build; no OpenMP batch entry point)
+        return os.environ["MRE_ORACLE_LIB"]
     so = os.path.join(_HERE, "libmre_oracle.so")
     srcs = [os.path.join(_HERE, f) for f in ("mre_oracle.c", "mre_oracle_batch.c", "mre_oracle.h")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
@@ -79,8 +102,11 @@ def lib() -> C.CDLL:
         L.mro_boxbox.argtypes = [C.POINTER(C.c_double)] * 6 + [C.c_double] + [C.POINTER(C.c_double)] * 3
         L.mro_cone_eval.restype = C.c_double
         L.mro_cone_eval.argtypes = [C.POINTER(C.c_double)] * 3 + [C.c_double] + [C.POINTER(C.c_double)] * 2 + [C.POINTER(C.c_int)]
-        L.mro_batch_step.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int,
-                                     C.POINTER(C.c_double), C.c_int, C.c_int]
+        if hasattr(L, "mro_batch_step"):
+            L.mro_batch_step.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int,
+                                         C.POINTER(C.c_double), C.c_int, C.c_int]
+        if hasattr(L, "mro_flops_read"):
+            L.mro_flops_read.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
         _LIB = L
     return _LIB
 

@@ -79,7 +79,11 @@ def test_push_env_matches_oracle(solver, cone):
     assert D[:125, :, :7].max() < 2e-5 and D[:125, :, 15:18].max() < (5e-6 if solver == "Newton" else 1e-4), \
         (D[:125, :, :7].max(), D[:125, :, 15:18].max())
     # envs whose tool misses the block stay there for the whole run
-    miss = qp[:, 15] < 0.3005
+    # (a miss = the block did not move at all; a tool that grazes a corner nudges it by 0.3 .. 0.8 mm and belongs to the
+    #  chaotic pushed cases below -- round 3's 0.5 mm threshold cut through the middle of those)
+    miss = qp[:, 15] < 0.3001
+    print(f"push {solver} {cone}: block x {np.round(qp[:, 15], 4).tolist()}; arm err per env {['%.1e' % v for v in D[:, :, :7].max(axis=(0, 2))]}; "
+          f"block err per env {['%.1e' % v for v in D[:, :, 15:18].max(axis=(0, 2))]}")
     assert miss.sum() >= 2 and D[:, miss][:, :, :7].max() < 2e-5
     # pushed (one hull contact steers a tumbling block): under 5e-3 over the 1.3 s; with the convergent solver
     # the worst env stays within the float32-state oracle's own worst distance to the fp64 run (x 4, + 1e-4)

@@ -17,7 +17,7 @@ rocprofv3 -L > gpurun_out/counters_$T.txt 2>&1 || true
 for CFG in "200 20" "20 5"; do
   set -- $CFG; K=$1; W=$2; X=s${K}w${W}
   for S in PGS Newton; do
-    A="--solver $S --steps $K --warmup $W --no-cpu-baseline"
+    A="--solver $S --steps $K --warmup $W --no-cpu-baseline --no-second-window"
     rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${T}_${S}_$X -- python bench.py $A > gpurun_out/bench_${T}_prof_${S}_$X.json 2>/dev/null
     head -4 $(find gpurun_out/prof_${T}_${S}_$X -name "*kernel_stats.csv" | head -1)
     rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch_${T}_${S}_$X -- python bench.py $A > /dev/null 2>&1
@@ -28,5 +28,5 @@ for CFG in "200 20" "20 5"; do
     echo "passes done: $S $X"
   done
 done
-python -c "import json; d=json.load(open('gpurun_out/bench_$T.json')); print(d['value'], d['ms_per_step'], d['health'], d['newton']['value'], d['cpu_baseline']['value'])"
-python -c "import json; d=json.load(open('gpurun_out/bench_${T}_s20w5.json')); print(d['value'], d['ms_per_step'], d['newton']['value'])"
+python -c "import json; d=json.load(open('gpurun_out/bench_$T.json')); print(d['value'], d['ms_per_step'], d['health'], d['pgs']['value'], d['default_regime']['value'], d['pgs']['default_regime']['value'], d['cpu_baseline']['value'])"
+python -c "import json; d=json.load(open('gpurun_out/bench_${T}_s20w5.json')); print(d['value'], d['ms_per_step'], d['pgs']['value'])"

@@ -42,7 +42,7 @@ def counter_rows(d):
         rows = [r for r in csv.DictReader(f) if r["Kernel_Name"].startswith(KERNEL)]
     # the first WARMUP dispatches of the kernel are the bench's untimed warm-up launches
     ids = sorted({int(r["Dispatch_Id"]) for r in rows})
-    keep = set(ids[WARMUP:]) if len(ids) > WARMUP else set(ids)
+    keep = set(ids[WARMUP:WARMUP + STEPS * GROUPS]) if len(ids) > WARMUP else set(ids)   # the timed window's launches only
     return path, [r for r in rows if int(r["Dispatch_Id"]) in keep]
 
 
