@@ -15,7 +15,7 @@ constexpr int NV = 39;
 constexpr int NRV = 15;    // robot dofs (ids 0..14), cube p owns dofs 15+6p..
 constexpr int NQ = 43;
 constexpr int NQP = 44;    // padded qpos row
-constexpr int TRACE_W = 48; // row of the parity trace: qpos[43], constraint census, contact-set hash, pad (MRE_TRACE_W)
+constexpr int TRACE_W = 48; // row of the parity trace: qpos[43], constraint census, contact-set hash, solution-state hash, pad (MRE_TRACE_W)
 constexpr int NVP = 40;    // padded qvel row
 constexpr int NU = 8;
 constexpr int QFINE = 32;  // row of low-order state words: robot joint angles [0:15], velocities [16:31] (StepArgs::qfine)

@@ -1430,6 +1430,27 @@ MRE_DEV void step_body(const StepArgs& a, Sm& s) {
           }
           v = (float)h;
         }
+        if (l == NQ + 2 && constrained && M->cone != 0) {
+          // what the step's solve left behind, per row (22-bit hash; the oracle: mro_state_hash): a limit row pushing or
+          // not, a contact open / sticking / sliding (|f_t| on the cone's boundary).  A solution that sits on one of
+          // those boundaries within rounding is as legitimate a fork of two arithmetics as a contact that closes a
+          // step apart: the parity tests count a difference here as a census switch too (elliptic cones).
+          unsigned h = 0u;
+          const int ns = 7 + s.nl;
+          for (int i = 7; i < ns; i++) h += (s.frc[i] > 0.f ? 1u : 2u) * (unsigned)((i + 1) * (i + 1));
+          for (int c = 0; c < s.ncon; c++) {
+            const int i = ns + 3 * c;
+#ifdef MRE_NEWTON
+            const float mu = s.con_fric[c];
+#else
+            const float mu = s.blkrec[8 + c][15];
+#endif
+            const float fn = s.frc[i], ft2 = s.frc[i + 1] * s.frc[i + 1] + s.frc[i + 2] * s.frc[i + 2], lim = mu * fn;
+            const unsigned z = fn <= 0.f ? 1u : (ft2 >= lim * lim * (1.f - 1e-4f) ? 3u : 2u);
+            h += z * (unsigned)((c + 3) * (c + 3));
+          }
+          v = (float)(h & 0x3FFFFFu);
+        }
         a.trace[((size_t)(a.trace_base + step) * a.trace_nenv + env) * TRACE_W + l] = v;
       }
     }

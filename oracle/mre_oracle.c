@@ -99,6 +99,7 @@ typedef struct {
 struct mro_data {
   /* per-env model parameters */
   int nprops, freeze_robot, no_constraints, ncon_cap, nefc_cap, nrrow_cap, npp_cap, overflow;
+  int state_hash; /* mro_state_hash */
   int pgs_emu;   /* diagnostic (mro_set_pgs_emulation): device-like matrix-free PGS, see sol_pgs_emu */
   int round32;   /* diagnostic (mro_set_round32): intermediate arrays rounded to float32, see mre_oracle.h */
   /* diagnostic (mro_set_emulation): a device-like error on the solver's output and the device's cure for it */
@@ -442,6 +443,29 @@ int mro_contact_set_hash(const mro_data* d) {   /* 22 bits: which pairs the acti
     h = (h + key * key) & 0x3FFFFFu;
   }
   return (int)h;
+}
+/* 22 bits: what the last solve left behind per row -- a limit row pushing (1) or not (2), a contact open (1), sticking
+ * (2) or sliding, i.e. on the cone's boundary (3) -- evaluated inside step2 right after the solve (device: trace
+ * column 45).  Elliptic cones; 0 otherwise. */
+int mro_state_hash(const mro_data* d) { return d->state_hash; }
+static int state_hash_eval(const mro_model* m, const mro_data* d) {
+  if (m->cone == 0 || d->no_constraints) return 0;
+  unsigned h = 0;
+  int ci = 0;
+  for (int i = 0; i < d->nefc; i++) {
+    if (d->efc_type[i] == EFC_CONTACT) {
+      const mro_contact_t* con = &d->contact[d->efc_id[i]];
+      double fn = d->efc_force[i], ft2 = d->efc_force[i + 1] * d->efc_force[i + 1] + d->efc_force[i + 2] * d->efc_force[i + 2];
+      double lim = con->friction[0] * fn;
+      unsigned z = fn <= 0 ? 1u : (ft2 >= lim * lim * (1.0 - 1e-4) ? 3u : 2u);
+      h += z * (unsigned)((ci + 3) * (ci + 3));
+      ci++;
+      i += 2;
+    } else if (d->efc_type[i] == EFC_LIMIT) {
+      h += (d->efc_force[i] > 0 ? 1u : 2u) * (unsigned)((i + 1) * (i + 1));
+    }
+  }
+  return (int)(h & 0x3FFFFFu);
 }
 int mro_ncon_active(const mro_data* d) {   /* contacts with constraint rows (three, or four with pyramidal cones) */
   int n = 0;
@@ -2140,6 +2164,7 @@ static void step2(const mro_model* m, mro_data* d) {
   fwd_acceleration(m, d);
   MRO_STAGE(FS_SOLVER);
   fwd_constraint(m, d);
+  d->state_hash = state_hash_eval(m, d);
   MRO_STAGE(FS_INTEGRATE);
   if (d->emu_rel_arm > 0 || d->emu_abs_finger > 0 || d->emu_polish) emulate_device_solver(m, d);
   if (d->round32 & 16) { round32(d->qacc, m->nv); round32(d->qfrc_constraint, m->nv); }

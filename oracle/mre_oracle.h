@@ -88,6 +88,7 @@ int mro_ncon(const mro_data*);
 int mro_nefc(const mro_data*);
 int mro_ncon_active(const mro_data*);
 int mro_contact_set_hash(const mro_data*);   /* contacts with constraint rows */
+int mro_state_hash(const mro_data*);   /* per-row state of the last solve's solution: limit pushing / not, contact open / stick / slide */
 int mro_nl(const mro_data*);   /* active joint-limit rows */
 int mro_limit_mask(const mro_data*);  /* bit b - 1: the hinge of body b has an active limit row */
 /* contact i: out[0:3]=pos, [3:12]=frame, [12]=dist, [13]=geom1, [14]=geom2 */

@@ -91,6 +91,7 @@ def lib() -> C.CDLL:
         L.mro_nefc.argtypes = [C.c_void_p]
         L.mro_ncon_active.argtypes = [C.c_void_p]
         L.mro_contact_set_hash.argtypes = [C.c_void_p]
+        L.mro_state_hash.argtypes = [C.c_void_p]
         L.mro_nl.argtypes = [C.c_void_p]
         L.mro_limit_mask.argtypes = [C.c_void_p]
         L.mro_contact.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double)]
@@ -228,6 +229,11 @@ class Env:
     def contact_set_hash(self) -> int:
         """22-bit hash of the geom pairs of the active contacts (the device traces the same number)."""
         return lib().mro_contact_set_hash(self.ptr)
+
+    @property
+    def state_hash(self) -> int:
+        """22-bit hash of what the last solve left behind per row (limit pushing or not, contact open / stick / slide)."""
+        return lib().mro_state_hash(self.ptr)
 
     @property
     def solver_iters(self):

@@ -44,10 +44,13 @@ def _divergence_report(name, gq, oq, nprops, gcen, ocen, tol=TOL):
             unexplained.append((i, int(bad[0]), float(worst[:, i].max())))
     clean = [i for i in range(N) if not np.any(gcen[:, i] != ocen[:, i])]
     cmax = err[:, clean].max() if clean else 0.0
+    M54 = (1 << 54) - 1
+    kinds = {"constraint set": sum(1 for i in range(N) if np.any((gcen[:, i] & M54) != (ocen[:, i] & M54))),
+             "solution state only (stick / slip / open, limit pushing)": sum(1 for i in range(N) if np.any(gcen[:, i] != ocen[:, i]) and not np.any((gcen[:, i] & M54) != (ocen[:, i] & M54)))}
     top = sorted(((float(err[:, i].max()), i, int(err[:, i].max(axis=0).argmax())) for i in clean), reverse=True)[:3]
     print(f"{name}: {len(under)}/{N} envs under {tol:g} on all 43 coordinates over {T} steps; "
           f"{len(switched)} left the bar after a constraint-set switch {switched[:6]}; {len(unexplained)} without one {unexplained[:6]}; "
-          f"{len(clean)} envs never switched, max err among them {cmax:.2e} "
+          f"{len(clean)} envs never switched (switches by kind: {kinds}), max err among them {cmax:.2e} "
           f"(arm {err[:, clean, :7].max() if clean else 0:.2e} fingers {err[:, clean, 7:15].max() if clean else 0:.2e} "
           f"cubes {err[:, clean, 15:].max() if clean else 0:.2e}); worst (err, env, coordinate) {[(f'{e:.1e}', i, c) for e, i, c in top]}")
     return under, switched, unexplained, cmax

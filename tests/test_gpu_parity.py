@@ -30,8 +30,9 @@ def _rollout_both(compiled_model, oracle_model, N, T, flags, scale, seed=0, no_c
                   control_steps=5, z_extra=0.0, gravity_comp=False, yaw=False, solver=None, census=False,
                   fp32_state=False, nprops_fixed=None):
     """census=True also returns, per step and env, the constraint census the solve of that step saw
-    (active contacts + 64 * bit mask of the joints at a limit, and in the high word a 22-bit hash of the geom pairs
-    those contacts belong to), device and oracle.
+    (active contacts + 64 * bit mask of the joints at a limit, in the high word a 22-bit hash of the geom pairs
+    those contacts belong to, and above it a hash of the solution's per-row state: limit rows pushing or not, contacts
+    open / sticking / sliding), device and oracle.
     fp32_state=True also returns the qpos trace of a SECOND fp64 oracle run whose state (qpos, qvel,
     warm start) is rounded to float32 after every step -- all arithmetic still fp64: the part of the
     device-vs-oracle gap that any implementation holding its state in fp32 has."""
@@ -74,7 +75,9 @@ def _rollout_both(compiled_model, oracle_model, N, T, flags, scale, seed=0, no_c
     phys.sync()
     tr = trace.cpu().numpy()
     gq = tr[:, :, :43]
-    gcen = tr[:, :, 43].astype(np.int64) + (tr[:, :, 44].astype(np.int64) << 32)
+    # bits 0..31 the census, 32..53 the contact-set hash, 54..62 the solution-state hash (mod 509): what the step's
+    # solve left behind per row -- limit pushing or not, contact open / sticking / sliding (trace column 45)
+    gcen = tr[:, :, 43].astype(np.int64) + (tr[:, :, 44].astype(np.int64) << 32) + ((tr[:, :, 45].astype(np.int64) % 509) << 54)
     oq = np.zeros_like(gq, dtype=np.float64)
     ocen = np.zeros(gq.shape[:2], np.int64)
     acts32 = acts.astype(np.float32).astype(np.float64)  # the device sees fp32 controls
@@ -84,6 +87,7 @@ def _rollout_both(compiled_model, oracle_model, N, T, flags, scale, seed=0, no_c
             for k in range(control_steps):
                 ocen[t * control_steps + k, i] = e.census + (e.contact_set_hash << 32)   # the rows the coming solve will see
                 e.step(1)
+                ocen[t * control_steps + k, i] += (e.state_hash % 509) << 54               # ... and what that solve left behind
                 oq[t * control_steps + k, i] = e.arr("qpos")[:43]
     if fp32_state:
         import concurrent.futures as cf
