@@ -155,6 +155,10 @@ struct mre_env {
   // gains nothing from the groups and pays their launches: after two such calls in a row the stepping calls
   // go back to one launch of the whole batch, until two stepping calls arrive back to back again
   int calls_since_drain = 0, sync_streak = 0;
+  // a pipelined launch failed half-way (a HIP error between the enqueue of a group's kernels and the record of its
+  // event): launches of the group that were in flight may have skipped envs waiting for a re-run, and their saved rows
+  // are gone -- the state is no longer the state of any rollout.  Every later call says so instead of stepping on.
+  bool broken = false;
 };
 
 // solver-specific instantiations of the step kernel (opt_solver of the model, mre_set_solver)
@@ -283,6 +287,8 @@ static int process_oldest(mre_env* e, mre_env::Group& G) {
 
 // Complete every pending group launch: every entry point that reads or writes device state starts here.
 static int drain(mre_env* e, bool api_call = false) {
+  if (e->broken) return fail(MRE_ERR_HIP, "an earlier stepping call failed while its launches were being enqueued: the "
+                                          "state of this handle is undefined (mre_destroy it, create a new one)");
   if (api_call) {
     if (e->calls_since_drain == 1) e->sync_streak++;
     else if (e->calls_since_drain > 1) e->sync_streak = 0;
@@ -329,6 +335,8 @@ static int launch_group(mre_env* e, mre_env::Group& G, const StepArgs& a_full) {
     (void)hipStreamSynchronize(G.st);
     (void)hipStreamSynchronize(G.st2);
     G.nout = 0; G.head = 0;
+    (void)hipMemset(e->d_pending + G.lo, 0, (size_t)G.n);
+    e->broken = true;
   }
   return rc;
 }
@@ -377,6 +385,7 @@ static int launch_group_enqueue(mre_env* e, mre_env::Group& G, const StepArgs& a
 }
 
 static int launch_step(mre_env* e, const StepArgs& a, bool settle = false, bool pipeline_ok = true) {
+  if (e->broken) return drain(e);   // (reports the failure)
   HIPCHK(hipSetDevice(e->device));  // the HIP current device is per thread; callers may have moved it
   {
     const bool guarded_ = e->fallback && a.nsteps > 0 && (a.flags & F_NO_CONSTRAINTS) == 0;
@@ -1686,7 +1695,6 @@ extern "C" int mre_place_props(mre_env* e, const uint8_t* mask, uint64_t seed, c
     e->profiling = prof;
     if (rc) return rc;
     if ((rc = copy_out(e, hs.data(), e->settle_steps, N * 4))) return rc;
-    bool again = false;
     if (getenv("MRE_DEBUG_PLACE")) {
       int nt = 0, ns = 0;
       for (size_t i = 0; i < N; i++) if (todo[i]) { nt++; ns += hs[i] >= 0; }
@@ -1698,20 +1706,25 @@ extern "C" int mre_place_props(mre_env* e, const uint8_t* mask, uint64_t seed, c
       const int n = hs[i] < 0 ? -hs[i] : hs[i];
       if (n > e->last_settle_max) e->last_settle_max = n;
       if (hs[i] >= 0) { todo[i] = 0; settled_now++; }               // settled
-      else if (round + 1 < max_settle_attempts) again = true;       // placed again in the next round
     }
     // a round in which NO env came to rest is not bad luck of a placement but the solver: PGS at 100 sweeps leaves a
     // friction creep of 1e-3 rad/s on resting cubes that never passes the velocity test (all 4096 envs of the bench,
     // in every one of ten rounds; with Newton all settle in the first).  Placing again cannot help: stop, flag them
-    if (settled_now == 0) break;
-    if (again) {
-      // `physics.data.time = original_time` of a failed attempt (:258): the clock goes back for the envs placed again
+    // (only where that diagnosis can hold: PGS, a batch large enough that "none of them" is not chance, first round;
+    //  a lone env keeps its ten attempts like the reference's)
+    const bool give_up = settled_now == 0 && round == 0 && N >= 64 && e->hM.solver != MRE_SOLVER_NEWTON;
+    bool left = false;
+    for (size_t i = 0; i < N; i++) left = left || todo[i];
+    if (left) {
+      // `physics.data.time = original_time` after EVERY failed attempt, the last one included
+      // (prop_initializer.py:240-258): the clock goes back for every env that did not settle in this round
       std::vector<int> now(N);
       if ((rc = copy_out(e, now.data(), e->nstep, N * 4))) return rc;
       for (size_t i = 0; i < N; i++) if (todo[i]) now[i] = nst[i];
       if ((rc = copy_in(e, e->nstep, now.data(), N * 4))) return rc;
       HIPCHK(hipStreamSynchronize(e->stream));
     }
+    if (give_up) break;
   }
   // status: envs that never settled (the reference logs _SETTLING_PHYSICS_FAILED and goes on), envs without a pose
   bool flag = false;

@@ -166,7 +166,8 @@ def _feature(value) -> bytes:
     a = np.asarray(value)
     if a.dtype.kind == "f":
         return _ld(2, _ld(1, a.astype("<f4").tobytes()))      # float_list, packed
-    if a.size and a.dtype.kind in "ub" or (a.size and a.min() >= 0 and a.max() < (1 << 14)):
+    # fast path (at most two varint bytes per value): uint8 / bool arrays by type, anything else by its value range
+    if a.size and (a.dtype in (np.uint8, np.bool_) or (a.min() >= 0 and a.max() < (1 << 14))):
         return _ld(3, _ld(1, _pack_varints(a)))               # int64_list, packed
     packed = b"".join(_varint(int(v) & 0xFFFFFFFFFFFFFFFF) for v in a.reshape(-1))
     return _ld(3, _ld(1, packed))                             # int64_list, packed

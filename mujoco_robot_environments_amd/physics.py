@@ -82,11 +82,12 @@ class BatchedPhysics:
         if not hasattr(self, "_keepalive"):
             self._keepalive = []
         self._keepalive.extend(tensors)
-        # the library reads an argument at the call (a rollout's control rows are copied on the handle's stream, and a
-        # stepping call first completes the previous launch of every env group, which follows the previous copy): only
-        # the arguments of the last few calls can still be in flight, so a loop that never calls sync() holds a bounded
-        # number of tensors
-        del self._keepalive[:-8]
+        # A rollout's control rows are copied on the handle's stream by the pipelined and the guarded launches, but an
+        # unguarded launch (no-constraints flag, fallback off) hands the caller's pointer straight to a kernel that runs
+        # later: nothing is dropped before the handle's stream has been waited for.  A loop that never calls sync()
+        # syncs here every 64 hand-overs instead of holding every tensor it ever passed.
+        if len(self._keepalive) > 64:
+            self.sync()
 
     def set_solver(self, solver: str) -> None:
         """mjOption.solver of a live handle: "PGS" or "Newton" (state and warm start carry over)."""
