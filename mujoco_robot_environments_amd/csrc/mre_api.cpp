@@ -608,6 +608,21 @@ static int build_model(const void* blob, size_t nbytes, DevModel& m) {
   RF("pair_friction", m.pair_friction, npair * 3); RF("pair_solref", m.pair_solref, npair * 2);
   RF("pair_solimp", m.pair_solimp, npair * 5); RF("pair_margin", m.pair_margin, npair);
   RF("pair_gap", m.pair_gap, npair);
+  for (int k = 0; k < NPAIR; k++) {
+    PairRec& r = m.pair_rec[k];
+    memset(&r, 0, sizeof(r));
+    r.g1 = m.pair_g1[k]; r.g2 = m.pair_g2[k];
+    if (r.g1 < 0) { r.g2 = -1; r.b1 = r.b2 = 0; r.pid1 = r.pid2 = -1; continue; }
+    if (r.g1 >= NG || r.g2 < 0 || r.g2 >= NG) return fail(MRE_ERR_MODEL, "pair table names a geom that does not exist");
+    r.b1 = m.geom_body[r.g1]; r.b2 = m.geom_body[r.g2];
+    r.pid1 = m.geom_propid[r.g1]; r.pid2 = m.geom_propid[r.g2];
+    r.type1 = m.geom_type[r.g1]; r.single = m.pair_single[k];
+    for (int c = 0; c < 3; c++) { r.pos1[c] = m.geom_pos[r.g1][c]; r.pos2[c] = m.geom_pos[r.g2][c];
+                                  r.size1[c] = m.geom_size[r.g1][c]; r.size2[c] = m.geom_size[r.g2][c]; }
+    for (int c = 0; c < 4; c++) { r.quat1[c] = m.geom_quat[r.g1][c]; r.quat2[c] = m.geom_quat[r.g2][c]; }
+    r.rb1 = m.geom_rbound[r.g1]; r.rb2 = m.geom_rbound[r.g2];
+    r.margin = m.pair_margin[k]; r.gap = m.pair_gap[k];
+  }
   RI("site_bodyid", m.site_body, NSITE); RF("site_pos", m.site_pos, NSITE * 3);
   RF("site_quat", m.site_quat, NSITE * 4);
   RI("eef_site", &m.eef_site, 1); RI("tcp_site", &m.tcp_site, 1);

@@ -70,6 +70,21 @@ constexpr int MAXBLK = 40;
 static_assert(NEFC_MAX <= 256 && NRROW_MAX < 127 && NPP_MAX <= 16 && MAXBLK >= 8 + NCON_MAX,
               "capacities must fit the block descriptor fields (mre_solver.h)");
 
+// Everything the collision stages need to know about one entry of the static pair table, in one 128-byte record:
+// the broad phase reads it with independent 16-byte loads (one trip to memory) where the separate tables cost a chain
+// of dependent loads -- pair -> geom -> body -> prop id, then the geoms' local frames -- per pass and lane
+// (round 3's phase stamps: broad phase 1.5 k of a Newton tick's 46.7 k units, geom frames 0.5 k).
+struct alignas(16) PairRec {
+  int g1, g2, b1, b2;              // geoms (g1 < 0: unused entry) and their bodies
+  int pid1, pid2, type1, single;   // cube slot of each geom (-1: none), type of geom 1 (0 = plane), one-contact pair
+  float pos1[3], rb1;              // geom 1 in its body's frame; bounding radius (a cube's comes from its per-env size)
+  float pos2[3], rb2;
+  float quat1[4], quat2[4];
+  float size1[3], margin;          // half sizes (a cube's come from its per-env size); pair margin
+  float size2[3], gap;
+};
+static_assert(sizeof(PairRec) == 128, "PairRec is eight 16-byte words");
+
 struct DevModel {
   // ---- bodies (index = body id)
   int body_parent[NB], body_level[NB], body_jnttype[NB], body_dofadr[NB], body_qposadr[NB];
@@ -102,6 +117,7 @@ struct DevModel {
   int pair_g1[NPAIR], pair_g2[NPAIR], pair_single[NPAIR];
   float pair_friction[NPAIR][3], pair_solref[NPAIR][2], pair_solimp[NPAIR][5];
   float pair_margin[NPAIR], pair_gap[NPAIR];
+  PairRec pair_rec[NPAIR];       // the same, packed per pair for the collision stages (filled by mre_create)
   int site_body[NSITE];
   float site_pos[NSITE][3], site_quat[NSITE][4];
   int eef_site, tcp_site;

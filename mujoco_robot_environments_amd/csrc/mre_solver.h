@@ -94,26 +94,29 @@ MRE_PHASE_FN void collide(ModelP M, Sm& s, int l, bool detect) {
   int nsurv = 0;
   for (int pass = 0; pass < NPAIR / 64; pass++) {
     const int pr = l + 64 * pass;
-    const int g1 = M->pair_g1[pr], g2 = M->pair_g2[pr];
+    // the pair's record: independent loads, one trip to memory (PairRec, mre_dev.h)
+    const auto* R = &M->pair_rec[pr];
+    const int g1 = R->g1, b1 = R->b1, b2 = R->b2, pid1 = R->pid1, pid2 = R->pid2, type1 = R->type1;
+    const float lp1[3] = {R->pos1[0], R->pos1[1], R->pos1[2]}, lp2[3] = {R->pos2[0], R->pos2[1], R->pos2[2]};
+    const float mrb1 = R->rb1, mrb2 = R->rb2, margin = R->margin, gap = R->gap;
+    const float lq1[4] = {R->quat1[0], R->quat1[1], R->quat1[2], R->quat1[3]};
     bool live = false;
-    if (g1 >= 0) {
-      const int b1 = M->geom_body[g1], b2 = M->geom_body[g2];
-      if (body_is_active(M, s, b1) && body_is_active(M, s, b2)) {
-        const float inc = detect ? M->pair_margin[pr] : M->pair_margin[pr] - M->pair_gap[pr];
-        float p1[3], p2[3], rb1, rb2, df[3];
-        geom_center(M, s, g1, p1, &rb1);
-        geom_center(M, s, g2, p2, &rb2);
-        v3sub(df, p2, p1);
-        if (M->geom_type[g1] == 0) {
-          float q[4], R1[9];
-          qmul(q, s.xquat[b1], M->geom_quat[g1]);
-          q2mat(R1, q);
-          const float nn[3] = {R1[2], R1[5], R1[8]};
-          live = v3dot(df, nn) - rb2 <= inc;
-        } else {
-          const float r = rb1 + rb2 + inc;
-          live = v3dot(df, df) <= r * r;
-        }
+    if (g1 >= 0 && (pid1 < 0 || pid1 < s.nprops) && (pid2 < 0 || pid2 < s.nprops)) {
+      const float inc = detect ? margin : margin - gap;
+      float p1[3], p2[3], df[3], tmp[3];
+      m3mulv(tmp, s.xmat[b1], lp1); v3add(p1, s.xpos[b1], tmp);
+      m3mulv(tmp, s.xmat[b2], lp2); v3add(p2, s.xpos[b2], tmp);
+      const float rb1 = pid1 >= 0 ? v3norm(s.prop_size[pid1]) : mrb1, rb2 = pid2 >= 0 ? v3norm(s.prop_size[pid2]) : mrb2;
+      v3sub(df, p2, p1);
+      if (type1 == 0) {
+        float q[4], R1[9];
+        qmul(q, s.xquat[b1], lq1);
+        q2mat(R1, q);
+        const float nn[3] = {R1[2], R1[5], R1[8]};
+        live = v3dot(df, nn) - rb2 <= inc;
+      } else {
+        const float r = rb1 + rb2 + inc;
+        live = v3dot(df, df) <= r * r;
       }
     }
     const unsigned long long m = __ballot(live);
@@ -129,13 +132,23 @@ MRE_PHASE_FN void collide(ModelP M, Sm& s, int l, bool detect) {
     float normal[3] = {0.f, 0.f, 1.f};
     int n = 0;
     if (pr >= 0) {
-      const int g1 = M->pair_g1[pr], g2 = M->pair_g2[pr];
-      float p1[3], R1[9], s1[3], rb1, p2[3], R2[9], s2[3], rb2;
-      geom_pose(M, s, g1, p1, R1, s1, &rb1);
-      geom_pose(M, s, g2, p2, R2, s2, &rb2);
-      const float inc = detect ? M->pair_margin[pr] : M->pair_margin[pr] - M->pair_gap[pr];
+      const auto* R = &M->pair_rec[pr];
+      const int b1 = R->b1, b2 = R->b2, pid1 = R->pid1, pid2 = R->pid2, type1 = R->type1;
+      const float lp1[3] = {R->pos1[0], R->pos1[1], R->pos1[2]}, lp2[3] = {R->pos2[0], R->pos2[1], R->pos2[2]};
+      const float lq1[4] = {R->quat1[0], R->quat1[1], R->quat1[2], R->quat1[3]};
+      const float lq2[4] = {R->quat2[0], R->quat2[1], R->quat2[2], R->quat2[3]};
+      const float ms1[3] = {R->size1[0], R->size1[1], R->size1[2]}, ms2[3] = {R->size2[0], R->size2[1], R->size2[2]};
+      const float margin = R->margin, gap = R->gap;
+      float p1[3], R1[9], s1[3], p2[3], R2[9], s2[3], tmp[3], q[4];
+      m3mulv(tmp, s.xmat[b1], lp1); v3add(p1, s.xpos[b1], tmp);
+      qmul(q, s.xquat[b1], lq1); q2mat(R1, q);
+      m3mulv(tmp, s.xmat[b2], lp2); v3add(p2, s.xpos[b2], tmp);
+      qmul(q, s.xquat[b2], lq2); q2mat(R2, q);
+      if (pid1 >= 0) v3copy(s1, s.prop_size[pid1]); else v3copy(s1, ms1);
+      if (pid2 >= 0) v3copy(s2, s.prop_size[pid2]); else v3copy(s2, ms2);
+      const float inc = detect ? margin : margin - gap;
       MRE_DBG_STAMP(6, 1);
-      if (M->geom_type[g1] == 0) n = plane_box(p1, R1, p2, R2, s2, inc, normal, buf);
+      if (type1 == 0) n = plane_box(p1, R1, p2, R2, s2, inc, normal, buf);
       else n = box_box(p1, R1, s1, p2, R2, s2, inc, normal, buf);
       MRE_DBG_STAMP(6, 2);
       // instantiate only contacts with dist < includemargin
@@ -151,7 +164,7 @@ MRE_PHASE_FN void collide(ModelP M, Sm& s, int l, bool detect) {
       n = m;
     }
     // mesh stand-in pairs keep ONE contact, like MuJoCo's convex-mesh test (formed at the write-out below)
-    const bool single = pr >= 0 && n > 1 && M->pair_single[pr] != 0;
+    const bool single = pr >= 0 && n > 1 && M->pair_rec[pr].single != 0;
     const int ncand = n;
     if (single) n = 1;
     // exclusive prefix sum of n (<= 8) over the lanes, bit by bit through ballots
@@ -169,7 +182,7 @@ MRE_PHASE_FN void collide(ModelP M, Sm& s, int l, bool detect) {
       // depth of the deepest candidate, position = the centroid of the active candidates weighted by their depth
       // below the threshold (the deepest point alone jumps between the corners of the clip polygon when two faces are
       // nearly parallel; oracle: collision()).  Written into candidate slot 0, which the loop below stores.
-      const float incw = M->pair_margin[pr] - M->pair_gap[pr];
+      const float incw = M->pair_rec[pr].margin - M->pair_rec[pr].gap;
       float wsum = 0.f, px = 0.f, py = 0.f, pz = 0.f, dmin = cand_dist(buf, 0);
       int best = 0;
       for (int c = 0; c < ncand; c++) {
@@ -335,8 +348,8 @@ MRE_PHASE_FN void assemble_constraints(ModelP M, Sm& s, int l) {
   // instead of chasing pair -> geom -> body through the model tables once per contact
   if (l < s.ncon) {
     const int pr = s.con_pair[l];
-    s.con_b1[l] = (uint8_t)M->geom_body[M->pair_g1[pr]];
-    s.con_b2[l] = (uint8_t)M->geom_body[M->pair_g2[pr]];
+    s.con_b1[l] = (uint8_t)M->pair_rec[pr].b1;
+    s.con_b2[l] = (uint8_t)M->pair_rec[pr].b2;
   }
   MRE_SYNC();
 #ifndef MRE_NEWTON

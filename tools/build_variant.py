@@ -5,7 +5,7 @@
 Known switches: -DMRE_PGS_F32 (PGS: robot-contact block update in float32, as up to round 3)."""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CSRC = os.path.join(ROOT, "mujoco_robot_environments_amd", "csrc")
+CSRC = os.environ.get("MRE_CSRC", os.path.join(ROOT, "mujoco_robot_environments_amd", "csrc"))   # (MRE_CSRC: another checkout's sources, for A/B against an earlier commit)
 DIAG = os.path.join(ROOT, "tools", "_diag")
 name, extra = sys.argv[1], sys.argv[2:]
 os.makedirs(DIAG, exist_ok=True)
