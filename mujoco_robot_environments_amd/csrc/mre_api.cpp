@@ -616,7 +616,9 @@ static int build_model(const void* blob, size_t nbytes, DevModel& m) {
     if (r.g1 >= NG || r.g2 < 0 || r.g2 >= NG) return fail(MRE_ERR_MODEL, "pair table names a geom that does not exist");
     r.b1 = m.geom_body[r.g1]; r.b2 = m.geom_body[r.g2];
     r.pid1 = m.geom_propid[r.g1]; r.pid2 = m.geom_propid[r.g2];
-    r.type1 = m.geom_type[r.g1]; r.single = m.pair_single[k];
+    r.type1 = m.geom_type[r.g1]; r.single = (m.pair_single[k] & 0xFF) | (m.geom_type[r.g2] << 8);
+    if (m.geom_type[r.g1] == 2 || (m.geom_type[r.g2] == 2 && m.geom_type[r.g1] != 1))
+      return fail(MRE_ERR_MODEL, "cylinder pairs: only box (geom 1) - cylinder (geom 2) is implemented");
     for (int c = 0; c < 3; c++) { r.pos1[c] = m.geom_pos[r.g1][c]; r.pos2[c] = m.geom_pos[r.g2][c];
                                   r.size1[c] = m.geom_size[r.g1][c]; r.size2[c] = m.geom_size[r.g2][c]; }
     for (int c = 0; c < 4; c++) { r.quat1[c] = m.geom_quat[r.g1][c]; r.quat2[c] = m.geom_quat[r.g2][c]; }

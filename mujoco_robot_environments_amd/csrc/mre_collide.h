@@ -244,6 +244,114 @@ MRE_DEV int plane_box(const float* pp, const float* Rp, const float* pb, const f
 }
 
 // mju_makeFrame: f[0:3] unit normal given, builds the two tangents
+// Cylinder (axis = local z of Rc, radius r, half height h; geom 2) against a box (geom 1): ONE contact, the normal from
+// the box to the cylinder -- the float32 form of the oracle's mro_cylbox (same candidate directions in the same order:
+// box face normals, cylinder axis, axis x box edges, closest points of the axis segment and the box; same contact
+// point rule).  MuJoCo hands this pair to its general convex collider, whose iterative penetration query has no
+// closed form to restate; tasks/push.py:153-160, tasks/lasa_draw.py:115-122 attach the cylinder.
+MRE_DEV int cyl_box(const float* pb, const float* Rb, const float* sb, const float* pc, const float* Rc,
+                    float r, float h, float margin, float* normal, float* buf) {
+  float df[3], c[3], a[3];
+  v3sub(df, pc, pb);
+  for (int k = 0; k < 3; k++) {
+    c[k] = Rb[k] * df[0] + Rb[3 + k] * df[1] + Rb[6 + k] * df[2];
+    a[k] = Rb[k] * Rc[2] + Rb[3 + k] * Rc[5] + Rb[6 + k] * Rc[8];
+  }
+  float best = -1e30f, b0 = 0.f, b1 = 0.f, b2 = 1.f;
+  auto tryd = [&](float dx, float dy, float dz) {
+    float dc = dx * c[0] + dy * c[1] + dz * c[2];
+    if (dc < 0.f) { dx = -dx; dy = -dy; dz = -dz; dc = -dc; }
+    const float ad = a[0] * dx + a[1] * dy + a[2] * dz, rad = fmaxf(1.f - ad * ad, 0.f);
+    const float sep = dc - (sb[0] * fabsf(dx) + sb[1] * fabsf(dy) + sb[2] * fabsf(dz)) - (h * fabsf(ad) + r * sqrtf(rad));
+    if (sep > best + 1e-7f) { best = sep; b0 = dx; b1 = dy; b2 = dz; }
+  };
+  tryd(1.f, 0.f, 0.f); tryd(0.f, 1.f, 0.f); tryd(0.f, 0.f, 1.f);
+  tryd(a[0], a[1], a[2]);
+  {
+    const float l0 = sqrtf(a[2] * a[2] + a[1] * a[1]), l1 = sqrtf(a[2] * a[2] + a[0] * a[0]), l2 = sqrtf(a[1] * a[1] + a[0] * a[0]);
+    if (l0 > 1e-6f) tryd(0.f, a[2] / l0, -a[1] / l0);
+    if (l1 > 1e-6f) tryd(-a[2] / l1, 0.f, a[0] / l1);
+    if (l2 > 1e-6f) tryd(a[1] / l2, -a[0] / l2, 0.f);
+  }
+  {
+    // closest points of the axis segment and the box (golden section on the convex f(t) = dist^2(c + t a, box))
+    float lo = -h, hi = h;
+    const float g = 0.61803399f;
+    float t1 = hi - g * (hi - lo), t2 = lo + g * (hi - lo);
+    for (int it = 0; it < 26; it++) {
+      float f1 = 0.f, f2 = 0.f;
+      for (int k = 0; k < 3; k++) {
+        const float u1 = fabsf(c[k] + t1 * a[k]) - sb[k], u2 = fabsf(c[k] + t2 * a[k]) - sb[k];
+        if (u1 > 0.f) f1 += u1 * u1;
+        if (u2 > 0.f) f2 += u2 * u2;
+      }
+      if (f1 <= f2) { hi = t2; t2 = t1; t1 = hi - g * (hi - lo); }
+      else { lo = t1; t1 = t2; t2 = lo + g * (hi - lo); }
+    }
+    const float t = 0.5f * (lo + hi);
+    float v[3];
+    for (int k = 0; k < 3; k++) {
+      const float q = c[k] + t * a[k];
+      v[k] = q - fminf(fmaxf(q, -sb[k]), sb[k]);
+    }
+    const float vn = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    if (vn > 1e-7f) tryd(v[0] / vn, v[1] / vn, v[2] / vn);
+  }
+  // refinement for rim-against-edge / corner poses (mro_cylbox): the direction from the box to the cylinder's deepest
+  // point along the best direction so far is one more candidate
+  for (int it = 0; it < 3; it++) {
+    const float adr = a[0] * b0 + a[1] * b1 + a[2] * b2;
+    float wr[3] = {b0 - adr * a[0], b1 - adr * a[1], b2 - adr * a[2]};
+    const float wrn = sqrtf(wr[0] * wr[0] + wr[1] * wr[1] + wr[2] * wr[2]);
+    const float sh = adr > 0.f ? -h : h;
+    float v[3];
+    for (int k = 0; k < 3; k++) {
+      const float xr = c[k] + sh * a[k] - (wrn > 1e-6f ? r * wr[k] / wrn : 0.f);
+      v[k] = xr - fminf(fmaxf(xr, -sb[k]), sb[k]);
+    }
+    const float vn = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    if (vn < 1e-7f) break;
+    const float before = best;
+    tryd(v[0] / vn, v[1] / vn, v[2] / vn);
+    if (!(best > before)) break;
+  }
+  if (best > margin) return 0;
+  const float bd[3] = {b0, b1, b2};
+  const float ad = a[0] * b0 + a[1] * b1 + a[2] * b2;
+  float w[3] = {b0 - ad * a[0], b1 - ad * a[1], b2 - ad * a[2]};
+  const float wn = sqrtf(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+  float x[3] = {c[0], c[1], c[2]};
+  if (fabsf(ad) > 1e-4f) {   // (parallel within 1e-4 rad: mro_cylbox)
+    const float sh = ad > 0.f ? -h : h;
+    for (int k = 0; k < 3; k++) x[k] += sh * a[k];
+  } else {
+    const float tau0 = -(c[0] * a[0] + c[1] * a[1] + c[2] * a[2]);
+    const float E = sb[0] * fabsf(a[0]) + sb[1] * fabsf(a[1]) + sb[2] * fabsf(a[2]);
+    const float lo = fmaxf(tau0 - E, -h), hi = fminf(tau0 + E, h);
+    const float t = lo <= hi ? 0.5f * (lo + hi) : fminf(fmaxf(tau0, -h), h);
+    for (int k = 0; k < 3; k++) x[k] += t * a[k];
+  }
+  if (wn > 1e-4f) {
+    for (int k = 0; k < 3; k++) x[k] -= r * w[k] / wn;
+  } else {
+    float o[3];
+    for (int k = 0; k < 3; k++) o[k] = fminf(fmaxf(x[k], -sb[k]), sb[k]) - x[k];
+    const float oa = o[0] * a[0] + o[1] * a[1] + o[2] * a[2];
+    for (int k = 0; k < 3; k++) o[k] -= oa * a[k];
+    const float on = sqrtf(o[0] * o[0] + o[1] * o[1] + o[2] * o[2]);
+    const float sc = on > r ? r / on : 1.f;
+    for (int k = 0; k < 3; k++) x[k] += sc * o[k];
+  }
+  for (int k = 0; k < 3; k++) x[k] -= 0.5f * best * bd[k];
+  float* c0 = cand_xyz(buf, 0);
+  for (int k = 0; k < 3; k++) {
+    c0[k] = pb[k] + Rb[3 * k] * x[0] + Rb[3 * k + 1] * x[1] + Rb[3 * k + 2] * x[2];
+    normal[k] = Rb[3 * k] * bd[0] + Rb[3 * k + 1] * bd[1] + Rb[3 * k + 2] * bd[2];
+  }
+  cand_dist(buf, 0) = best;
+  return 1;
+}
+
 MRE_DEV void make_frame(float* f) {
   float y[3] = {0.f, 0.f, 0.f};
   if (f[1] < 0.5f && f[1] > -0.5f) y[1] = 1.f; else y[2] = 1.f;

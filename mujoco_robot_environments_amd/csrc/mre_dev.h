@@ -76,7 +76,7 @@ static_assert(NEFC_MAX <= 256 && NRROW_MAX < 127 && NPP_MAX <= 16 && MAXBLK >= 8
 // (round 3's phase stamps: broad phase 1.5 k of a Newton tick's 46.7 k units, geom frames 0.5 k).
 struct alignas(16) PairRec {
   int g1, g2, b1, b2;              // geoms (g1 < 0: unused entry) and their bodies
-  int pid1, pid2, type1, single;   // cube slot of each geom (-1: none), type of geom 1 (0 = plane), one-contact pair
+  int pid1, pid2, type1, single;   // cube slot of each geom (-1: none), type of geom 1 (0 = plane), one-contact pair | type of geom 2 << 8
   float pos1[3], rb1;              // geom 1 in its body's frame; bounding radius (a cube's comes from its per-env size)
   float pos2[3], rb2;
   float quat1[4], quat2[4];

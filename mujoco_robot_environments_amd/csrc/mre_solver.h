@@ -148,7 +148,8 @@ MRE_PHASE_FN void collide(ModelP M, Sm& s, int l, bool detect) {
       if (pid2 >= 0) v3copy(s2, s.prop_size[pid2]); else v3copy(s2, ms2);
       const float inc = detect ? margin : margin - gap;
       MRE_DBG_STAMP(6, 1);
-      if (type1 == 0) n = plane_box(p1, R1, p2, R2, s2, inc, normal, buf);
+      if ((R->single >> 8) == 2) n = cyl_box(p1, R1, s1, p2, R2, s2[0], s2[2], inc, normal, buf);   // geom 2 is a cylinder
+      else if (type1 == 0) n = plane_box(p1, R1, p2, R2, s2, inc, normal, buf);
       else n = box_box(p1, R1, s1, p2, R2, s2, inc, normal, buf);
       MRE_DBG_STAMP(6, 2);
       // instantiate only contacts with dist < includemargin
@@ -164,7 +165,7 @@ MRE_PHASE_FN void collide(ModelP M, Sm& s, int l, bool detect) {
       n = m;
     }
     // mesh stand-in pairs keep ONE contact, like MuJoCo's convex-mesh test (formed at the write-out below)
-    const bool single = pr >= 0 && n > 1 && M->pair_rec[pr].single != 0;
+    const bool single = pr >= 0 && n > 1 && (M->pair_rec[pr].single & 0xFF) != 0;
     const int ncand = n;
     if (single) n = 1;
     // exclusive prefix sum of n (<= 8) over the lanes, bit by bit through ballots

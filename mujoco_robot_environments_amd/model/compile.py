@@ -34,7 +34,7 @@ BLOB_MAGIC = 0x4D524542  # 'MREB'
 BLOB_VERSION = 4
 
 JNT_NONE, JNT_HINGE, JNT_FREE = 0, 1, 2
-GEOM_PLANE, GEOM_BOX = 0, 1
+GEOM_PLANE, GEOM_BOX, GEOM_CYLINDER = 0, 1, 2   # (cylinder: size = (r, r, half height), axis z)
 EQ_CONNECT, EQ_JOINT = 0, 1
 MINVAL = 1e-15
 
@@ -119,7 +119,7 @@ class _Body:
 
 
 def _geom_inertia(g):
-    if g["mass"] is None or g["type"] != "box":
+    if g["mass"] is None or g["type"] not in ("box", "cylinder"):
         return None
     m = float(g["mass"])
     a, b, c = g["size"]
@@ -435,11 +435,11 @@ def compile_scene(scene: dict = None) -> Dict[str, np.ndarray]:
     n_early = sum(1 for g in geoms if not g.get("late", False))
     # MuJoCo sorts nothing; keep spec order but put the plane first for pair typing
     ng = len(geoms)
-    gtype = np.array([GEOM_PLANE if g["type"] == "plane" else GEOM_BOX for g in geoms], np.int32)
+    gtype = np.array([{"plane": GEOM_PLANE, "box": GEOM_BOX, "cylinder": GEOM_CYLINDER}[g["type"]] for g in geoms], np.int32)
     geom_size = np.array([g["size"] for g in geoms], dtype=np.float64)
     geom_pos = np.array([g["pos"] for g in geoms], dtype=np.float64)
     geom_quat = np.array([qnorm(g["quat"]) for g in geoms])
-    geom_rbound = np.array([0.0 if t == GEOM_PLANE else np.linalg.norm(s)
+    geom_rbound = np.array([0.0 if t == GEOM_PLANE else (np.hypot(s[0], s[2]) if t == GEOM_CYLINDER else np.linalg.norm(s))
                             for t, s in zip(gtype, geom_size)])
     geom_propid = np.full(ng, -1, np.int32)
     body_propid = np.full(nb, -1, np.int32)
@@ -521,6 +521,10 @@ def compile_scene(scene: dict = None) -> Dict[str, np.ndarray]:
         # hull geoms stand in for convex collision MESHES: MuJoCo's mesh narrow phase (mjc_Convex,
         # multiccd off) returns ONE contact per pair -> keep only the deepest point of the box test
         pair_single[k] = int(bool(geoms[g1]["hull"] or geoms[g2]["hull"]))
+        if gtype[g2] == GEOM_CYLINDER:
+            # the narrow phases cover cylinder - box (mro_cylbox / cyl_box): one contact, the cylinder as geom 2
+            assert gtype[g1] == GEOM_BOX, "cylinder pairs: only cylinder - box is implemented"
+            pair_single[k] = 1
         assert c == 3, "kernels implement condim 3 (all geoms of this scene)"
 
     A.update(

@@ -328,14 +328,17 @@ def default_scene(cfg: Optional[Dict] = None, max_props: int = 4) -> dict:
 # --------------------------------------------------------------------------
 # The reference's other tasks (tasks/base.py, tasks/push.py, tasks/lasa_draw.py) on the same kernels
 # --------------------------------------------------------------------------
-def tool_cylinder() -> dict:
+def tool_cylinder(shape: str = "cylinder") -> dict:
     """The cylinder added to the arm's attachment body for non-prehensile work (tasks/push.py:156-163,
     tasks/lasa_draw.py:113-120): radius 0.015, half height 0.05, centre 0.05 above the attachment site,
-    default density 1000 (mass and inertia are the cylinder's).  Its collision shape is the box hull of
-    the cylinder -- the repo's stated deviation for every convex shape MuJoCo hands to its general convex
-    collider (one contact per pair)."""
+    default density 1000.  It collides as a cylinder (one contact per pair like MuJoCo's convex collider; narrow phase:
+    oracle mro_cylbox / csrc/mre_collide.h cyl_box -- a closed-form separating-axis search).
+    ``shape="hull"`` restores rounds 1-3's stand-in, the box hull of the cylinder.  ``size`` = (r, r, half height)
+    either way (the camera draws the hull)."""
     r, hh = 0.015, 0.05
-    g = box("tool_cylinder", (r, r, hh), pos=(0.0, 0.0, 0.05), hull=True)
+    g = box("tool_cylinder", (r, r, hh), pos=(0.0, 0.0, 0.05), hull=(shape == "hull"))
+    if shape != "hull":
+        g["type"] = "cylinder"
     g["mass"] = 1000.0 * math.pi * r * r * 2 * hh
     g["inertia_shape"] = "cylinder"
     return g
@@ -399,7 +402,7 @@ def other_task_scene(task: str, cfg: Optional[Dict] = None, embed: bool = True, 
         gripper = robotiq_spec()
     else:
         gripper = robotiq_spec(inert=True) if embed else None
-    tool = None if has_gripper else tool_cylinder()
+    tool = None if has_gripper else tool_cylinder(cfg.get("tool_shape", "cylinder"))
     statics, props, robot_z = [], [], 0.4
     if task == "base":
         robot_z = 0.0                                  # tasks/base.py:81-85

@@ -45,6 +45,7 @@ int mro_flops_read(unsigned long long* out, int reset) {
 #define JNT_FREE 2
 #define GEOM_PLANE 0
 #define GEOM_BOX 1
+#define GEOM_CYLINDER 2
 #define EQ_CONNECT 0
 #define EQ_JOINT 1
 enum { EFC_EQ = 0, EFC_LIMIT = 1, EFC_CONTACT = 2, EFC_PYRAMID = 3 };
@@ -853,6 +854,119 @@ int mro_boxbox(const double* p1, const double* R1, const double* s1, const doubl
 }
 
 /* mju_makeFrame: frame[0:3] given (unit); build tangents */
+/* Cylinder (axis = local z, radius r, half height h) against a box: ONE contact, like the single contact MuJoCo's
+ * general convex collider (mjc_Convex) returns for this pair -- but by a closed-form separating-axis search, not by
+ * MuJoCo's iterative penetration query, which has no closed form to restate (tasks/push.py:153-160,
+ * tasks/lasa_draw.py:115-122 attach the cylinder).  Box = geom 1, cylinder = geom 2; the normal
+ * points from the box to the cylinder.  Candidate directions d, in the box's frame: its three face normals, the
+ * cylinder's axis a, a x e_i, and the direction between the closest points of the axis segment and the box (rim or
+ * side against an edge or corner).  Along d the bodies are sep(d) = d.c - sum s_i |d_i| - (h |a.d| + r sqrt(1 - (a.d)^2))
+ * apart; the direction of largest separation (least penetration) is the contact normal, that separation the distance,
+ * the contact point lies half way between the cylinder's deepest point along -d and the box's supporting plane.
+ * Where the deepest "point" is a whole cap (d parallel to a) it is taken at the cap's centre moved over the box's
+ * cross-section, where it is a generator line (d normal to a) at the middle of the line's overlap with the box. */
+int mro_cylbox(const double* pb, const double* Rb, const double* sb, const double* pc, const double* Rc,
+               double r, double h, double margin, double* normal, double* pos, double* dist) {
+  double c[3], a[3], df[3];
+  v3sub(df, pc, pb);
+  m3tmulv(c, Rb, df);
+  const double az[3] = {Rc[2], Rc[5], Rc[8]};
+  m3tmulv(a, Rb, az);
+  double best = -1e30, bd[3] = {0, 0, 1};
+  double cand[8][3];
+  int nc = 0;
+  for (int i = 0; i < 3; i++) { cand[nc][0] = cand[nc][1] = cand[nc][2] = 0; cand[nc][i] = 1; nc++; }
+  v3copy(cand[nc++], a);
+  for (int i = 0; i < 3; i++) {
+    double e[3] = {0, 0, 0}, x[3];
+    e[i] = 1;
+    v3cross(x, a, e);
+    if (v3normalize(x) > 1e-6) v3copy(cand[nc++], x);
+  }
+  {
+    /* closest points of the axis segment and the box: f(t) = dist^2(c + t a, box) is convex in t */
+    double lo = -h, hi = h;
+    const double g = 0.6180339887498949;
+    double t1 = hi - g * (hi - lo), t2 = lo + g * (hi - lo), f1 = 0, f2 = 0;
+    for (int it = 0; it < 40; it++) {
+      f1 = f2 = 0;
+      for (int k = 0; k < 3; k++) {
+        double u1 = fabs(c[k] + t1 * a[k]) - sb[k], u2 = fabs(c[k] + t2 * a[k]) - sb[k];
+        if (u1 > 0) f1 += u1 * u1;
+        if (u2 > 0) f2 += u2 * u2;
+      }
+      if (f1 <= f2) { hi = t2; t2 = t1; t1 = hi - g * (hi - lo); }
+      else { lo = t1; t1 = t2; t2 = lo + g * (hi - lo); }
+    }
+    const double t = 0.5 * (lo + hi);
+    double v[3];
+    for (int k = 0; k < 3; k++) {
+      double q = c[k] + t * a[k], b = q > sb[k] ? sb[k] : (q < -sb[k] ? -sb[k] : q);
+      v[k] = q - b;
+    }
+    if (v3normalize(v) > 1e-9) v3copy(cand[nc++], v);
+  }
+  for (int k = 0; k < nc; k++) {
+    double d[3];
+    v3copy(d, cand[k]);
+    if (v3dot(d, c) < 0) { d[0] = -d[0]; d[1] = -d[1]; d[2] = -d[2]; }
+    double ad = v3dot(a, d), rad = 1.0 - ad * ad;
+    double sep = v3dot(d, c) - (sb[0] * fabs(d[0]) + sb[1] * fabs(d[1]) + sb[2] * fabs(d[2])) -
+                 (h * fabs(ad) + r * sqrt(rad > 0 ? rad : 0));
+    if (sep > best + 1e-9) { best = sep; v3copy(bd, d); }   /* (earlier candidates win ties: faces, axis, crosses) */
+  }
+  /* refinement for rim-against-edge / corner poses, where none of the fixed directions is the separating one: the
+   * direction from the box to the cylinder's deepest point along the best direction so far is one more candidate
+   * (every sep(d) is a lower bound of the true distance, so taking the largest can only tighten it) */
+  for (int it = 0; it < 3; it++) {
+    double adr = v3dot(a, bd), wr[3], xr[3], v[3];
+    for (int k = 0; k < 3; k++) wr[k] = bd[k] - adr * a[k];
+    double wrn = v3normalize(wr);
+    v3copy(xr, c);
+    v3addscl(xr, a, adr > 0 ? -h : h);
+    if (wrn > 1e-6) v3addscl(xr, wr, -r);
+    for (int k = 0; k < 3; k++) { double b = xr[k] > sb[k] ? sb[k] : (xr[k] < -sb[k] ? -sb[k] : xr[k]); v[k] = xr[k] - b; }
+    if (v3normalize(v) < 1e-9) break;
+    double ad2 = v3dot(a, v), rad2 = 1.0 - ad2 * ad2;
+    double sep = v3dot(v, c) - (sb[0] * fabs(v[0]) + sb[1] * fabs(v[1]) + sb[2] * fabs(v[2])) -
+                 (h * fabs(ad2) + r * sqrt(rad2 > 0 ? rad2 : 0));
+    if (!(sep > best + 1e-9)) break;
+    best = sep; v3copy(bd, v);
+  }
+  if (best > margin) return 0;
+  /* deepest point of the cylinder along -bd */
+  double ad = v3dot(a, bd), w[3], x[3];
+  for (int k = 0; k < 3; k++) w[k] = bd[k] - ad * a[k];
+  double wn = v3normalize(w);
+  v3copy(x, c);
+  /* (a generator within 1e-4 rad of a face is parallel to it: its ends differ by 10 um in depth, and which of them is
+   *  "the deepest" would otherwise flip with the last bit of the pose) */
+  if (fabs(ad) > 1e-4) v3addscl(x, a, ad > 0 ? -h : h);
+  else {
+    double tau0 = -v3dot(c, a), E = sb[0] * fabs(a[0]) + sb[1] * fabs(a[1]) + sb[2] * fabs(a[2]);
+    double lo = tau0 - E > -h ? tau0 - E : -h, hi = tau0 + E < h ? tau0 + E : h;
+    double t = lo <= hi ? 0.5 * (lo + hi) : (tau0 > h ? h : (tau0 < -h ? -h : tau0));
+    v3addscl(x, a, t);
+  }
+  if (wn > 1e-4) v3addscl(x, w, -r);
+  else {
+    /* a whole cap faces the box: its centre, moved (within the disc) over the box's cross-section */
+    double o[3];
+    for (int k = 0; k < 3; k++) { double b = x[k] > sb[k] ? sb[k] : (x[k] < -sb[k] ? -sb[k] : x[k]); o[k] = b - x[k]; }
+    double oa = v3dot(o, a);
+    for (int k = 0; k < 3; k++) o[k] -= oa * a[k];
+    double on = v3norm(o);
+    if (on > r) for (int k = 0; k < 3; k++) o[k] *= r / on;
+    v3add(x, x, o);
+  }
+  v3addscl(x, bd, -0.5 * best);
+  m3mulv(pos, Rb, x);
+  v3add(pos, pos, pb);
+  m3mulv(normal, Rb, bd);
+  dist[0] = best;
+  return 1;
+}
+
 static void make_frame(double* f) {
   double y[3] = {0, 0, 0};
   if (f[1] < 0.5 && f[1] > -0.5) y[1] = 1; else y[2] = 1;
@@ -923,8 +1037,13 @@ static void collision(const mro_model* m, mro_data* d) {
       double r = d->geom_rbound[g1] + d->geom_rbound[g2] + margin;
       if (v3dot(df, df) > r * r) continue;
       double normal[3], pos[24], dist[8];
-      int n = mro_boxbox(d->geom_xpos[g1], d->geom_xmat[g1], d->geom_size[g1], d->geom_xpos[g2],
-                         d->geom_xmat[g2], d->geom_size[g2], margin, normal, pos, dist);
+      int n;
+      if (m->geom_type[g2] == GEOM_CYLINDER)   /* (pairs are ordered by type: the cylinder is geom 2; size = r, r, half height) */
+        n = mro_cylbox(d->geom_xpos[g1], d->geom_xmat[g1], d->geom_size[g1], d->geom_xpos[g2], d->geom_xmat[g2],
+                       d->geom_size[g2][0], d->geom_size[g2][2], margin, normal, pos, dist);
+      else
+        n = mro_boxbox(d->geom_xpos[g1], d->geom_xmat[g1], d->geom_size[g1], d->geom_xpos[g2],
+                       d->geom_xmat[g2], d->geom_size[g2], margin, normal, pos, dist);
       if (m->pair_single[k] && n > 1) {
         /* mesh stand-in: one contact per pair, like mjc_Convex.  Depth = the deepest candidate's; position = the
          * centroid of the ACTIVE candidates (dist < margin - gap) weighted by their depth below that threshold.

@@ -122,6 +122,10 @@ int mro_boxbox(const double* p1, const double* R1, const double* s1, const doubl
                const double* R2, const double* s2, double margin, double* normal,
                double* pos /*[8][3]*/, double* dist /*[8]*/);
 
+/* stand-alone cylinder (axis z of Rc, radius r, half height h) - box narrow phase: one contact; returns 0 / 1 */
+int mro_cylbox(const double* pb, const double* Rb, const double* sb, const double* pc, const double* Rc,
+               double r, double h, double margin, double* normal, double* pos, double* dist);
+
 #ifdef __cplusplus
 }
 #endif

@@ -101,6 +101,7 @@ def lib() -> C.CDLL:
         L.mro_run_controller.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(OscParams),
                                          C.c_double, C.c_int, C.c_int]
         L.mro_boxbox.argtypes = [C.POINTER(C.c_double)] * 6 + [C.c_double] + [C.POINTER(C.c_double)] * 3
+        L.mro_cylbox.argtypes = [C.POINTER(C.c_double)] * 5 + [C.c_double] * 3 + [C.POINTER(C.c_double)] * 3
         L.mro_cone_eval.restype = C.c_double
         L.mro_cone_eval.argtypes = [C.POINTER(C.c_double)] * 3 + [C.c_double] + [C.POINTER(C.c_double)] * 2 + [C.POINTER(C.c_int)]
         if hasattr(L, "mro_batch_step"):
@@ -281,6 +282,14 @@ def boxbox(p1, R1, s1, p2, R2, s2, margin=0.0):
     normal, pos, dist = np.zeros(3), np.zeros(24), np.zeros(8)
     n = lib().mro_boxbox(*[_dp(x) for x in a], float(margin), _dp(normal), _dp(pos), _dp(dist))
     return n, normal, pos.reshape(8, 3)[:n], dist[:n]
+
+
+def cylbox(pb, Rb, sb, pc, Rc, r, h, margin=0.0):
+    """Cylinder (axis = column z of Rc) against a box: (n, normal box -> cylinder, pos, dist) of the one contact."""
+    a = [np.ascontiguousarray(x, np.float64).ravel() for x in (pb, Rb, sb, pc, Rc)]
+    normal, pos, dist = np.zeros(3), np.zeros(3), np.zeros(1)
+    n = lib().mro_cylbox(*[_dp(x) for x in a], float(r), float(h), float(margin), _dp(normal), _dp(pos), _dp(dist))
+    return n, normal, pos, float(dist[0])
 
 
 def make_osc(cfg: Optional[dict] = None) -> OscParams:

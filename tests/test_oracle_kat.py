@@ -454,3 +454,75 @@ def test_joint_limit_row_balances_a_torque_pushing_into_the_limit(compiled_model
     assert abs(e.arr("qfrc_constraint")[5] - 4.0) < 0.05, e.arr("qfrc_constraint")[:7]
     others = [0, 1, 2, 3, 4, 6]
     assert np.abs(np.array(q[:7])[others] - np.array(HOME)[others]).max() < 2e-2
+
+
+def test_cylinder_box_known_answers():
+    """mro_cylbox (the tool cylinder of PushEnv / LasaDrawEnv against boxes; one contact like MuJoCo's convex collider):
+    cap flat on a face, generator lying on a face, side against a vertical face, side against a vertical edge, rim
+    against a face (tilted), and the detected-but-separated case."""
+    from oracle import oracle as O
+    I = np.eye(3)
+    r, h = 0.015, 0.05
+    table = ([0, 0, 0], I, [0.5, 0.5, 0.1])
+    # cap flat on the table, 1 mm deep: normal +z, at the cap's centre, half way between the surfaces
+    n, nm, pos, d = O.cylbox(*table, [0.1, 0.05, 0.1 + h - 0.001], I, r, h)
+    assert n == 1 and np.allclose(nm, [0, 0, 1]) and abs(d + 0.001) < 1e-12 and np.allclose(pos, [0.1, 0.05, 0.0995])
+    # lying on its side (axis along x), 2 mm deep: middle of the generator
+    Rx = np.array([[0, 0, 1], [0, 1, 0], [-1, 0, 0.0]])
+    n, nm, pos, d = O.cylbox(*table, [0.1, 0.05, 0.1 + r - 0.002], Rx, r, h)
+    assert n == 1 and np.allclose(nm, [0, 0, 1]) and abs(d + 0.002) < 1e-12 and np.allclose(pos, [0.1, 0.05, 0.099])
+    # upright, pushing a cube's +x face: the generator overlaps the face between z = -0.02 and 0.025
+    cube = ([0, 0, 0], I, [0.025] * 3)
+    n, nm, pos, d = O.cylbox(*cube, [0.025 + r - 0.001, 0.0, 0.03], I, r, h)
+    assert n == 1 and np.allclose(nm, [1, 0, 0]) and abs(d + 0.001) < 1e-12 and np.allclose(pos, [0.0245, 0.0, 0.0025])
+    # upright against the cube's vertical edge, along the diagonal: the radial direction, 1 mm deep
+    c = 0.025 + (r - 0.001) / np.sqrt(2)
+    n, nm, pos, d = O.cylbox(*cube, [c, c, 0.0], I, r, h)
+    assert n == 1 and np.allclose(nm, [np.sqrt(0.5), np.sqrt(0.5), 0], atol=1e-6) and abs(d + 0.001) < 1e-6
+    assert np.allclose(pos[:2], 0.025 - 0.0005 / np.sqrt(2), atol=1e-6)
+    # tilted 30 degrees about y over the table: the rim's lowest point touches first
+    th = np.deg2rad(30.0)
+    Rt = np.array([[np.cos(th), 0, np.sin(th)], [0, 1, 0], [-np.sin(th), 0, np.cos(th)]])
+    low = h * np.cos(th) + r * np.sin(th)                  # height of the centre when the rim touches z = 0.1
+    n, nm, pos, d = O.cylbox(*table, [0.0, 0.0, 0.1 + low - 0.0005], Rt, r, h)
+    assert n == 1 and np.allclose(nm, [0, 0, 1]) and abs(d + 0.0005) < 1e-9
+    rim = np.array([0.0, 0.0, 0.1 + low - 0.0005]) + Rt @ np.array([r, 0, -h])   # the rim point that is lowest
+    assert np.allclose(pos, rim + [0, 0, 0.00025], atol=1e-9)
+    # 2 cm apart within a 5 cm margin: detected, positive distance; beyond the margin: nothing
+    n, nm, pos, d = O.cylbox(*cube, [0.06, 0.0, 0.0], I, r, h, margin=0.05)
+    assert n == 1 and abs(d - 0.02) < 1e-12 and np.allclose(pos, [0.035, 0, 0])
+    assert O.cylbox(*cube, [0.06, 0.0, 0.0], I, r, h, margin=0.01)[0] == 0
+
+
+def test_cylinder_box_distance_is_a_lower_bound_of_the_true_separation():
+    """Random separated poses: the reported distance never exceeds the true distance between the two convex bodies
+    (a separating-axis search over a finite set of directions underestimates, never overestimates), and equals it to
+    1e-6 whenever the closest feature is a face, the axis or the radial direction (sampled surface points)."""
+    from oracle import oracle as O
+    rng_ = np.random.default_rng(5)
+    r, h, s = 0.015, 0.05, np.array([0.025, 0.03, 0.02])
+    gaps = []
+    for _ in range(300):
+        q = rng_.standard_normal(4); q /= np.linalg.norm(q)
+        w, x, y, z = q
+        Rc = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                       [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                       [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+        dirv = rng_.standard_normal(3); dirv /= np.linalg.norm(dirv)
+        pc = dirv * rng_.uniform(0.07, 0.12)
+        n, nm, pos, d = O.cylbox([0, 0, 0], np.eye(3), s, pc, Rc, r, h, margin=1.0)
+        assert n == 1
+        # true distance by dense sampling of the cylinder's surface against the box
+        tt = np.linspace(-h, h, 41); ph = np.linspace(0, 2 * np.pi, 73)[:-1]
+        T, P = np.meshgrid(tt, ph, indexing="ij")
+        side = np.stack([r * np.cos(P), r * np.sin(P), T], -1).reshape(-1, 3)
+        rr = np.linspace(0, r, 7)
+        Rr, P2 = np.meshgrid(rr, ph, indexing="ij")
+        caps = np.concatenate([np.stack([Rr * np.cos(P2), Rr * np.sin(P2), np.full_like(Rr, sg * h)], -1).reshape(-1, 3) for sg in (-1, 1)])
+        pts = np.concatenate([side, caps]) @ Rc.T + pc
+        dd = np.linalg.norm(pts - np.clip(pts, -s, s), axis=1).min()
+        if dd < 1e-3:         # (the pose overlaps or touches: the sampled distance says nothing about a penetration depth)
+            continue
+        assert d <= dd + 1e-9, (d, dd)
+        gaps.append(dd - d)
+    assert len(gaps) > 150 and max(gaps) < 4e-3 and np.median(gaps) < 2e-4, (len(gaps), max(gaps), np.median(gaps))   # (sampling grid: 2 mm)

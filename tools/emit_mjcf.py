@@ -49,8 +49,11 @@ def _geom(g: dict, size=None, masks=None) -> str:
     if g["type"] == "plane":
         a += ['type="plane"', 'size="2 2 2"']
     else:
-        a += ['type="box"', f'size="{_v(size if size is not None else g["size"])}"', f'pos="{_v(g["pos"])}"',
-              f'quat="{_v(g["quat"])}"']
+        if g["type"] == "cylinder":   # MuJoCo: size = radius, half height
+            a += ['type="cylinder"', f'size="{_v((g["size"][0], g["size"][2]))}"']
+        else:
+            a += ['type="box"', f'size="{_v(size if size is not None else g["size"])}"']
+        a += [f'pos="{_v(g["pos"])}"', f'quat="{_v(g["quat"])}"']
         if g["mass"] is not None:
             a.append(f'mass="{float(g["mass"])!r}"')
     return "<geom " + " ".join(a) + "/>"
