@@ -313,3 +313,41 @@ def test_pyramidal_cone_brakes_like_a_diamond(solver):
     assert 0.9 < dec[0] < 1.15 and 0.9 < dec[2] < 1.15, dec          # along the tangent axes: mu g (first 20 ms: 1.08)
     assert 0.6 < dec[1] < 0.8 and 0.6 < dec[3] < 0.8, dec            # along the diagonals: the diamond's short side
     env.close()
+
+
+def test_cylinder_box_narrow_phase_matches_oracle():
+    """The tool cylinder against the push block, contact by contact (physics.data.contact through mre_get_contacts vs the
+    oracle's mro_cylbox on the same poses): 16 envs with the block set at random poses around the tool's tip -- side against a
+    face, rim against an edge or a corner, cap on the top face, and separated within the block's margin."""
+    from mujoco_robot_environments_amd.tasks.push import BatchedPushEnv
+    from oracle import oracle as O
+    N = 16
+    env = BatchedPushEnv(num_envs=N, solver="Newton")
+    env.reset()
+    names = list(env.model["_names"]["geoms"])
+    tool, block = names.index("tool_cylinder"), 12
+    phys = env.physics
+    tw0 = _oracle_twin(env, 0)
+    gx = tw0.arr("geom_xpos").reshape(-1, 3)[tool].copy()       # the tool's centre at the home pose (same in every env)
+    r = np.random.default_rng(3)
+    qp = phys.qpos().copy()
+    for i in range(N):
+        d = r.standard_normal(3); d /= np.linalg.norm(d)
+        dist = r.uniform(0.02, 0.075)
+        qp[i, 15:18] = gx + d * dist
+        q = r.standard_normal(4); q /= np.linalg.norm(q)
+        qp[i, 18:22] = q
+    phys.set_state(qp, np.zeros((N, 39), np.float32))
+    cnt, con = phys.contacts()
+    found = 0
+    for i in range(N):
+        e = _oracle_twin(env, i)
+        oc = [c for c in e.contacts() if int(c[13]) == block and int(c[14]) == tool]
+        dc = [con[i, k] for k in range(abs(int(cnt[i]))) if int(con[i, k, 0]) == block and int(con[i, k, 1]) == tool]
+        assert len(oc) == len(dc) <= 1, (i, len(oc), len(dc))
+        if oc:
+            found += 1
+            assert abs(float(dc[0][2]) - oc[0][12]) < 2e-6, (i, float(dc[0][2]), oc[0][12])
+    print(f"cylinder - box: {found}/{N} poses with a detected contact, distances equal to 2e-6")
+    assert found >= 8
+    env.close()
