@@ -93,6 +93,7 @@ def main():
                   f"(min {float(d.min()):.3f} m, max {float(d.max()):.3f} m) on {d.device}")
         failed_now = active & ~env.last_converged
         names, counts = np.unique(env.failed_phase[failed_now].astype(str), return_counts=True)
+        names = [str(n) for n in names]
         alive &= env.last_converged | ~active   # (an idle env's no-op phases do not end an episode)
         nsim = 2 * 9000
         still = env.sort_colours(peek=True)[0]

@@ -1,0 +1,68 @@
+"""Why does 'Failed to move arm to pre pick position' hit 40 % of the envs in the SECOND pick / place pair with
+osc.yaml's gains (profiles/r04t_datagen_full_refgains.log) when the first pair converges in 98 %?  (GPU diagnostic)
+    python tests/diagnostics/dbg_second_pair.py [N=512]"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+from mujoco_robot_environments_amd.tasks.rearrangement import BatchedRearrangementEnv, colour_separator_task_config  # noqa: E402
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+env = BatchedRearrangementEnv(cfg=colour_separator_task_config(), num_envs=N, seed=3, solver="Newton")
+env.reset()
+cam = "overhead_camera/overhead_camera"
+log = []
+inner = env._phase
+
+
+def phase(name, duration):
+    conv = inner(name, duration)
+    c = env._robot.arm_controller
+    ep = np.linalg.norm(c.current_position_error(), axis=1)
+    eo = np.linalg.norm(c.current_orientation_error(), axis=1)
+    qp, qv = env.physics.get_state()
+    tcp, eef, props = env.physics.sites()
+    held = (props[:, :, 2] > 0.5).any(axis=1)          # a cube above 0.5 m: in the gripper
+    log.append((name, np.array(conv, bool).copy(), ep, eo, np.abs(qv[:, :7]).max(axis=1), held, qp[:, :7].copy(), qp[:, 7].copy()))
+    return conv
+
+
+env._phase = phase
+picks = []
+for pair in range(2):
+    prog, pick, place = env.sort_colours()
+    picks.append((pick.copy(), place.copy()))
+    env.last_converged[:] = True
+    a = {"pose": pick, "pixel_coords": env.world_2_pixel(cam, pick[:, :3]), "gripper_rot": 0.0}
+    env.step(a)
+    a = {"pose": place, "pixel_coords": env.world_2_pixel(cam, place[:, :3]), "gripper_rot": 0.0}
+    env.step(a)
+    print(f"pair {pair}: in progress {int(prog.sum())}")
+lim = np.asarray(env.model["jnt_range"])[1:8]
+for k, (name, conv, ep, eo, qv, held, q, grip) in enumerate(log):
+    bad = ~conv
+    nearlim = (np.minimum(q - lim[:, 0], lim[:, 1] - q) < 0.02).any(axis=1)
+    print(f"phase {k:2d} {name:45s}: not converged {int(bad.sum()):4d}/{N}; among them: pos err median {np.median(ep[bad]) if bad.any() else 0:.4f} "
+          f"(> 5e-3: {int((ep[bad] > 5e-3).sum())}), ori err median {np.median(eo[bad]) if bad.any() else 0:.4f} (> 68e-3: {int((eo[bad] > 68e-3).sum())}), "
+          f"max |qvel| median {np.median(qv[bad]) if bad.any() else 0:.3f}, cube held {int(held[bad].sum())}, a joint within 0.02 of a limit {int(nearlim[bad].sum())} "
+          f"| converged envs: cube held {int(held[conv].sum())}, near a limit {int(nearlim[conv].sum())}, gripper q median {np.median(grip):.3f}")
+
+# ---- what distinguishes the envs that go unstable in the second pre-pick (phase 10)?
+home = np.asarray(env.model["home_qpos"])
+bad10 = ~log[10][1]
+q9, q10 = log[9][6], log[10][6]
+print("\nend of phase 9 (home), |q - q_home| per joint: failing envs median", np.round(np.median(np.abs(q9[bad10] - home), axis=0), 3),
+      "| converging envs median", np.round(np.median(np.abs(q9[~bad10] - home), axis=0), 3))
+print("end of phase 10, joints within 0.02 of a limit (count per joint, failing envs):",
+      [(int(((q10[bad10][:, j] - lim[j, 0] < 0.02) | (lim[j, 1] - q10[bad10][:, j] < 0.02)).sum())) for j in range(7)])
+# pick targets of pair 1 vs pair 0: distance of the pick from the robot base and yaw of the grasp
+for pair in range(2):
+    pk, pl = picks[pair]
+    r = np.hypot(pk[:, 0], pk[:, 1]); rp = np.hypot(pl[:, 0], pl[:, 1])
+    print(f"pair {pair}: pick radius from the base median {np.median(r):.3f} (failing-in-phase-10 envs {np.median(r[bad10]):.3f}, others {np.median(r[~bad10]):.3f}); "
+          f"pick y median |y| failing {np.median(np.abs(pk[bad10, 1])):.3f} others {np.median(np.abs(pk[~bad10, 1])):.3f}; place radius {np.median(rp):.3f}; "
+          f"pick quat (w) failing {np.round(np.median(np.abs(pk[bad10, 3])), 3)} others {np.round(np.median(np.abs(pk[~bad10, 3])), 3)}")
+# which cube is picked in pair 1, and where it is (was it knocked about?)
+tcp, eef, props = env.physics.sites()
