@@ -1,0 +1,58 @@
+"""The oracle's own sensitivity (SOLVER=Newton|PGS, default Newton) on the bench law (256-env sample of tests/diagnostics/parity_sample.py): a
+1e-9 kick of every velocity at step 400, distance of the kicked fp64 run from the plain one at the end, per env.  Which
+envs amplify a float32-sized difference past the 1e-4 bar by themselves?   (CPU only)
+    [SOLVER=PGS] python tests/diagnostics/oracle_amplification.py [env ...]"""
+import concurrent.futures as cf
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+from mujoco_robot_environments_amd import rng  # noqa: E402
+from mujoco_robot_environments_amd.model import compile as MC  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+from tests.common import init_oracle_env  # noqa: E402
+
+O.build()
+om = O.Model(MC.to_blob(MC.compile_scene()))
+scale, seed, N, T, cs = 1.0, 5, 256, 200, 5
+ids = np.arange(N)
+nprops, sizes = rng.prop_params(seed, ids)
+acts = rng.random_actions(seed, ids, np.arange(T), scale=scale).astype(np.float32).astype(np.float64)
+yaws = rng.uniform(seed + 7, ids, [0], 4)[0] * np.pi
+
+
+def run(i, eps, at=400):
+    e = O.Env(om, int(nprops[i]), sizes[i])
+    e.set_solver(os.environ.get("SOLVER", "Newton"))
+    q0 = init_oracle_env(e, int(nprops[i]), sizes[i], z_extra=0.0005, yaw=yaws[i]).astype(np.float32)
+    e.arr("qpos")[:43] = q0
+    e.forward()
+    out = np.zeros((T * cs, 43))
+    r = np.random.default_rng(100 + i)
+    for t in range(T):
+        e.arr("ctrl")[:] = acts[t, i]
+        for k in range(cs):
+            if t * cs + k == at and eps:
+                e.arr("qvel")[:39] += eps * r.standard_normal(39)
+            e.step(1)
+            out[t * cs + k] = e.arr("qpos")[:43]
+    return out
+
+
+def amp(i):
+    d = np.abs(run(i, 0.0) - run(i, 1e-9))
+    n = 15 + 7 * int(nprops[i])
+    return i, d[450, :n].max(), d[700, :n].max(), d[999, :n].max(), d[400:, :n].max()
+
+
+envs = [int(x) for x in sys.argv[1:]] or ([128, 142, 254] + list(range(0, 64)))
+with cf.ThreadPoolExecutor(8) as ex:
+    res = list(ex.map(amp, envs))
+for r in res[:3] if not sys.argv[1:] else res:
+    print("env %d: max |dq| at 450 %.1e, 700 %.1e, 999 %.1e, over the run %.1e" % r)
+if not sys.argv[1:]:
+    m = np.array([r[4] for r in res[3:]])
+    print("envs 0..63: max |dq| quantiles 50 / 75 / 90 / 97 / 100 %%: %s" % " ".join(f"{np.quantile(m, q):.1e}" for q in (0.5, 0.75, 0.9, 0.97, 1.0)))
+    print("envs with more than 1e-7 (a hundredfold amplification of the kick's 1e-9):", [(r[0], f"{r[4]:.1e}") for r in res[3:] if r[4] > 1e-7])
