@@ -136,10 +136,11 @@ int mre_set_env_ids(mre_env*, const long long* ids);
 int mre_set_state(mre_env*, const float* qpos, const float* qvel);
 int mre_get_state(mre_env*, float* qpos, float* qvel);
 /* the same state as the reference holds it (physics.data.qpos / .qvel are float64): rows [N][MRE_NQ] /
- * [N][MRE_NV] of doubles, HOST pointers.  On the device the robot's 15 joints are double-float pairs (the float32
- * row entry + a low-order word: the soft closures of the 2F-85 four-bars amplify a float32 rounding of the state
- * past the 1e-4 parity bar within 1000 steps), the cubes' coordinates are float32.  mre_set_state (float rows)
- * clears the low-order words. */
+ * [N][MRE_NV] of doubles, HOST pointers.  On the device every coordinate is a double-float pair (the float32 row
+ * entry + a low-order word): the robot's 15 joints because the soft closures of the 2F-85 four-bars amplify a float32
+ * rounding of the state past the 1e-4 parity bar within 1000 steps, the cubes' poses and velocities (round 4) because
+ * the envs whose reference trajectory amplifies a difference a hundredfold do the same to a float32 random walk of a
+ * cube.  mre_set_state (float rows) clears the low-order words. */
 int mre_get_state_f64(mre_env*, double* qpos, double* qvel);
 int mre_set_state_f64(mre_env*, const double* qpos, const double* qvel);
 /* physics.data.time (models/robot_arm.py:68-69): seconds of physics since the last mre_reset, per env, host [N] */

@@ -55,7 +55,7 @@ struct mre_env {
   DevModel* dM = nullptr;
   DevModel hM;
   float *qpos = nullptr, *qvel = nullptr, *qacc_ws = nullptr, *ctrl = nullptr;
-  float* qfine = nullptr;   // [N][QFINE] low-order words of the robot's joint angles / velocities (StepArgs::qfine)
+  float* qfine = nullptr;   // [N][QFINE_ROW] low-order words of the state: robot joints, then cube poses and velocities (StepArgs::qfine)
   int *nstep = nullptr, *sv_nstep = nullptr;   // [N] physics steps since the last reset (physics.data.time)
   int* nprops = nullptr;
   float* prop_size = nullptr;
@@ -766,8 +766,8 @@ static int create_buffers(mre_env* e, int num_envs, int device_id) {
   HIPCHK(hipMemcpy(e->dM, &e->hM, sizeof(DevModel), hipMemcpyHostToDevice));
   HIPCHK(hipMalloc(&e->qpos, N * NQP * 4)); HIPCHK(hipMalloc(&e->qvel, N * NVP * 4));
   HIPCHK(hipMalloc(&e->qacc_ws, N * NVP * 4)); HIPCHK(hipMalloc(&e->ctrl, N * NU * 4));
-  HIPCHK(hipMalloc(&e->qfine, N * QFINE * 4)); HIPCHK(hipMalloc(&e->sv_qfine, N * QFINE * 4));
-  HIPCHK(hipMemsetAsync(e->qfine, 0, N * QFINE * 4, e->stream));
+  HIPCHK(hipMalloc(&e->qfine, N * QFINE_ROW * 4)); HIPCHK(hipMalloc(&e->sv_qfine, N * QFINE_ROW * 4));
+  HIPCHK(hipMemsetAsync(e->qfine, 0, N * QFINE_ROW * 4, e->stream));
   HIPCHK(hipMalloc(&e->nstep, N * 4)); HIPCHK(hipMalloc(&e->sv_nstep, N * 4));
   HIPCHK(hipMemsetAsync(e->nstep, 0, N * 4, e->stream));
   HIPCHK(hipMalloc(&e->nprops, N * 4)); HIPCHK(hipMalloc(&e->prop_size, N * NPROP * 3 * 4));
@@ -1217,8 +1217,16 @@ extern "C" int mre_set_state(mre_env* e, const float* qpos, const float* qvel) {
   if (qpos) rc = copy_in(e, e->qpos, qpos, (size_t)e->N * NQP * 4);
   if (!rc && qvel) rc = copy_in(e, e->qvel, qvel, (size_t)e->N * NVP * 4);
   // a float32 row IS the value: the low-order words of the robot's angles / velocities start from zero
-  if (!rc && qpos) HIPCHK(hipMemset2DAsync(e->qfine, QFINE * 4, 0, QFINE * 2, (size_t)e->N, e->stream));
-  if (!rc && qvel) HIPCHK(hipMemset2DAsync(e->qfine + QFINE / 2, QFINE * 4, 0, QFINE * 2, (size_t)e->N, e->stream));
+  // the float32 rows ARE the state now: the low-order words of what was overwritten go to zero (robot joints, cube poses /
+  // robot and cube velocities)
+  if (!rc && qpos) {
+    HIPCHK(hipMemset2DAsync(e->qfine, QFINE_ROW * 4, 0, QFINE * 2, (size_t)e->N, e->stream));
+    HIPCHK(hipMemset2DAsync(e->qfine + QFINE_CUBE_Q, QFINE_ROW * 4, 0, (QFINE_CUBE_V - QFINE_CUBE_Q) * 4, (size_t)e->N, e->stream));
+  }
+  if (!rc && qvel) {
+    HIPCHK(hipMemset2DAsync(e->qfine + QFINE / 2, QFINE_ROW * 4, 0, QFINE * 2, (size_t)e->N, e->stream));
+    HIPCHK(hipMemset2DAsync(e->qfine + QFINE_CUBE_V, QFINE_ROW * 4, 0, (QFINE_ROW - QFINE_CUBE_V) * 4, (size_t)e->N, e->stream));
+  }
   return rc;
 }
 
@@ -1228,16 +1236,16 @@ extern "C" int mre_get_state_f64(mre_env* e, double* qpos, double* qvel) {
   if (!e) return fail(MRE_ERR_ARG, "null handle");
   DRAIN(e);
   const size_t N = (size_t)e->N;
-  std::vector<float> hq(N * NQP), hv(N * NVP), hf(N * QFINE);
+  std::vector<float> hq(N * NQP), hv(N * NVP), hf(N * QFINE_ROW);
   int rc = copy_out(e, hq.data(), e->qpos, N * NQP * 4);
   if (!rc) rc = copy_out(e, hv.data(), e->qvel, N * NVP * 4);
-  if (!rc) rc = copy_out(e, hf.data(), e->qfine, N * QFINE * 4);
+  if (!rc) rc = copy_out(e, hf.data(), e->qfine, N * QFINE_ROW * 4);
   if (rc) return rc;
   for (size_t i = 0; i < N; i++) {
     if (qpos) for (int k = 0; k < NQ; k++)
-      qpos[i * NQ + k] = (double)hq[i * NQP + k] + (k < NRV ? (double)hf[i * QFINE + k] : 0.0);
+      qpos[i * NQ + k] = (double)hq[i * NQP + k] + (double)hf[i * QFINE_ROW + (k < NRV ? k : QFINE_CUBE_Q + (k - NRV))];
     if (qvel) for (int k = 0; k < NV; k++)
-      qvel[i * NV + k] = (double)hv[i * NVP + k] + (k < NRV ? (double)hf[i * QFINE + QFINE / 2 + k] : 0.0);
+      qvel[i * NV + k] = (double)hv[i * NVP + k] + (double)hf[i * QFINE_ROW + (k < NRV ? QFINE / 2 + k : QFINE_CUBE_V + (k - NRV))];
   }
   return MRE_OK;
 }
@@ -1245,26 +1253,26 @@ extern "C" int mre_set_state_f64(mre_env* e, const double* qpos, const double* q
   if (!e) return fail(MRE_ERR_ARG, "null handle");
   DRAIN(e);
   const size_t N = (size_t)e->N;
-  std::vector<float> hq(N * NQP), hv(N * NVP), hf(N * QFINE);
+  std::vector<float> hq(N * NQP), hv(N * NVP), hf(N * QFINE_ROW);
   int rc = copy_out(e, hq.data(), e->qpos, N * NQP * 4);
   if (!rc) rc = copy_out(e, hv.data(), e->qvel, N * NVP * 4);
-  if (!rc) rc = copy_out(e, hf.data(), e->qfine, N * QFINE * 4);
+  if (!rc) rc = copy_out(e, hf.data(), e->qfine, N * QFINE_ROW * 4);
   if (rc) return rc;
   for (size_t i = 0; i < N; i++) {
     if (qpos) for (int k = 0; k < NQ; k++) {
       const float hi = (float)qpos[i * NQ + k];
       hq[i * NQP + k] = hi;
-      if (k < NRV) hf[i * QFINE + k] = (float)(qpos[i * NQ + k] - (double)hi);
+      hf[i * QFINE_ROW + (k < NRV ? k : QFINE_CUBE_Q + (k - NRV))] = (float)(qpos[i * NQ + k] - (double)hi);
     }
     if (qvel) for (int k = 0; k < NV; k++) {
       const float hi = (float)qvel[i * NV + k];
       hv[i * NVP + k] = hi;
-      if (k < NRV) hf[i * QFINE + QFINE / 2 + k] = (float)(qvel[i * NV + k] - (double)hi);
+      hf[i * QFINE_ROW + (k < NRV ? QFINE / 2 + k : QFINE_CUBE_V + (k - NRV))] = (float)(qvel[i * NV + k] - (double)hi);
     }
   }
   rc = copy_in(e, e->qpos, hq.data(), N * NQP * 4);
   if (!rc) rc = copy_in(e, e->qvel, hv.data(), N * NVP * 4);
-  if (!rc) rc = copy_in(e, e->qfine, hf.data(), N * QFINE * 4);
+  if (!rc) rc = copy_in(e, e->qfine, hf.data(), N * QFINE_ROW * 4);
   if (!rc) HIPCHK(hipStreamSynchronize(e->stream));   // (the staged rows must outlive the uploads)
   return rc;
 }
@@ -1579,7 +1587,7 @@ static int search_buffers(mre_env* e) {
 }
 static void fill_search(mre_env* e, SearchArgs& sa) {
   memset(&sa, 0, sizeof(sa));
-  sa.M = e->dM; sa.N = e->N; sa.qpos = e->qpos; sa.nprops = e->nprops; sa.prop_size = e->prop_size;
+  sa.M = e->dM; sa.N = e->N; sa.qpos = e->qpos; sa.qfine = e->qfine; sa.nprops = e->nprops; sa.prop_size = e->prop_size;
   sa.env_ids = e->d_env_ids; sa.env_id_offset = e->env_id_offset;
   sa.attempts = e->ps_attempts; sa.fixed_prop = -1;
 }
@@ -1669,6 +1677,13 @@ extern "C" int mre_place_props(mre_env* e, const uint8_t* mask, uint64_t seed, c
           q[3] = 1.f; q[4] = q[5] = q[6] = 0.f;
         }
     if ((rc = copy_in(e, e->qpos, qp.data(), qp.size() * 4)) || (rc = copy_in(e, e->mask, todo.data(), N))) return rc;
+    {   // the parked poses and the velocities written here are float32 values: their low-order words are zero
+      std::vector<float> hf(N * QFINE_ROW);
+      if ((rc = copy_out(e, hf.data(), e->qfine, hf.size() * 4))) return rc;
+      for (size_t i = 0; i < N; i++)
+        if (todo[i]) for (int k = QFINE_CUBE_Q; k < QFINE_ROW; k++) hf[i * QFINE_ROW + k] = 0.f;
+      if ((rc = copy_in(e, e->qfine, hf.data(), hf.size() * 4))) return rc;
+    }
     if (round > 0) {   // a second try starts from rest
       std::vector<float> z(N * NVP, 0.f), qv(N * NVP);
       if ((rc = copy_out(e, qv.data(), e->qvel, qv.size() * 4))) return rc;

@@ -18,7 +18,14 @@ constexpr int NQP = 44;    // padded qpos row
 constexpr int TRACE_W = 48; // row of the parity trace: qpos[43], constraint census, contact-set hash, solution-state hash, pad (MRE_TRACE_W)
 constexpr int NVP = 40;    // padded qvel row
 constexpr int NU = 8;
-constexpr int QFINE = 32;  // row of low-order state words: robot joint angles [0:15], velocities [16:31] (StepArgs::qfine)
+constexpr int QFINE = 32;  // low-order state words of the robot kept in LDS: joint angles [0:15], velocities [16:31]
+// row of StepArgs::qfine in HBM: the robot's words, then the cubes' -- pose (position + quaternion) of cube p at
+// [QFINE_CUBE_Q + 7 p, +7), velocity at [QFINE_CUBE_V + 6 p, +6).  The cubes' words never enter LDS: the integrator
+// reads and writes them in place once per step (round 4: the cubes' state is a double-float pair like the robot's).
+constexpr int QFINE_ROW = 96;
+constexpr int QFINE_CUBE_Q = 32;
+constexpr int QFINE_CUBE_V = 60;
+static_assert(QFINE_CUBE_Q + 7 * 4 == QFINE_CUBE_V && QFINE_CUBE_V + 6 * 4 <= QFINE_ROW, "qfine row layout");
 constexpr int NPROP = 4;
 constexpr int NG = 20;     // geoms: ground, table, robot hulls + pads, 4 cubes, then the hulls of arm links 1..4
 constexpr int PROP_GEOM0 = 12;  // geom id of cube 0 (cubes 12..15; checked against the blob in mre_create)
@@ -168,7 +175,7 @@ struct StepArgs {
   float* qpos;            // [N][NQP]
   float* qvel;            // [N][NVP]
   float* qacc_ws;         // [N][NVP]
-  float* qfine;           // [N][QFINE] or null: low-order words of the robot's state -- its 15 joint angles
+  float* qfine;           // [N][QFINE_ROW] or null: low-order words of the robot's state -- its 15 joint angles
                           //  [0:15] and their velocities [16:31] are carried as unevaluated sums hi + lo of two
                           //  floats (hi = the qpos / qvel row entry, i.e. the value rounded to float32)
   float* ctrl;            // [N][NU]  (held control / last applied control)
@@ -246,6 +253,7 @@ struct SearchArgs {
   double fixed_quat[4];
   float max_dist;            // +inf: any detected contact rejects (PropPlacer); 0.05: prop_place
   int commit;                // 1: the accepted pose is written to qpos (PropPlacer); 0: state untouched
+  float* qfine;              // [N][QFINE_ROW] or null: with commit, the low-order words of the accepted fp64 pose
   double* pose;              // [N][7] accepted pose (xyz fp64, quat) or null
   int* attempts;             // [N]: attempts used (>= 1); -max_attempts: none accepted; 0: env skipped
 };

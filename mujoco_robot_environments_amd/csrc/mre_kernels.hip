@@ -293,8 +293,12 @@ MRE_DEV void kinematics(ModelP M, Sm& s, int l, BodyRegs& br) {
     const int qa = M->body_qposadr[b];
     v3copy(mine.p, &s.qpos[qa]);
     for (int k = 0; k < 4; k++) mine.q[k] = s.qpos[qa + 3 + k];
+    // mj_kinematics normalises the quaternion in qpos.  The state is a double-float pair that the integrator keeps at
+    // unit length to 1e-16 (the float32 word alone is off by its rounding, 6e-8): only a quaternion that is really not
+    // normalised -- handed in by the caller, whose low words are zero -- is written back.
+    const float n2 = mine.q[0] * mine.q[0] + mine.q[1] * mine.q[1] + mine.q[2] * mine.q[2] + mine.q[3] * mine.q[3];
     qnormalize(mine.q);
-    if (WRITEBACK) for (int k = 0; k < 4; k++) s.qpos[qa + 3 + k] = mine.q[k];
+    if (WRITEBACK && fabsf(n2 - 1.f) > 1e-5f) for (int k = 0; k < 4; k++) s.qpos[qa + 3 + k] = mine.q[k];
     q2mat(mine.m, mine.q);
     v3copy(br.anchor, mine.p);
     br.axis[0] = 0.f; br.axis[1] = 0.f; br.axis[2] = 1.f;
@@ -1171,7 +1175,13 @@ MRE_PHASE_FN void integrate_setup(ModelP M, Sm& s, int l, unsigned act_clamped) 
 }
 
 // part 2 (after the solve of MH x = f, also run from the kernel body): advance velocities and positions
-MRE_PHASE_FN void integrate(ModelP M, Sm& s, int l, unsigned flags, bool polished) {
+// clo: the cubes' low-order state words of this env in HBM (row of StepArgs::qfine from QFINE_CUBE_Q on) or null.
+// With them a cube's pose and velocity advance in fp64 on the double-float pair, like the robot's joints: a float32
+// position is off by up to 3e-8 m after every step, a random walk that the envs whose reference trajectory amplifies a
+// difference a hundredfold (cubes knocked flying by the arm) take past the 1e-4 bar -- the fp64 oracle with ONLY the
+// cubes' state rounded to float32 leaves it in exactly the two cube exits of the 256-env sample, and with the cubes'
+// state in double it does not (profiles/NOTES.md, round 4).
+MRE_PHASE_FN void integrate(ModelP M, Sm& s, int l, unsigned flags, bool polished, float* clo) {
   const float h = M->timestep;
   const bool freeze = (flags & F_FREEZE_ROBOT) != 0;
   if (l < NV) {
@@ -1188,7 +1198,16 @@ MRE_PHASE_FN void integrate(ModelP M, Sm& s, int l, unsigned flags, bool polishe
         s.qvel[l] = hi; s.qlo[QFINE / 2 + l] = (float)(v - (double)hi);
       }
     } else if (body_is_active(M, s, b)) {
-      s.qvel[l] += h * s.qacc[l];  // free joints carry no damping: MH = M on cube blocks
+      // free joints carry no damping: MH = M on cube blocks
+      if (clo != nullptr) {
+        float* const vl = clo + (QFINE_CUBE_V - QFINE_CUBE_Q) + (l - NRV);
+        const double v = (double)s.qvel[l] + (double)*vl + (double)h * (double)s.qacc[l];
+        const float hi = (float)v, lo = (float)(v - (double)hi);
+        s.qvel[l] = hi; *vl = lo;
+        s.scratch[l] = lo;   // (scratch[NRV ..]: free here; the body lanes below read the new low words from it)
+      } else {
+        s.qvel[l] += h * s.qacc[l];
+      }
     }
   }
   MRE_SYNC();
@@ -1199,6 +1218,38 @@ MRE_PHASE_FN void integrate(ModelP M, Sm& s, int l, unsigned flags, bool polishe
         const double q = robot_q(s, qa) + (double)h * robot_v(s, da);
         const float hi = (float)q;
         s.qpos[qa] = hi; s.qlo[qa] = (float)(q - (double)hi);
+      }
+    } else if (body_is_active(M, s, b) && clo != nullptr) {
+      // mj_integratePos of a free joint on the double-float state: position, then q <- normalize(q (x) exp(h w / 2))
+      float* const ql = clo + 7 * (b - NRB);
+      double vv[6];
+      for (int k = 0; k < 6; k++) vv[k] = (double)s.qvel[da + k] + (double)s.scratch[da + k];
+      for (int k = 0; k < 3; k++) {
+        const double x = (double)s.qpos[qa + k] + (double)ql[k] + (double)h * vv[k];
+        const float hi = (float)x;
+        s.qpos[qa + k] = hi; ql[k] = (float)(x - (double)hi);
+      }
+      double q0[4], qn[4];
+      for (int k = 0; k < 4; k++) q0[k] = (double)s.qpos[qa + 3 + k] + (double)ql[3 + k];
+      const double wn2 = vv[3] * vv[3] + vv[4] * vv[4] + vv[5] * vv[5];
+      if (wn2 > 1e-60) {
+        const double inv = rsq64(wn2), half = 0.5 * (double)h * wn2 * inv;
+        double sn, cs;
+        sincos_poly_d(half, sn, cs);
+        const double ax = vv[3] * inv * sn, ay = vv[4] * inv * sn, az = vv[5] * inv * sn;
+        qn[0] = q0[0] * cs - q0[1] * ax - q0[2] * ay - q0[3] * az;
+        qn[1] = q0[0] * ax + q0[1] * cs + q0[2] * az - q0[3] * ay;
+        qn[2] = q0[0] * ay - q0[1] * az + q0[2] * cs + q0[3] * ax;
+        qn[3] = q0[0] * az + q0[1] * ay - q0[2] * ax + q0[3] * cs;
+      } else {
+        for (int k = 0; k < 4; k++) qn[k] = q0[k];
+      }
+      const double nn = qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3];
+      const double sc = nn > 1e-30 ? rsq64(nn) : 1.0;
+      for (int k = 0; k < 4; k++) {
+        const double x = qn[k] * sc;
+        const float hi = (float)x;
+        s.qpos[qa + 3 + k] = hi; ql[3 + k] = (float)(x - (double)hi);
       }
     } else if (body_is_active(M, s, b)) {
       for (int k = 0; k < 3; k++) s.qpos[qa + k] += h * s.qvel[da + k];
@@ -1268,10 +1319,12 @@ MRE_DEV void step_body(const StepArgs& a, Sm& s) {
     if (save) { a.sv_qvel[(size_t)env * NVP + l] = v; a.sv_qacc_ws[(size_t)env * NVP + l] = w; }
   }
   if (l < QFINE) {
-    const float v = a.qfine != nullptr ? a.qfine[(size_t)env * QFINE + l] : 0.f;
+    const float v = a.qfine != nullptr ? a.qfine[(size_t)env * QFINE_ROW + l] : 0.f;
     s.qlo[l] = v;
-    if (save && a.qfine != nullptr) a.sv_qfine[(size_t)env * QFINE + l] = v;
+    if (save && a.qfine != nullptr) a.sv_qfine[(size_t)env * QFINE_ROW + l] = v;
   }
+  if (save && a.qfine != nullptr && l < QFINE_ROW - QFINE)   // the cubes' words stay in HBM; the restore point takes a copy
+    a.sv_qfine[(size_t)env * QFINE_ROW + QFINE + l] = a.qfine[(size_t)env * QFINE_ROW + QFINE + l];
   if (l < NU) {
     const float v = a.ctrl[(size_t)env * NU + l];
     s.ctrl[l] = v;
@@ -1400,7 +1453,7 @@ MRE_DEV void step_body(const StepArgs& a, Sm& s) {
 
     integrate_setup(M, s, l, clamped);
     factor_solve_robot(s.qLD, s.scratch, l);
-    integrate(M, s, l, a.flags, polished);
+    integrate(M, s, l, a.flags, polished, a.qfine != nullptr ? a.qfine + (size_t)env * QFINE_ROW + QFINE_CUBE_Q : nullptr);
     steps_done = step + 1;
     if ((a.flags & F_SETTLE_EXIT) != 0) {
       // PropPlacer's settle test on this env's own cubes (prop_initializer.py:247-258)
@@ -1524,7 +1577,7 @@ MRE_DEV void step_body(const StepArgs& a, Sm& s) {
     a.qvel[(size_t)env * NVP + l] = s.qvel[l];
     a.qacc_ws[(size_t)env * NVP + l] = l < NV ? s.qacc[l] : 0.f;
   }
-  if (l < QFINE && a.qfine != nullptr) a.qfine[(size_t)env * QFINE + l] = s.qlo[l];
+  if (l < QFINE && a.qfine != nullptr) a.qfine[(size_t)env * QFINE_ROW + l] = s.qlo[l];
   if (l < NU) a.ctrl[(size_t)env * NU + l] = s.ctrl[l];
   if (l == 0 && a.launch_info != nullptr) {
     int* li = a.launch_info + (size_t)env * 4;
@@ -1616,7 +1669,7 @@ __global__ __launch_bounds__(64) void k_reset(const DevModel* M, int N, float* q
     qpos[(size_t)env * NQP + l] = v;
   }
   if (l < NVP) { qvel[(size_t)env * NVP + l] = 0.f; qacc_ws[(size_t)env * NVP + l] = 0.f; }
-  if (l < QFINE) qfine[(size_t)env * QFINE + l] = 0.f;
+  for (int k = l; k < QFINE_ROW; k += 64) qfine[(size_t)env * QFINE_ROW + k] = 0.f;
   if (l < NU) ctrl[(size_t)env * NU + l] = 0.f;
   if (l == 0) { status[env] = 0u; nstep[env] = 0; }   // Physics.reset(): data.time = 0
 }
@@ -1728,6 +1781,11 @@ __global__ __launch_bounds__(64) void k_pose_search(SearchArgs a) {
       if (a.commit) {
         float* q = a.qpos + (size_t)env * NQP + NRV + 7 * p;
         for (int k = 0; k < 7; k++) q[k] = (float)pose[k];
+        if (a.qfine != nullptr) {   // the accepted pose is an fp64 draw: its low-order words go with it, the cube starts at rest
+          float* ql = a.qfine + (size_t)env * QFINE_ROW;
+          for (int k = 0; k < 7; k++) ql[QFINE_CUBE_Q + 7 * p + k] = (float)(pose[k] - (double)(float)pose[k]);
+          for (int k = 0; k < 6; k++) ql[QFINE_CUBE_V + 6 * p + k] = 0.f;
+        }
       }
     }
   }
@@ -1804,7 +1862,7 @@ __global__ __launch_bounds__(64) void k_restore_rows(const uint8_t* sel, int env
     qvel[(size_t)env * NVP + l] = sv_qvel[(size_t)env * NVP + l];
     qacc_ws[(size_t)env * NVP + l] = sv_qacc_ws[(size_t)env * NVP + l];
   }
-  if (l < QFINE) qfine[(size_t)env * QFINE + l] = sv_qfine[(size_t)env * QFINE + l];
+  for (int k = l; k < QFINE_ROW; k += 64) qfine[(size_t)env * QFINE_ROW + k] = sv_qfine[(size_t)env * QFINE_ROW + k];
   if (l < NU) ctrl[(size_t)env * NU + l] = sv_ctrl[(size_t)env * NU + l];
   if (l == 0) { status[env] = sv_status[env]; converged[env] = sv_converged[env]; nstep[env] = sv_nstep[env]; }
 }

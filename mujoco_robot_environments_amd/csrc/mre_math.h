@@ -235,4 +235,19 @@ MRE_DEV float wave_max(float v) {
 }
 MRE_DEV float clampf(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
+// fp64 reciprocal and reciprocal square root (PGS: robot-contact block update; integrator: the cubes' quaternions): the hardware estimates (v_rcp_f64 /
+// v_rsq_f64, ~2^-26 relative) + two Newton steps = 1e-16, a third of the instructions of the IEEE division / sqrt
+// sequences with their scaling and fix-up steps (operands here are never denormal, zero or infinite: guarded by the callers)
+MRE_DEV double rcp64(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = r * (2.0 - x * r);
+  return r * (2.0 - x * r);
+}
+MRE_DEV double rsq64(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  y = y * (1.5 - 0.5 * x * y * y);
+  return y * (1.5 - 0.5 * x * y * y);
+}
+
+
 }  // namespace mre

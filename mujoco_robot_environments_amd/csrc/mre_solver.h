@@ -710,20 +710,6 @@ MRE_DEV void build_schedule(ModelP M, Sm& s) {
   s.nsched = nst;
 }
 
-// fp64 reciprocal and reciprocal square root for the robot-contact block update: the hardware estimates (v_rcp_f64 /
-// v_rsq_f64, ~2^-26 relative) + two Newton steps = 1e-16, a third of the instructions of the IEEE division / sqrt
-// sequences with their scaling and fix-up steps (operands here are never denormal, zero or infinite: guarded by the callers)
-MRE_DEV double rcp64(double x) {
-  double r = __builtin_amdgcn_rcp(x);
-  r = r * (2.0 - x * r);
-  return r * (2.0 - x * r);
-}
-MRE_DEV double rsq64(double x) {
-  double y = __builtin_amdgcn_rsq(x);
-  y = y * (1.5 - 0.5 * x * y * y);
-  return y * (1.5 - 0.5 * x * y * y);
-}
-
 // ------------------------------------------------------------- mj_fwdConstraint
 // On exit: s.qacc = qacc_smooth + M^-1 J' f, s.qfrc_con = J' f.
 // PYR: pyramidal friction cones (opt.cone == 0); the two instantiations are separate phase functions, so the

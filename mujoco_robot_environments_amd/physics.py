@@ -181,8 +181,8 @@ class BatchedPhysics:
         return self.get_state()[0]
 
     def get_state_f64(self):
-        """physics.data.qpos / .qvel as float64 [N, 43] / [N, 39]: the finger joints with the low-order words the
-        device carries for them (mre_get_state_f64), every other coordinate the float32 value."""
+        """physics.data.qpos / .qvel as float64 [N, 43] / [N, 39]: float32 word + the low-order word the device carries
+        for every coordinate (robot joints and cube poses / velocities are double-float pairs; mre_get_state_f64)."""
         q = np.empty((self.num_envs, MRE_NQ), np.float64)
         v = np.empty((self.num_envs, MRE_NV), np.float64)
         check(_lib.lib().mre_get_state_f64(self._h, _ptr(q), _ptr(v)), "mre_get_state_f64")

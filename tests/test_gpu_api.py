@@ -408,9 +408,9 @@ def test_placement_failure_is_per_env(compiled_model):
 
 
 def test_state_f64_and_time(compiled_model):
-    """physics.data.qpos / .qvel / .time as the reference holds them (float64): the robot's 15 joints are
-    double-float pairs on the device, mre_set_state (float rows) clears their low-order words, and time counts the
-    physics steps since mre_reset (models/robot_arm.py:68-69)."""
+    """physics.data.qpos / .qvel / .time as the reference holds them (float64): every coordinate -- the robot's 15 joints
+    and, since round 4, the cubes' poses and velocities -- is a double-float pair on the device, mre_set_state (float
+    rows) clears the low-order words, and time counts the physics steps since mre_reset (models/robot_arm.py:68-69)."""
     from mujoco_robot_environments_amd.physics import BatchedPhysics
     A, _ = compiled_model
     N = 8
@@ -425,12 +425,13 @@ def test_state_f64_and_time(compiled_model):
     phys.set_state_f64(q, v)
     q1, v1 = phys.get_state_f64()
     assert np.abs(q1[:, :15] - q[:, :15]).max() < 1e-14 and np.abs(v1[:, :15] - v[:, :15]).max() < 1e-14   # hi + lo
-    assert np.array_equal(q1[:, 15:], q[:, 15:].astype(np.float32).astype(np.float64))                       # cubes: float32
+    n = 15 + 7 * 2                                                                                           # two cubes in use
+    assert np.abs(q1[:, 15:n] - q[:, 15:n]).max() < 1e-13 and np.abs(v1[:, 15:27] - v[:, 15:27]).max() < 1e-14
     qf, vf = phys.get_state()
     assert np.array_equal(qf[:, :15], q[:, :15].astype(np.float32))        # the float rows ARE the rounded values
     phys.set_state(qf, vf)                                                 # a float32 state is the value: lo = 0
     q2, _ = phys.get_state_f64()
-    assert np.array_equal(q2[:, :15], qf[:, :15].astype(np.float64))
+    assert np.array_equal(q2, qf.astype(np.float64)[:, :43])
     phys.set_state_f64(q0, np.zeros((N, 39)))
     phys.set_control(np.zeros((N, 8), np.float32))
     phys.step(7)
@@ -439,6 +440,8 @@ def test_state_f64_and_time(compiled_model):
     q3, v3 = phys.get_state_f64()
     lo = q3[:, :15] - q3[:, :15].astype(np.float32)
     assert (lo != 0).any() and np.abs(lo).max() < 3e-7     # the integrator keeps bits below float32's last place
+    loc = q3[:, 15:18] - q3[:, 15:18].astype(np.float32)   # ... for the falling cubes too
+    assert (loc != 0).any() and np.abs(loc).max() < 3e-7
     phys.reset()
     assert (phys.time() == 0).all()
 
