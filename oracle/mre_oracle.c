@@ -1330,6 +1330,11 @@ static void fwd_position(const mro_model* m, mro_data* d) {
   make_constraint(m, d);
   if (d->round32 & 1) for (int i = 0; i < d->nefc; i++) round32(d->efc_J[i], m->nv);
   if (d->round32 & 64) round32(d->efc_pos, d->nefc);
+  /* 1024: contact distances with the ABSOLUTE rounding of float32 world coordinates (a distance formed as a difference
+   * of 0.4 m coordinates is good to 3e-8 m, not to 1e-7 of its own size) */
+  if (d->round32 & 1024)
+    for (int i = 0; i < d->nefc; i++)
+      if (d->efc_type[i] == EFC_CONTACT || d->efc_type[i] == EFC_PYRAMID) d->efc_pos[i] = (double)(float)(d->efc_pos[i] + 0.4) - 0.4;
   make_impedance(m, d);
   if (d->round32 & 128) { round32(d->efc_R, d->nefc); for (int i = 0; i < d->nefc; i++) d->efc_D[i] = 1.0 / d->efc_R[i]; }
   /* (AR = J M^-1 J' + R exists for the dual solvers only: mj_projectConstraint is skipped under Newton) */

@@ -55,7 +55,8 @@ void mro_step(const mro_model*, mro_data*, int nstep);
 void mro_set_freeze_robot(mro_data*, int freeze);
 /* Diagnostic (tests/diagnostics/finger_precision_study.py): round intermediate arrays to float32 where they are
  * produced -- 1 efc_J, 2 efc_aref, 4 qM, 8 qfrc_smooth + qacc_smooth, 16 qacc + qfrc_constraint (solver output),
- * 32 the implicit integrator's acceleration, 64 efc_pos, 128 efc_R / efc_D, 256 qfrc_bias.  0 = the plain fp64 oracle. */
+ * 32 the implicit integrator's acceleration, 64 efc_pos, 128 efc_R / efc_D, 256 qfrc_bias, 1024 contact distances at the
+ * absolute resolution of float32 world coordinates (0.4 m).  0 = the plain fp64 oracle. */
 void mro_set_round32(mro_data*, int mask);
 /* Diagnostic (tests/diagnostics/pgs_precision_study.py): PGS run matrix-free with float32 roundings like the
  * device's, selected quantities kept in double (mask bits: mre_oracle.c, sol_pgs_emu).  0 = mj_solPGS on the explicit AR. */
