@@ -104,7 +104,7 @@ struct mro_data {
   int pgs_emu;   /* diagnostic (mro_set_pgs_emulation): device-like matrix-free PGS, see sol_pgs_emu */
   int round32;   /* diagnostic (mro_set_round32): intermediate arrays rounded to float32, see mre_oracle.h */
   /* diagnostic (mro_set_emulation): a device-like error on the solver's output and the device's cure for it */
-  double emu_rel_arm, emu_abs_finger, emu_abs_bias;
+  double emu_rel_arm, emu_abs_finger, emu_abs_bias, emu_rel_cube;
   int emu_polish;
   unsigned long long emu_rng;
   int body_active[MRO_MAXB], dof_active[MRO_MAXV];
@@ -2230,6 +2230,7 @@ static void emulate_device_solver(const mro_model* m, mro_data* d) {
   memcpy(a, d->qacc, sizeof(double) * nv);
   for (int k = 0; k < 7; k++) a[k] *= 1.0 + d->emu_rel_arm * emu_gauss(d);
   for (int k = 7; k < 15; k++) a[k] += d->emu_abs_finger * emu_gauss(d);
+  for (int k = 15; k < nv; k++) a[k] *= 1.0 + d->emu_rel_cube * emu_gauss(d);   /* a float32 solve of the cube blocks */
   int lo = d->emu_polish == 2 ? 0 : 7, nb = 15 - lo;
   for (int it = 0; d->emu_polish && it < 3; it++) {
     mul_jac(d, nv, jar, a);
@@ -2281,6 +2282,7 @@ static void emulate_device_solver(const mro_model* m, mro_data* d) {
   for (int k = 0; k < nv; k++) d->qfrc_constraint[k] = Ma[k] - d->qfrc_smooth[k];
 }
 
+void mro_set_cube_noise(mro_data* d, double rel_cube) { d->emu_rel_cube = rel_cube; if (!d->emu_rng) d->emu_rng = 0x2545F4914F6CDD1Dull; }
 void mro_set_bias_noise(mro_data* d, double abs_bias) { d->emu_abs_bias = abs_bias; if (!d->emu_rng) d->emu_rng = 0x2545F4914F6CDD1Dull; }
 static void step2(const mro_model* m, mro_data* d) {
   MRO_STAGE(FS_ACTUATION_ACC);
@@ -2290,7 +2292,7 @@ static void step2(const mro_model* m, mro_data* d) {
   fwd_constraint(m, d);
   d->state_hash = state_hash_eval(m, d);
   MRO_STAGE(FS_INTEGRATE);
-  if (d->emu_rel_arm > 0 || d->emu_abs_finger > 0 || d->emu_polish) emulate_device_solver(m, d);
+  if (d->emu_rel_arm > 0 || d->emu_abs_finger > 0 || d->emu_rel_cube > 0 || d->emu_polish) emulate_device_solver(m, d);
   if (d->round32 & 16) { round32(d->qacc, m->nv); round32(d->qfrc_constraint, m->nv); }
   integrate(m, d);
   MRO_STAGE(FS_OTHER);

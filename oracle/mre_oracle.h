@@ -68,6 +68,8 @@ void mro_set_pgs_emulation(mro_data*, int mask);
 void mro_set_emulation(mro_data*, double rel_arm, double abs_finger, int polish, unsigned long long seed);
 /* Diagnostic: Gaussian error of `abs_bias` N m on the finger rows of qfrc_smooth (a float32 bias force) */
 void mro_set_bias_noise(mro_data*, double abs_bias);
+/* Diagnostic: Gaussian relative error `rel_cube` on the cubes' accelerations after every solve (a float32 solve) */
+void mro_set_cube_noise(mro_data*, double rel_cube);
 /* test switches: drop all constraints (smooth-dynamics parity slice); emulate the
  * device capacity limits (active contacts / rows beyond the caps are dropped) */
 void mro_set_no_constraints(mro_data*, int flag);

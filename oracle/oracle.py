@@ -77,6 +77,7 @@ def lib() -> C.CDLL:
         L.mro_set_pgs_emulation.argtypes = [C.c_void_p, C.c_int]
         L.mro_set_emulation.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_ulonglong]
         L.mro_set_bias_noise.argtypes = [C.c_void_p, C.c_double]
+        L.mro_set_cube_noise.argtypes = [C.c_void_p, C.c_double]
         L.mro_set_caps.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
         L.mro_overflow.argtypes = [C.c_void_p]
         L.mro_set_solver.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double]
@@ -167,6 +168,10 @@ class Env:
     def pgs_emulation(self, mask: int):
         """Diagnostic: device-like float32 PGS (mro_set_pgs_emulation)."""
         lib().mro_set_pgs_emulation(self.ptr, int(mask))
+
+    def cube_noise(self, rel: float):
+        """Diagnostic: relative Gaussian error on the cubes' accelerations after every solve (mro_set_cube_noise)."""
+        lib().mro_set_cube_noise(self.ptr, float(rel))
 
     def round32(self, mask: int):
         """Diagnostic: round intermediate arrays to float32 (bit mask, oracle/mre_oracle.h)."""
