@@ -172,6 +172,8 @@ def cpu_baseline(seed, budget_s=12.0, nenv=64):
     dt2 = time.perf_counter() - t2
     return {"finite_envs": finite, "value": nenv * ticks * CONTROL_STEPS / dt, "unit": "env-steps/s", "cores": threads,
             "pgs_value": nenv * ticks2 * CONTROL_STEPS / dt2,
+            "pgs_sample": f"the same envs right after the Newton sample (ticks {ticks + ticks1}..{ticks + ticks1 + ticks2}: arms on the "
+                          "table, the heaviest regime; from rest the PGS oracle runs at twice this rate)",
             "kind": "port", "sample": f"{nenv} envs x {ticks} ticks x {CONTROL_STEPS} steps, fp64 oracle "
             f"(Newton, same scene / actions as the headline), OpenMP {threads} threads, {dt:.1f} s",
             "single_thread_value": 4 * ticks1 * CONTROL_STEPS / dt1}
