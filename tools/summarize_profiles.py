@@ -91,9 +91,24 @@ def main():
         summary["VGPR_Count"] = int(rows[0]["VGPR_Count"])
         summary["Accum_VGPR_Count"] = int(rows[0]["Accum_VGPR_Count"])
         summary["Scratch_Size"] = int(rows[0]["Scratch_Size"])
-    summary["hbm_read_bytes_per_launch"] = summary["FETCH_SIZE_per_launch"] * 1024.0
-    summary["hbm_write_bytes_per_launch"] = summary["WRITE_SIZE_per_launch"] * 1024.0
+    # MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reads half the bytes of a streaming read, and "other access widths are
+    # uncalibrated: calibrate on a known byte count in your own access pattern".  tools/pmc_calibrate.hip did, for the
+    # step kernels' pattern (one wave moves one row of 44 floats): FETCH_SIZE x 1.22, WRITE_SIZE x 0.917; dword- and
+    # 16-B-per-lane streaming reads both x 2.0, streaming writes exact (profiles/*_pmc_calibration.json).
+    cal = sorted(glob.glob(os.path.join(out, "*_pmc_calibration.json")))
+    f_read, f_write, f_read_stream = 1.0, 1.0, 2.0
+    if cal:
+        with open(cal[-1]) as f:
+            c = json.load(f)
+        f_read = c.get("FETCH_SIZE k_rows44", {}).get("factor") or 1.0
+        f_write = c.get("WRITE_SIZE k_rows44", {}).get("factor") or 1.0
+        f_read_stream = c.get("FETCH_SIZE k_read_dword", {}).get("factor") or 2.0
+        summary["calibration"] = {"file": os.path.basename(cal[-1]), "read_rows": f_read, "write_rows": f_write, "read_streaming": f_read_stream}
+    summary["hbm_read_bytes_per_launch"] = summary["FETCH_SIZE_per_launch"] * 1024.0 * f_read
+    summary["hbm_write_bytes_per_launch"] = summary["WRITE_SIZE_per_launch"] * 1024.0 * f_write
     summary["traffic_bytes_per_launch"] = summary["hbm_read_bytes_per_launch"] + summary["hbm_write_bytes_per_launch"]
+    # upper bound: every read counted like a streaming one
+    summary["traffic_bytes_per_launch_upper"] = summary["FETCH_SIZE_per_launch"] * 1024.0 * f_read_stream + summary["hbm_write_bytes_per_launch"]
     g = lambda k: summary.get(f"SQ_INSTS_VALU_{k}_per_launch", 0.0)
     if "SQ_INSTS_VALU_per_launch" in summary:
         # VALU issue: a wave64 VALU instruction holds its SIMD for 4 cycles; 1024 SIMDs at 2.4 GHz
@@ -108,9 +123,9 @@ def main():
         # matrix-core work of the Newton Hessian (v_mfma_f32_16x16x4_f32).  MI355X_MICROARCH.md: the MOPS counters
         # count in units of 512 flops per wave instruction
         summary["mfma_flop_f32_per_launch"] = 512.0 * summary["SQ_INSTS_VALU_MFMA_MOPS_F32_per_launch"]
-    summary["note"] = ("FETCH_SIZE/WRITE_SIZE are in KiB. The gfx950 x2 FETCH_SIZE correction applies to 16-B-per-lane "
-                       "streaming reads; this kernel reads dword rows, so the read figure is reported uncorrected "
-                       "(upper bound with the correction: 2x).")
+    summary["note"] = ("FETCH_SIZE/WRITE_SIZE are in KiB; traffic = FETCH_SIZE x read_rows + WRITE_SIZE x write_rows with the factors "
+                       "calibrated on a known byte count in this kernel's access pattern (tools/pmc_calibrate.hip: one wave moves "
+                       "one row of 44 floats); traffic_bytes_per_launch_upper counts every read like a streaming one (x 2).")
     with open(os.path.join(out, f"{tag}_pmc_summary{sfx}.json"), "w") as f:
         json.dump(summary, f, indent=1)
     print(json.dumps(summary, indent=1))
